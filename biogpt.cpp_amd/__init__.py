@@ -1,0 +1,232 @@
+"""Host-side Python mirror of the reference's model-library interface, bound over the C-ABI.
+
+The reference is compiled C++ (biogpt.h:128-151); its drop-in C++ wrappers live in
+include/biogpt_compat.h.  This module is the thin ctypes stub used by tests/, bench.py and
+__graft_entry__.py -- it only marshals pointers and sizes into libbiogpt_hip.so
+(include/biogpt_hip.h).  No compute happens here and there is NO fallback: if the HIP library
+is missing or no GPU is present the calls raise.
+
+Names mirror the reference: biogpt_model_load() -> BiogptModel, biogpt_eval() -> .eval(),
+biogpt_model_quantize_internal()/quantize CLI -> quantize_file().
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbiogpt_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FTYPES = {"f32": 0, "f16": 1, "q4_0": 2, "q4_1": 3, "q8_0": 7, "q5_0": 8, "q5_1": 9}
+FTYPE_NAMES = {v: k for k, v in FTYPES.items()}
+# bytes per 32-element block in the FILE layout
+FILE_BLOCK_BYTES = {0: 128, 1: 64, 2: 18, 3: 20, 7: 34, 8: 22, 9: 24}
+
+
+class HParams(C.Structure):
+    """biogpt_hparams (biogpt.h:25-35) in file order + n_merges as found in the file."""
+    _fields_ = [("n_vocab", C.c_int32), ("n_layer", C.c_int32), ("n_head", C.c_int32),
+                ("n_positions", C.c_int32), ("d_ff", C.c_int32), ("d_model", C.c_int32),
+                ("ftype", C.c_int32), ("n_merges", C.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+BIOGPT_BASE = dict(n_vocab=42384, n_layer=24, n_head=16, n_positions=1024, d_ff=4096, d_model=1024,
+                   ftype=0, n_merges=40000)
+
+
+class BiogptError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile libbiogpt_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "biogpt_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["make", "-C", CSRC, "-B", "all"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL, stderr=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+# every symbol include/biogpt_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("biogpt_hip_last_error", C.c_char_p, []),
+    ("biogpt_hip_version", C.c_char_p, []),
+    ("biogpt_hip_load", _P, [C.c_char_p, C.c_int, C.c_int]),
+    ("biogpt_hip_load_into", _P, [C.c_char_p, C.c_int, C.c_int, _P, C.c_size_t]),
+    ("biogpt_hip_attach", _P, [C.POINTER(HParams), C.c_int, _P, C.c_size_t]),
+    ("biogpt_hip_arena_bytes_for", C.c_size_t, [C.POINTER(HParams)]),
+    ("biogpt_hip_arena_ptr", _P, [_P]),
+    ("biogpt_hip_arena_bytes", C.c_size_t, [_P]),
+    ("biogpt_hip_free", None, [_P]),
+    ("biogpt_hip_get_hparams", C.c_int, [_P, C.POINTER(HParams)]),
+    ("biogpt_hip_n_tensors", C.c_int, [_P]),
+    ("biogpt_hip_vocab_token", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
+    ("biogpt_hip_merge", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
+    ("biogpt_hip_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("biogpt_hip_logits_device", _P, [_P]),
+    ("biogpt_hip_synchronize", C.c_int, [_P]),
+    ("biogpt_hip_eval_all", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("biogpt_hip_generate_greedy", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
+    ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
+    ("biogpt_hip_bench_matvec", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("biogpt_hip_bench_decode", C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(C.c_double)]),
+    ("biogpt_hip_quantize_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_write_synthetic", C.c_int, [C.c_char_p, C.POINTER(HParams), C.c_uint64]),
+]
+
+
+def lib():
+    """Load libbiogpt_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BiogptError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _err():
+    return lib().biogpt_hip_last_error().decode("utf-8", "replace")
+
+
+def quantize_file(src, dst, ftype):
+    """examples/quantize equivalent (quantize.cpp:8-135): ftype by name or ggml_ftype id."""
+    ft = FTYPES[ftype] if isinstance(ftype, str) else int(ftype)
+    if lib().biogpt_hip_quantize_file(os.fsencode(src), os.fsencode(dst), ft) != 0:
+        raise BiogptError(_err())
+
+
+def write_synthetic(path, seed=0x42494F47, **hparams):
+    """Write a seeded synthetic model file. hparams default to BioGPT-base."""
+    hp = HParams(**{**BIOGPT_BASE, **hparams})
+    if lib().biogpt_hip_write_synthetic(os.fsencode(path), C.byref(hp), C.c_uint64(seed)) != 0:
+        raise BiogptError(_err())
+    return hp
+
+
+def arena_bytes_for(hp):
+    return int(lib().biogpt_hip_arena_bytes_for(C.byref(hp)))
+
+
+class BiogptModel:
+    """biogpt_model + biogpt_vocab handle (biogpt.h:78-107, :37-48) living on one HIP device."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise BiogptError(_err())
+        self._h = handle
+        self.hparams = HParams()
+        lib().biogpt_hip_get_hparams(self._h, C.byref(self.hparams))
+        self.n_vocab = self.hparams.n_vocab
+        self.n_tensors = lib().biogpt_hip_n_tensors(self._h)
+
+    # -- biogpt_model_load (biogpt.h:128-132) --
+    @classmethod
+    def load(cls, fname, device=0, verbosity=0, arena=None, arena_bytes=0):
+        if arena is None:
+            return cls(lib().biogpt_hip_load(os.fsencode(fname), device, verbosity))
+        return cls(lib().biogpt_hip_load_into(os.fsencode(fname), device, verbosity, arena, arena_bytes))
+
+    @classmethod
+    def attach(cls, hparams, device, arena, arena_bytes):
+        return cls(lib().biogpt_hip_attach(C.byref(hparams), device, arena, arena_bytes))
+
+    # -- biogpt_eval (biogpt.h:145-151): logits of the last token --
+    def eval(self, tokens, n_past):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.n_vocab, dtype=np.float32)
+        if lib().biogpt_hip_eval(self._h, toks.ctypes.data, toks.size, int(n_past), out.ctypes.data) != 0:
+            raise BiogptError(_err())
+        return out
+
+    def eval_all(self, tokens, n_past):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty((toks.size, self.n_vocab), dtype=np.float32)
+        if lib().biogpt_hip_eval_all(self._h, toks.ctypes.data, toks.size, int(n_past), out.ctypes.data) != 0:
+            raise BiogptError(_err())
+        return out
+
+    def eval_device(self, tokens, n_past):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        if lib().biogpt_hip_eval_device(self._h, toks.ctypes.data, toks.size, int(n_past)) != 0:
+            raise BiogptError(_err())
+
+    def synchronize(self):
+        if lib().biogpt_hip_synchronize(self._h) != 0:
+            raise BiogptError(_err())
+
+    # -- main.cpp:91-151 with --top_k 1 --
+    def generate_greedy(self, prompt, n_predict, n_batch=8):
+        pr = np.ascontiguousarray(prompt, dtype=np.int32)
+        out = np.zeros(max(int(n_predict), 1), dtype=np.int32)
+        secs = C.c_double(0.0)
+        n = lib().biogpt_hip_generate_greedy(self._h, pr.ctypes.data, pr.size, int(n_batch), int(n_predict),
+                                             out.ctypes.data, C.byref(secs))
+        if n < 0:
+            raise BiogptError(_err())
+        return out[:n].copy(), secs.value
+
+    def read_kv(self, which, offset, count):
+        out = np.empty(int(count), dtype=np.float32)
+        if lib().biogpt_hip_read_kv(self._h, int(which), int(offset), int(count), out.ctypes.data) != 0:
+            raise BiogptError(_err())
+        return out
+
+    def bench_matvec(self, which, layer=0, reps=200):
+        secs, nbytes = C.c_double(0.0), C.c_double(0.0)
+        if lib().biogpt_hip_bench_matvec(self._h, int(which), int(layer), int(reps), C.byref(secs), C.byref(nbytes)) != 0:
+            raise BiogptError(_err())
+        return secs.value, nbytes.value
+
+    def bench_decode(self, n_past, reps=50):
+        secs = C.c_double(0.0)
+        if lib().biogpt_hip_bench_decode(self._h, int(n_past), int(reps), C.byref(secs)) != 0:
+            raise BiogptError(_err())
+        return secs.value
+
+    def vocab_token(self, i):
+        p, n = C.c_char_p(), C.c_int32()
+        if lib().biogpt_hip_vocab_token(self._h, int(i), C.byref(p), C.byref(n)) != 0:
+            raise IndexError(i)
+        return C.string_at(p, n.value)
+
+    @property
+    def arena(self):
+        return lib().biogpt_hip_arena_ptr(self._h), int(lib().biogpt_hip_arena_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            lib().biogpt_hip_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_bytes_per_token(hp, T):
+    """Algorithmic HBM bytes of one decoded token at context T:
+    W(type) + 2*L*T*D*4 (KV read) + 2*L*D*4 (KV write) + V*4 (logits)."""
+    D, F, V, L = hp.d_model, hp.d_ff, hp.n_vocab, hp.n_layer
+    bb = FILE_BLOCK_BYTES[hp.ftype] / 32.0
+    mats = L * (4 * D * D + 2 * D * F) * bb + V * D * bb
+    vecs = (L * (4 * D + 4 * D + F + D) + 2 * D) * 4
+    rows = 2 * D * bb
+    return mats + vecs + rows + 2 * L * T * D * 4 + 2 * L * D * 4 + V * 4

@@ -1,0 +1,853 @@
+// MI355X-native BioGPT decoder engine: weight arena + repack, launch sequence, hipGraph capture,
+// and the extern "C" entry points declared in include/biogpt_hip.h.
+//
+// Reference path replaced: biogpt_model_load (biogpt.cpp:27-453), biogpt_graph (:624-810),
+// biogpt_eval (:812-847) and the greedy decode loop of examples/main/main.cpp:91-151.
+//
+// Device memory (sized for 288 GB of HBM3E, nothing is streamed or paged):
+//   arena     all weights, repacked to the SoA block layout of kernels.hip.h, plus the two fp16
+//             tables; ONE contiguous allocation so that a multi-GPU launcher can broadcast it with a
+//             single RCCL collective
+//   memory_k / memory_v   F32 [n_layer][n_positions][d_model], as biogpt.cpp:331-335 (F4)
+//   scratch   x, x1, q, att [n_positions][d_model], h [n_positions][d_ff], logits
+//   state     DevState + token ring (kernels read n_past / ids from HBM so the captured decode graph
+//             advances itself)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host_common.h"
+#include "kernels.hip.h"
+#include "model_file.h"
+#include "quant_host.h"
+
+using namespace bg;
+
+#define HIP_TRY(ret, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) BG_FAIL(ret, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
+
+// ---- arena plan -----------------------------------------------------------------------------------
+struct MatSlot {  // offsets of one (possibly row-fused) matrix inside the arena
+    int32_t type = 0;
+    int64_t M = 0, K = 0;
+    size_t qs = 0, sc = 0, qh = 0;
+    size_t qs_bytes = 0, sc_bytes = 0, qh_bytes = 0;
+};
+
+struct LayerSlots {
+    MatSlot qkv, o, fc1, fc2;
+    size_t qkv_b, o_b, ln0_w, ln0_b, ln1_w, ln1_b, fc1_b, fc2_b;
+};
+
+struct ArenaPlan {
+    MatSlot lm_head, embed_tokens, embed_pos;
+    size_t ln_w = 0, ln_b = 0, gelu_tab = 0, exp_tab = 0;
+    std::vector<LayerSlots> layers;
+    size_t total = 0;
+};
+
+size_t unit_bytes_qs(int32_t t, int64_t k) {  // bytes of the qs stream per row
+    switch (t) {
+        case T_F32: return (size_t)k * 4;
+        case T_F16: return (size_t)k * 2;
+        case T_Q8_0: return (size_t)(k / QK) * 32;
+        default: return (size_t)(k / QK) * 16;
+    }
+}
+size_t unit_bytes_sc(int32_t t, int64_t k) {
+    switch (t) {
+        case T_Q4_0: case T_Q5_0: case T_Q8_0: return (size_t)(k / QK) * 2;
+        case T_Q4_1: case T_Q5_1: return (size_t)(k / QK) * 4;
+        default: return 0;
+    }
+}
+size_t unit_bytes_qh(int32_t t, int64_t k) { return (t == T_Q5_0 || t == T_Q5_1) ? (size_t)(k / QK) * 4 : 0; }
+
+ArenaPlan plan_arena(const biogpt_hip_hparams &hp, int64_t pos_rows) {
+    ArenaPlan pl;
+    const int32_t wt = ftype_to_type(hp.ftype);
+    const int64_t D = hp.d_model, F = hp.d_ff, V = hp.n_vocab;
+    size_t off = 0;
+    auto mat = [&](MatSlot &m, int64_t M, int64_t K) {
+        m.type = wt; m.M = M; m.K = K;
+        m.qs_bytes = unit_bytes_qs(wt, K) * (size_t)M;
+        m.sc_bytes = unit_bytes_sc(wt, K) * (size_t)M;
+        m.qh_bytes = unit_bytes_qh(wt, K) * (size_t)M;
+        m.qs = off; off = align_up(off + m.qs_bytes);
+        m.sc = off; off = align_up(off + m.sc_bytes);
+        m.qh = off; off = align_up(off + m.qh_bytes);
+    };
+    auto vec = [&](size_t &slot, int64_t n) { slot = off; off = align_up(off + (size_t)n * 4); };
+    mat(pl.embed_tokens, V, D);
+    mat(pl.embed_pos, pos_rows, D);
+    pl.layers.resize((size_t)hp.n_layer);
+    for (auto &L : pl.layers) {
+        vec(L.ln0_w, D); vec(L.ln0_b, D);
+        mat(L.qkv, 3 * D, D); vec(L.qkv_b, 3 * D);
+        mat(L.o, D, D); vec(L.o_b, D);
+        vec(L.ln1_w, D); vec(L.ln1_b, D);
+        mat(L.fc1, F, D); vec(L.fc1_b, F);
+        mat(L.fc2, D, F); vec(L.fc2_b, D);
+    }
+    vec(pl.ln_w, D); vec(pl.ln_b, D);
+    mat(pl.lm_head, V, D);
+    pl.gelu_tab = off; off = align_up(off + 65536 * 2);
+    pl.exp_tab = off; off = align_up(off + 65536 * 2);
+    pl.total = off;
+    return pl;
+}
+
+// ---- repack one tensor (file layout -> SoA device layout) into host staging buffers ---------------
+void repack_rows(int32_t type, const uint8_t *src, int64_t rows, int64_t K, uint8_t *qs, uint8_t *sc, uint8_t *qh) {
+    if (type == T_F32 || type == T_F16) {
+        std::memcpy(qs, src, file_row_bytes(type, K) * (size_t)rows);
+        return;
+    }
+    const size_t bb = file_block_bytes(type);
+    const int64_t nblocks = rows * (K / QK);
+    const unsigned nw = nblocks > (1 << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nw; w++) {
+        const int64_t b0 = nblocks * w / nw, b1 = nblocks * (w + 1) / nw;
+        auto job = [=] {
+            for (int64_t b = b0; b < b1; b++) {
+                const uint8_t *p = src + (size_t)b * bb;
+                switch (type) {
+                    case T_Q4_0: std::memcpy(sc + b * 2, p, 2); std::memcpy(qs + b * 16, p + 2, 16); break;
+                    case T_Q4_1: std::memcpy(sc + b * 4, p, 4); std::memcpy(qs + b * 16, p + 4, 16); break;
+                    case T_Q5_0: std::memcpy(sc + b * 2, p, 2); std::memcpy(qh + b * 4, p + 2, 4); std::memcpy(qs + b * 16, p + 6, 16); break;
+                    case T_Q5_1: std::memcpy(sc + b * 4, p, 4); std::memcpy(qh + b * 4, p + 4, 4); std::memcpy(qs + b * 16, p + 8, 16); break;
+                    case T_Q8_0: std::memcpy(sc + b * 2, p, 2); std::memcpy(qs + b * 32, p + 2, 32); break;
+                    default: break;
+                }
+            }
+        };
+        if (nw == 1) job(); else pool.emplace_back(job);
+    }
+    for (auto &t : pool) t.join();
+}
+
+inline float gelu_tanh_f32(float x) {  // ggml_gelu_f32 [SURVEY A.5]
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+int env_int(const char *name, int dflt) {
+    const char *s = std::getenv(name);
+    return s ? std::atoi(s) : dflt;
+}
+
+}  // namespace
+
+// ---- context ----------------------------------------------------------------------------------------
+struct biogpt_hip_ctx {
+    biogpt_hip_hparams hp{};
+    int device = 0;
+    int n_tensors = 0;
+    int64_t pos_rows = 0;
+    std::vector<std::string> vocab, merges;
+
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0;
+    bool owns_arena = false;
+    ArenaPlan plan;
+
+    float *memory_k = nullptr, *memory_v = nullptr;
+    float *x = nullptr, *x1 = nullptr, *q = nullptr, *att = nullptr, *h = nullptr;
+    float *logits = nullptr;      // [n_vocab]
+    float *logits_all = nullptr;  // lazily [n][n_vocab]
+    size_t logits_all_rows = 0;
+    float *pmax_val = nullptr;
+    int32_t *pmax_idx = nullptr;
+    int pmax_cap = 0;
+    bgk::DevState *state = nullptr;  // device
+    uint8_t *state_host = nullptr;   // pinned upload ring: STATE_SLOTS x (header + tokens)
+    size_t state_bytes = 0;
+    size_t slot_bytes = 0;
+    int slot_idx = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipGraphExec_t graph_step[2] = {nullptr, nullptr};  // [advance]
+    int lm_blocks = 0;
+    bool ready = false;  // weights present
+};
+
+namespace {
+
+bgk::DevMatrix dev_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
+    bgk::DevMatrix d;
+    d.qs = c->arena + m.qs;
+    d.sc = c->arena + m.sc;
+    d.qh = reinterpret_cast<const uint32_t *>(c->arena + m.qh);
+    d.type = m.type;
+    d.M = (int32_t)m.M;
+    d.K = (int32_t)m.K;
+    return d;
+}
+const float *dev_vec(const biogpt_hip_ctx *c, size_t off) { return reinterpret_cast<const float *>(c->arena + off); }
+
+struct MvShape { int upr, lpr_log2, nit, rpw, nwaves, grid; };
+
+MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs) {
+    MvShape s;
+    const int elems = (type == T_F32) ? 4 : (type == T_F16) ? 8 : 32;
+    s.upr = (int)(K / elems);
+    const int lpr = std::min(64, pow2ceil(s.upr));
+    s.lpr_log2 = ilog2(lpr);
+    s.nit = (s.upr + lpr - 1) / lpr;
+    const int rps = 64 / lpr;
+    // waves per workgroup: as many as possible (up to 4) while keeping >= target_wgs workgroups
+    int nw = 4;
+    while (nw > 1 && (M + (int64_t)nw * rps - 1) / ((int64_t)nw * rps) < target_wgs) nw >>= 1;
+    int steps = 1;
+    const int max_wgs = env_int("BIOGPT_HIP_MAX_WGS", 1024);
+    while ((M + (int64_t)nw * rps * steps - 1) / ((int64_t)nw * rps * steps) > max_wgs) steps++;
+    s.nwaves = nw;
+    s.rpw = rps * steps;
+    s.grid = (int)((M + (int64_t)nw * s.rpw - 1) / ((int64_t)nw * s.rpw));
+    return s;
+}
+
+template <int WT, int PRO, int EPI>
+hipError_t launch_mv_nc(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
+    const bool quant = bgk::TypeInfo<WT>::quant;
+    constexpr int NCW = bgk::TypeInfo<WT>::quant ? 8 : 4;
+    if (p.N == 1) {
+        const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, 1);
+        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, 1>), dim3(s.grid, 1), dim3(s.nwaves * 64), sm, st, p);
+    } else {
+        const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NCW);
+        const int gy = (p.N + NCW - 1) / NCW;
+        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NCW>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+    }
+    (void)quant;
+    return hipGetLastError();
+}
+
+template <int PRO, int EPI>
+hipError_t launch_mv(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
+    switch (p.W.type) {
+        case T_F32: return launch_mv_nc<bgk::W_F32, PRO, EPI>(p, s, st);
+        case T_F16: return launch_mv_nc<bgk::W_F16, PRO, EPI>(p, s, st);
+        case T_Q4_0: return launch_mv_nc<bgk::W_Q4_0, PRO, EPI>(p, s, st);
+        case T_Q4_1: return launch_mv_nc<bgk::W_Q4_1, PRO, EPI>(p, s, st);
+        case T_Q5_0: return launch_mv_nc<bgk::W_Q5_0, PRO, EPI>(p, s, st);
+        case T_Q5_1: return launch_mv_nc<bgk::W_Q5_1, PRO, EPI>(p, s, st);
+        case T_Q8_0: return launch_mv_nc<bgk::W_Q8_0, PRO, EPI>(p, s, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvShape &s) {
+    bgk::MatvecParams p{};
+    p.W = dev_matrix(c, m);
+    p.upr = s.upr; p.lpr_log2 = s.lpr_log2; p.nit = s.nit; p.rpw = s.rpw;
+    p.eps = 1e-5f;  // NORM_EPS biogpt.cpp:24
+    p.D = c->hp.d_model;
+    p.st = c->state;
+    p.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+    return p;
+}
+
+int target_wgs() { return env_int("BIOGPT_HIP_TARGET_WGS", 256); }
+
+// The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
+// lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
+bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
+    const auto &hp = c->hp;
+    const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
+    const int dk = D / H;
+    hipStream_t st = c->stream;
+    const int tw = target_wgs();
+
+    hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
+                       dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
+                       sqrtf((float)D), c->x, D);
+    for (int l = 0; l < hp.n_layer; l++) {
+        const LayerSlots &L = c->plan.layers[(size_t)l];
+        {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
+            const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw);
+            bgk::MatvecParams p = mv_base(c, L.qkv, s);
+            p.x = c->x; p.ldx = D; p.N = N;
+            p.ln_w = dev_vec(c, L.ln0_w); p.ln_b = dev_vec(c, L.ln0_b);
+            p.bias = dev_vec(c, L.qkv_b);
+            p.q_out = c->q;
+            p.kcache = c->memory_k + (size_t)l * P * D;
+            p.vcache = c->memory_v + (size_t)l * P * D;
+            p.q_scale = 1.0f / sqrtf((float)dk);
+            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, st)));
+        }
+        {  // attention
+            bgk::AttnParams a{};
+            a.q = c->q; a.kcache = c->memory_k + (size_t)l * P * D; a.vcache = c->memory_v + (size_t)l * P * D;
+            a.out = c->att; a.st = c->state;
+            a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
+            a.N = N; a.D = D; a.dk = dk; a.P = P;
+            const int nt = 256;
+            hipLaunchKernelGGL(bgk::attn_kernel, dim3(H, N), dim3(nt), bgk::attn_smem_bytes(P, dk, nt), st, a);
+        }
+        {  // out_proj + bias + residual
+            const MvShape s = mv_shape(L.o.type, L.o.M, L.o.K, tw);
+            bgk::MatvecParams p = mv_base(c, L.o, s);
+            p.x = c->att; p.ldx = D; p.N = N;
+            p.bias = dev_vec(c, L.o_b);
+            p.resid = c->x; p.ldr = D; p.out = c->x1; p.ldo = D;
+            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+        }
+        {  // LN1 + fc1 + bias + GELU
+            const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
+            bgk::MatvecParams p = mv_base(c, L.fc1, s);
+            p.x = c->x1; p.ldx = D; p.N = N;
+            p.ln_w = dev_vec(c, L.ln1_w); p.ln_b = dev_vec(c, L.ln1_b);
+            p.bias = dev_vec(c, L.fc1_b);
+            p.out = c->h; p.ldo = F;
+            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, st)));
+        }
+        {  // fc2 + bias + residual
+            const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw);
+            bgk::MatvecParams p = mv_base(c, L.fc2, s);
+            p.x = c->h; p.ldx = F; p.N = N;
+            p.bias = dev_vec(c, L.fc2_b);
+            p.resid = c->x1; p.ldr = D; p.out = c->x; p.ldo = D;
+            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+        }
+    }
+    {  // final LayerNorm + lm_head; only the rows that are returned (F8)
+        const MatSlot &m = c->plan.lm_head;
+        const MvShape s = mv_shape(m.type, m.M, m.K, tw);
+        bgk::MatvecParams p = mv_base(c, m, s);
+        p.ln_w = dev_vec(c, c->plan.ln_w); p.ln_b = dev_vec(c, c->plan.ln_b);
+        p.ldx = D; p.ldo = V;
+        if (all_rows) {
+            p.x = c->x; p.N = N; p.out = c->logits_all;
+        } else {
+            p.x = c->x + (size_t)(N - 1) * D; p.N = 1; p.out = c->logits;
+            if (s.grid > c->pmax_cap) BG_FAIL(false, "internal: arg-max partial buffer too small (%d > %d)", s.grid, c->pmax_cap);
+            p.pmax_val = c->pmax_val; p.pmax_idx = c->pmax_idx;
+            c->lm_blocks = s.grid;
+        }
+        HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, st)));
+    }
+    return true;
+}
+
+bool enqueue_argmax(biogpt_hip_ctx *c, int n_eval) {
+    hipLaunchKernelGGL(bgk::argmax_kernel, dim3(1), dim3(256), 0, c->stream, c->pmax_val, c->pmax_idx, c->lm_blocks,
+                       c->state, n_eval, c->hp.n_positions);
+    HIP_TRY(false, hipGetLastError());
+    return true;
+}
+
+constexpr int STATE_SLOTS = 64;
+
+// Async upload of {n_past, tokens} through a ring of pinned slots (a slot is only reused after the
+// stream has drained, so an in-flight copy never sees a half-written slot).
+bool upload_state(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past) {
+    if (c->slot_idx == STATE_SLOTS) {
+        HIP_TRY(false, hipStreamSynchronize(c->stream));
+        c->slot_idx = 0;
+    }
+    uint8_t *slot = c->state_host + (size_t)c->slot_idx++ * c->slot_bytes;
+    auto *hs = reinterpret_cast<bgk::DevState *>(slot);
+    hs->n_past = n_past;
+    hs->n_gen = 0;
+    hs->causal = env_int("BIOGPT_HIP_CAUSAL", 0);
+    hs->pad = 0;
+    std::memcpy(slot + sizeof(bgk::DevState), tokens, (size_t)n * 4);
+    HIP_TRY(false, hipMemcpyAsync(c->state, slot, sizeof(bgk::DevState) + (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    return true;
+}
+
+bool check_eval_args(const biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past) {
+    if (!c) BG_FAIL(false, "null context");
+    if (!c->ready) BG_FAIL(false, "model has no tensors loaded (empty model): cannot evaluate");
+    if (!tokens || n < 1) BG_FAIL(false, "no tokens to evaluate");
+    if (n_past < 0 || n_past + n > c->hp.n_positions)
+        BG_FAIL(false, "n_past (%d) + n_tokens (%d) exceeds n_positions (%d)", n_past, n, c->hp.n_positions);
+    for (int i = 0; i < n; i++)
+        if (tokens[i] < 0 || tokens[i] >= c->hp.n_vocab) BG_FAIL(false, "token id %d out of range [0, %d)", tokens[i], c->hp.n_vocab);
+    return true;
+}
+
+bool alloc_runtime(biogpt_hip_ctx *c) {
+    const auto &hp = c->hp;
+    const size_t P = (size_t)hp.n_positions, D = (size_t)hp.d_model, F = (size_t)hp.d_ff, V = (size_t)hp.n_vocab;
+    const size_t kv = (size_t)hp.n_layer * P * D * 4;
+    HIP_TRY(false, hipMalloc(&c->memory_k, kv));
+    HIP_TRY(false, hipMalloc(&c->memory_v, kv));
+    HIP_TRY(false, hipMemset(c->memory_k, 0, kv));
+    HIP_TRY(false, hipMemset(c->memory_v, 0, kv));
+    HIP_TRY(false, hipMalloc(&c->x, P * D * 4));
+    HIP_TRY(false, hipMalloc(&c->x1, P * D * 4));
+    HIP_TRY(false, hipMalloc(&c->q, P * D * 4));
+    HIP_TRY(false, hipMalloc(&c->att, P * D * 4));
+    HIP_TRY(false, hipMalloc(&c->h, P * F * 4));
+    HIP_TRY(false, hipMalloc(&c->logits, V * 4));
+    c->pmax_cap = 4096;
+    HIP_TRY(false, hipMalloc(&c->pmax_val, (size_t)c->pmax_cap * 4));
+    HIP_TRY(false, hipMalloc(&c->pmax_idx, (size_t)c->pmax_cap * 4));
+    c->state_bytes = sizeof(bgk::DevState) + 2 * P * 4;
+    HIP_TRY(false, hipMalloc(&c->state, c->state_bytes));
+    HIP_TRY(false, hipMemset(c->state, 0, c->state_bytes));
+    c->slot_bytes = (sizeof(bgk::DevState) + P * 4 + 63) & ~(size_t)63;
+    HIP_TRY(false, hipHostMalloc(reinterpret_cast<void **>(&c->state_host), c->slot_bytes * STATE_SLOTS, hipHostMallocDefault));
+    std::memset(c->state_host, 0, c->slot_bytes * STATE_SLOTS);
+    HIP_TRY(false, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(false, hipEventCreate(&c->ev0));
+    HIP_TRY(false, hipEventCreate(&c->ev1));
+    return true;
+}
+
+bool select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) BG_FAIL(false, "no HIP device available (%s): this engine has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n) BG_FAIL(false, "HIP device %d out of range (found %d)", device, n);
+    HIP_TRY(false, hipSetDevice(device));
+    return true;
+}
+
+// read every tensor, validate against the expected directory (biogpt.cpp:394-417), repack, upload
+bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
+    const auto &hp = c->hp;
+    const int32_t wt = ftype_to_type(hp.ftype);
+    const int64_t D = hp.d_model;
+    const auto expected = expected_tensors(hp);
+    // unknown tensors are an error (biogpt.cpp:394-397)
+    for (const auto &t : mf.tensors) {
+        bool known = false;
+        for (const auto &e : expected) if (e.name == t.name) { known = true; break; }
+        if (!known) BG_FAIL(false, "unknown tensor '%s' in model file", t.name.c_str());
+    }
+    if (mf.tensors.size() != expected.size())
+        BG_FAIL(false, "ERROR not all tensors loaded from model file - expected %zu, got %zu", expected.size(), mf.tensors.size());
+
+    std::vector<uint8_t> raw, qs, sc, qh;
+    auto put_matrix = [&](const std::string &name, const MatSlot &slot, int64_t row0, int64_t rows, int64_t K) -> bool {
+        const TensorEntry *t = mf.find(name);
+        if (!t) BG_FAIL(false, "ERROR not all tensors loaded from model file - missing '%s'", name.c_str());
+        if (t->ne0 != K || t->ne1 != rows)
+            BG_FAIL(false, "tensor '%s' has wrong shape in model file: got [%lld, %lld], expected [%lld, %lld]", name.c_str(),
+                    (long long)t->ne0, (long long)t->ne1, (long long)K, (long long)rows);
+        if (t->type != wt) BG_FAIL(false, "tensor '%s' has wrong size in model file: type %s, expected %s", name.c_str(), type_name(t->type), type_name(wt));
+        raw.resize(t->nbytes);
+        if (!mf.read_payload(*t, raw.data())) return false;
+        const size_t qb = unit_bytes_qs(wt, K) * (size_t)rows, sb = unit_bytes_sc(wt, K) * (size_t)rows, hb = unit_bytes_qh(wt, K) * (size_t)rows;
+        qs.resize(qb); sc.resize(sb + 4); qh.resize(hb + 4);
+        repack_rows(wt, raw.data(), rows, K, qs.data(), sc.data(), qh.data());
+        HIP_TRY(false, hipMemcpy(c->arena + slot.qs + unit_bytes_qs(wt, K) * (size_t)row0, qs.data(), qb, hipMemcpyHostToDevice));
+        if (sb) HIP_TRY(false, hipMemcpy(c->arena + slot.sc + unit_bytes_sc(wt, K) * (size_t)row0, sc.data(), sb, hipMemcpyHostToDevice));
+        if (hb) HIP_TRY(false, hipMemcpy(c->arena + slot.qh + unit_bytes_qh(wt, K) * (size_t)row0, qh.data(), hb, hipMemcpyHostToDevice));
+        return true;
+    };
+    auto put_vec = [&](const std::string &name, size_t off, int64_t elem0, int64_t n) -> bool {
+        const TensorEntry *t = mf.find(name);
+        if (!t) BG_FAIL(false, "ERROR not all tensors loaded from model file - missing '%s'", name.c_str());
+        if (t->ne0 != n || t->ne1 != 1)
+            BG_FAIL(false, "tensor '%s' has wrong shape in model file: got [%lld, %lld], expected [%lld, 1]", name.c_str(),
+                    (long long)t->ne0, (long long)t->ne1, (long long)n);
+        if (t->type != T_F32) BG_FAIL(false, "tensor '%s' has wrong size in model file: type %s, expected f32", name.c_str(), type_name(t->type));
+        raw.resize(t->nbytes);
+        if (!mf.read_payload(*t, raw.data())) return false;
+        HIP_TRY(false, hipMemcpy(c->arena + off + (size_t)elem0 * 4, raw.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        return true;
+    };
+
+    const ArenaPlan &pl = c->plan;
+    if (!put_matrix("biogpt.embed_tokens.weight", pl.embed_tokens, 0, hp.n_vocab, D)) return false;
+    if (!put_matrix("biogpt.embed_positions.weight", pl.embed_pos, 0, c->pos_rows, D)) return false;
+    for (int l = 0; l < hp.n_layer; l++) {
+        const LayerSlots &L = pl.layers[(size_t)l];
+        const std::string p = "biogpt.layers." + std::to_string(l) + ".";
+        const char *proj[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int k = 0; k < 3; k++) {
+            if (!put_matrix(p + "self_attn." + proj[k] + ".weight", L.qkv, (int64_t)k * D, D, D)) return false;
+            if (!put_vec(p + "self_attn." + proj[k] + ".bias", L.qkv_b, (int64_t)k * D, D)) return false;
+        }
+        if (!put_matrix(p + "self_attn.out_proj.weight", L.o, 0, D, D)) return false;
+        if (!put_vec(p + "self_attn.out_proj.bias", L.o_b, 0, D)) return false;
+        if (!put_vec(p + "self_attn_layer_norm.weight", L.ln0_w, 0, D)) return false;
+        if (!put_vec(p + "self_attn_layer_norm.bias", L.ln0_b, 0, D)) return false;
+        if (!put_vec(p + "final_layer_norm.weight", L.ln1_w, 0, D)) return false;
+        if (!put_vec(p + "final_layer_norm.bias", L.ln1_b, 0, D)) return false;
+        if (!put_matrix(p + "fc1.weight", L.fc1, 0, hp.d_ff, D)) return false;
+        if (!put_vec(p + "fc1.bias", L.fc1_b, 0, hp.d_ff)) return false;
+        if (!put_matrix(p + "fc2.weight", L.fc2, 0, D, hp.d_ff)) return false;
+        if (!put_vec(p + "fc2.bias", L.fc2_b, 0, D)) return false;
+    }
+    if (!put_vec("biogpt.layer_norm.weight", pl.ln_w, 0, D)) return false;
+    if (!put_vec("biogpt.layer_norm.bias", pl.ln_b, 0, D)) return false;
+    if (!put_matrix("output_projection.weight", pl.lm_head, 0, hp.n_vocab, D)) return false;
+
+    // fp16 tables, built the way ggml_init builds them [SURVEY A.5]
+    std::vector<uint16_t> tg(65536), te(65536);
+    for (uint32_t i = 0; i < 65536; i++) {
+        const float f = f16_to_f32((uint16_t)i);
+        tg[i] = f32_to_f16(gelu_tanh_f32(f));
+        te[i] = f32_to_f16(expf(f));
+    }
+    HIP_TRY(false, hipMemcpy(c->arena + pl.gelu_tab, tg.data(), 65536 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(false, hipMemcpy(c->arena + pl.exp_tab, te.data(), 65536 * 2, hipMemcpyHostToDevice));
+    return true;
+}
+
+void destroy(biogpt_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto &g : c->graph_step) if (g) (void)hipGraphExecDestroy(g);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->owns_arena && c->arena) (void)hipFree(c->arena);
+    for (void *p : {(void *)c->memory_k, (void *)c->memory_v, (void *)c->x, (void *)c->x1, (void *)c->q, (void *)c->att,
+                    (void *)c->h, (void *)c->logits, (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
+        if (p) (void)hipFree(p);
+    if (c->state_host) (void)hipHostFree(c->state_host);
+    delete c;
+}
+
+biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ext_arena, size_t ext_bytes) {
+    clear_error();
+    if (!fname) BG_FAIL(nullptr, "null file name");
+    fprintf(stderr, "%s: loading model from '%s'\n", "biogpt_hip_load", fname);
+    ModelFile mf;
+    if (!mf.open(fname)) return nullptr;
+    if (!select_device(device)) return nullptr;
+
+    std::unique_ptr<biogpt_hip_ctx, void (*)(biogpt_hip_ctx *)> c(new biogpt_hip_ctx(), destroy);
+    c->hp = mf.hp;
+    c->device = device;
+    c->n_tensors = (int)mf.tensors.size();
+    c->vocab = mf.vocab;
+    c->merges = mf.merges;
+    const auto &hp = c->hp;
+    if (verbosity > 0) {
+        fprintf(stderr, "biogpt_hip_load: n_vocab = %d d_ff = %d d_model = %d n_positions = %d n_head = %d n_layer = %d ftype = %d n_merges = %d\n",
+                hp.n_vocab, hp.d_ff, hp.d_model, hp.n_positions, hp.n_head, hp.n_layer, hp.ftype, hp.n_merges);
+    }
+    const int dk = hp.d_model / hp.n_head;
+    if (hp.d_model % 32 != 0 || hp.d_ff % 32 != 0) BG_FAIL(nullptr, "d_model (%d) and d_ff (%d) must be multiples of 32", hp.d_model, hp.d_ff);
+    if (dk % 4 != 0 || (dk & (dk - 1)) != 0 || dk > 256) BG_FAIL(nullptr, "head size %d unsupported (needs a power of two in [4, 256])", dk);
+
+    // F5: size embed_positions by what the file holds (must cover n_positions + 2 rows)
+    c->pos_rows = (int64_t)hp.n_positions + 2;
+    if (const TensorEntry *pe = mf.find("biogpt.embed_positions.weight")) {
+        if (pe->ne1 < c->pos_rows)
+            BG_FAIL(nullptr, "tensor 'biogpt.embed_positions.weight' has wrong shape in model file: got [%lld, %lld], expected [%d, >=%lld]",
+                    (long long)pe->ne0, (long long)pe->ne1, hp.d_model, (long long)c->pos_rows);
+        c->pos_rows = pe->ne1;
+    }
+    c->plan = plan_arena(hp, c->pos_rows);
+    if (ext_arena) {
+        if (ext_bytes < c->plan.total) BG_FAIL(nullptr, "external arena too small: %zu < %zu bytes", ext_bytes, c->plan.total);
+        c->arena = static_cast<uint8_t *>(ext_arena);
+        c->owns_arena = false;
+    } else {
+        HIP_TRY(nullptr, hipMalloc(reinterpret_cast<void **>(&c->arena), c->plan.total));
+        c->owns_arena = true;
+    }
+    c->arena_bytes = c->plan.total;
+    if (!alloc_runtime(c.get())) return nullptr;
+
+    if (mf.tensors.empty()) {  // biogpt.cpp:442-443
+        fprintf(stderr, "biogpt_hip_load: WARN no tensors loaded from model file - assuming empty model for testing\n");
+        c->ready = false;
+        return c.release();
+    }
+    if (!upload_weights(c.get(), mf)) return nullptr;
+    HIP_TRY(nullptr, hipDeviceSynchronize());
+    c->ready = true;
+    if (verbosity > 0)
+        fprintf(stderr, "biogpt_hip_load: weight arena = %.2f MB, KV cache = %.2f MB, %d tensors\n", c->plan.total / 1048576.0,
+                2.0 * hp.n_layer * hp.n_positions * hp.d_model * 4 / 1048576.0, c->n_tensors);
+    return c.release();
+}
+
+bool ensure_graph(biogpt_hip_ctx *c, int advance) {
+    if (c->graph_step[advance]) return true;
+    hipGraph_t g = nullptr;
+    HIP_TRY(false, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    bool ok = enqueue_forward(c, 1, false) && enqueue_argmax(c, advance);
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
+    HIP_TRY(false, e);
+    HIP_TRY(false, hipGraphInstantiate(&c->graph_step[advance], g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    return true;
+}
+
+}  // namespace
+
+// ======================================== extern "C" ================================================
+extern "C" {
+
+const char *biogpt_hip_last_error(void) { return last_error(); }
+const char *biogpt_hip_version(void) { return "biogpt-hip gfx950 r1"; }
+
+biogpt_hip_ctx *biogpt_hip_load(const char *fname, int device, int verbosity) { return load_impl(fname, device, verbosity, nullptr, 0); }
+
+biogpt_hip_ctx *biogpt_hip_load_into(const char *fname, int device, int verbosity, void *device_arena, size_t arena_bytes) {
+    if (!device_arena) BG_FAIL(nullptr, "null arena");
+    return load_impl(fname, device, verbosity, device_arena, arena_bytes);
+}
+
+size_t biogpt_hip_arena_bytes_for(const biogpt_hip_hparams *hp) {
+    if (!hp || ftype_to_type(hp->ftype) == T_INVALID) return 0;
+    return plan_arena(*hp, (int64_t)hp->n_positions + 2).total;
+}
+
+biogpt_hip_ctx *biogpt_hip_attach(const biogpt_hip_hparams *hp, int device, void *device_arena, size_t arena_bytes) {
+    clear_error();
+    if (!hp || !device_arena) BG_FAIL(nullptr, "null argument");
+    if (ftype_to_type(hp->ftype) == T_INVALID) BG_FAIL(nullptr, "bad ftype value %d", hp->ftype);
+    if (!select_device(device)) return nullptr;
+    std::unique_ptr<biogpt_hip_ctx, void (*)(biogpt_hip_ctx *)> c(new biogpt_hip_ctx(), destroy);
+    c->hp = *hp;
+    c->device = device;
+    c->pos_rows = (int64_t)hp->n_positions + 2;
+    c->plan = plan_arena(*hp, c->pos_rows);
+    if (arena_bytes < c->plan.total) BG_FAIL(nullptr, "external arena too small: %zu < %zu bytes", arena_bytes, c->plan.total);
+    c->arena = static_cast<uint8_t *>(device_arena);
+    c->arena_bytes = c->plan.total;
+    c->owns_arena = false;
+    c->n_tensors = 5 + 16 * hp->n_layer;
+    if (!alloc_runtime(c.get())) return nullptr;
+    c->ready = true;
+    return c.release();
+}
+
+void *biogpt_hip_arena_ptr(biogpt_hip_ctx *ctx) { return ctx ? ctx->arena : nullptr; }
+size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+void biogpt_hip_free(biogpt_hip_ctx *ctx) { destroy(ctx); }
+
+int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out) {
+    if (!ctx || !out) BG_FAIL(-1, "null argument");
+    *out = ctx->hp;
+    return 0;
+}
+int biogpt_hip_n_tensors(const biogpt_hip_ctx *ctx) { return ctx ? ctx->n_tensors : -1; }
+
+int biogpt_hip_vocab_token(const biogpt_hip_ctx *ctx, int32_t id, const char **bytes, int32_t *len) {
+    if (!ctx || id < 0 || (size_t)id >= ctx->vocab.size()) return -1;
+    if (bytes) *bytes = ctx->vocab[(size_t)id].data();
+    if (len) *len = (int32_t)ctx->vocab[(size_t)id].size();
+    return 0;
+}
+int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes, int32_t *len) {
+    if (!ctx || rank < 0 || (size_t)rank >= ctx->merges.size()) return -1;
+    if (bytes) *bytes = ctx->merges[(size_t)rank].data();
+    if (len) *len = (int32_t)ctx->merges[(size_t)rank].size();
+    return 0;
+}
+
+int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) {
+    clear_error();
+    if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!upload_state(ctx, tokens, n, n_past)) return -2;
+    if (!enqueue_forward(ctx, n, false)) return -2;
+    return 0;
+}
+
+const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) { return ctx ? ctx->logits : nullptr; }
+
+int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
+    if (!ctx) BG_FAIL(-1, "null context");
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
+    if (!logits_out) BG_FAIL(-1, "null logits buffer");
+    const int rc = biogpt_hip_eval_device(ctx, tokens, n, n_past);
+    if (rc) return rc;
+    HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
+    clear_error();
+    if (!logits_out) BG_FAIL(-1, "null logits buffer");
+    if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    if ((size_t)n > ctx->logits_all_rows) {
+        if (ctx->logits_all) (void)hipFree(ctx->logits_all);
+        ctx->logits_all = nullptr;
+        HIP_TRY(-2, hipMalloc(&ctx->logits_all, (size_t)n * ctx->hp.n_vocab * 4));
+        ctx->logits_all_rows = (size_t)n;
+    }
+    if (!upload_state(ctx, tokens, n, n_past)) return -2;
+    if (!enqueue_forward(ctx, n, true)) return -2;
+    HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits_all, (size_t)n * ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_batch,
+                               int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+    clear_error();
+    if (!ctx || !prompt || !out_ids) BG_FAIL(-1, "null argument");
+    if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
+    if (n_prompt < 1) BG_FAIL(-1, "empty prompt");
+    if (!check_eval_args(ctx, prompt, n_prompt, 0)) return -1;
+    n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);  // main.cpp:82
+    if (n_predict <= 0) return 0;
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    const bool use_graph = env_int("BIOGPT_HIP_NO_GRAPH", 0) == 0;
+    if (use_graph && !ensure_graph(ctx, 1)) return -2;
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+
+    const auto t0 = std::chrono::steady_clock::now();
+    int n_past = 0;
+    while (n_past < n_prompt) {  // prompt ingestion in chunks of n_batch (main.cpp:129-137)
+        const int n = std::min(n_batch, n_prompt - n_past);
+        if (!upload_state(ctx, prompt + n_past, n, n_past)) return -2;
+        if (!enqueue_forward(ctx, n, false)) return -2;
+        if (n_past + n == n_prompt && !enqueue_argmax(ctx, n)) return -2;  // first sampled token
+        n_past += n;
+    }
+    for (int k = 1; k < n_predict; k++) {  // one eval + one sample per further token
+        if (use_graph) {
+            HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1], ctx->stream));
+        } else {
+            if (!enqueue_forward(ctx, 1, false) || !enqueue_argmax(ctx, 1)) return -2;
+        }
+    }
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+    HIP_TRY(-2, hipMemcpy(out_ids, reinterpret_cast<uint8_t *>(ctx->state) + sizeof(bgk::DevState) + (size_t)ctx->hp.n_positions * 4,
+                          (size_t)n_predict * 4, hipMemcpyDeviceToHost));
+    return n_predict;
+}
+
+int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t count, float *out) {
+    if (!ctx || !out) BG_FAIL(-1, "null argument");
+    const size_t total = (size_t)ctx->hp.n_layer * ctx->hp.n_positions * ctx->hp.d_model;
+    if (offset + count > total) BG_FAIL(-1, "KV range out of bounds");
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(-2, hipMemcpy(out, (which ? ctx->memory_v : ctx->memory_k) + offset, count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
+    clear_error();
+    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
+    if (reps < 1 || (which != 4 && (layer < 0 || layer >= ctx->hp.n_layer))) BG_FAIL(-1, "bad argument");
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    const auto &hp = ctx->hp;
+    const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, P = hp.n_positions;
+    const int tw = target_wgs();
+    // cycling through the layers defeats L2 residency of one matrix; the whole model still
+    // fits the 256 MiB Infinity Cache -- stated in DESIGN.md
+    auto launch = [&](int l) -> bool {
+        const LayerSlots &L = ctx->plan.layers[(size_t)(hp.n_layer ? l % hp.n_layer : 0)];
+        if (which == 0) {
+            const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
+            bgk::MatvecParams p = mv_base(ctx, L.fc1, s);
+            p.x = ctx->x1; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, L.ln1_w); p.ln_b = dev_vec(ctx, L.ln1_b);
+            p.bias = dev_vec(ctx, L.fc1_b); p.out = ctx->h; p.ldo = F;
+            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, ctx->stream)));
+        } else if (which == 1) {
+            const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw);
+            bgk::MatvecParams p = mv_base(ctx, L.fc2, s);
+            p.x = ctx->h; p.ldx = F; p.N = 1; p.bias = dev_vec(ctx, L.fc2_b);
+            p.resid = ctx->x1; p.ldr = D; p.out = ctx->x; p.ldo = D;
+            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
+        } else if (which == 2) {
+            const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw);
+            bgk::MatvecParams p = mv_base(ctx, L.qkv, s);
+            p.x = ctx->x; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, L.ln0_w); p.ln_b = dev_vec(ctx, L.ln0_b);
+            p.bias = dev_vec(ctx, L.qkv_b); p.q_out = ctx->q;
+            p.kcache = ctx->memory_k + (size_t)(l % hp.n_layer) * P * D; p.vcache = ctx->memory_v + (size_t)(l % hp.n_layer) * P * D;
+            p.q_scale = 0.125f;
+            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, ctx->stream)));
+        } else if (which == 3) {
+            const MvShape s = mv_shape(L.o.type, L.o.M, L.o.K, tw);
+            bgk::MatvecParams p = mv_base(ctx, L.o, s);
+            p.x = ctx->att; p.ldx = D; p.N = 1; p.bias = dev_vec(ctx, L.o_b);
+            p.resid = ctx->x; p.ldr = D; p.out = ctx->x1; p.ldo = D;
+            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
+        } else {
+            const MatSlot &m = ctx->plan.lm_head;
+            const MvShape s = mv_shape(m.type, m.M, m.K, tw);
+            bgk::MatvecParams p = mv_base(ctx, m, s);
+            p.x = ctx->x; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, ctx->plan.ln_w); p.ln_b = dev_vec(ctx, ctx->plan.ln_b);
+            p.out = ctx->logits; p.ldo = V; p.pmax_val = ctx->pmax_val; p.pmax_idx = ctx->pmax_idx;
+            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, ctx->stream)));
+        }
+        return true;
+    };
+    const int32_t tok0 = 0;
+    if (!upload_state(ctx, &tok0, 1, 0)) return -2;
+    for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
+    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; i++) if (!launch(layer + i)) return -2;
+    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
+    if (bytes_out) {
+        const MatSlot *m = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
+                         : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
+        // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
+        *bytes_out = (double)file_row_bytes(m->type, m->K) * (double)m->M + 4.0 * (double)m->K + 4.0 * (double)m->M;
+    }
+    return 0;
+}
+
+int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out) {
+    clear_error();
+    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
+    if (reps < 1 || n_past < 0 || n_past >= ctx->hp.n_positions) BG_FAIL(-1, "bad argument");
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!ensure_graph(ctx, 0)) return -2;
+    const int32_t tok0 = 2;
+    if (!upload_state(ctx, &tok0, 1, n_past)) return -2;
+    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0], ctx->stream));
+    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0], ctx->stream));
+    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
+    return 0;
+}
+
+int biogpt_hip_quantize_file(const char *fname_in, const char *fname_out, int32_t ftype) {
+    clear_error();
+    if (!fname_in || !fname_out) BG_FAIL(-1, "null file name");
+    return quantize_file(fname_in, fname_out, ftype) ? 0 : -1;
+}
+
+int biogpt_hip_write_synthetic(const char *fname, const biogpt_hip_hparams *hp, uint64_t seed) {
+    clear_error();
+    if (!fname || !hp) BG_FAIL(-1, "null argument");
+    return write_synthetic(fname, *hp, seed) ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+/*
+ * include/biogpt_hip.h -- C-ABI of the MI355X-native BioGPT decoder engine.
+ *
+ * This is the drop-in boundary for the reference's model-library path:
+ *
+ *   reference (C++, biogpt.h)                         this library (extern "C")
+ *   ------------------------------------------------  ---------------------------------------
+ *   biogpt_model_load()      biogpt.h:128-132         biogpt_hip_load()
+ *                            biogpt.cpp:27-453
+ *   biogpt_eval()            biogpt.h:145-151         biogpt_hip_eval()
+ *                            biogpt.cpp:812-847
+ *   biogpt_graph()           biogpt.h:139-143         (internal: fixed launch sequence / hipGraph;
+ *                            biogpt.cpp:624-810        nothing to size, see biogpt_compat.h)
+ *   generation loop          main.cpp:91-151          biogpt_hip_generate_greedy()  (device-resident
+ *   + top_k=1 sampler        biogpt.cpp:908-980        loop: argmax + token feedback stay in HBM)
+ *   biogpt_model_quantize_internal + quantize CLI     biogpt_hip_quantize_file()
+ *                            biogpt.cpp:459-621, quantize.cpp:8-135
+ *   teardown                 main.cpp:164-169         biogpt_hip_free()
+ *
+ * Plain pointers and sizes only: no C++/torch types cross this boundary.  The C++ wrappers with
+ * the reference's exact signatures live in include/biogpt_compat.h and are implemented on top of
+ * these entry points.  All functions are thread-compatible per context (one eval at a time per
+ * context; different contexts -- e.g. one per GPU -- may run concurrently).
+ *
+ * Error convention: the reference returns false + fprintf(stderr).  Here: pointer
+ * results are NULL on failure, int results are 0 on success and negative on failure; the message
+ * is printed to stderr (prefixed like the reference's "%s: ...") and kept for
+ * biogpt_hip_last_error().  There is NO CPU fallback: without a usable HIP device every compute
+ * entry point fails loudly.
+ */
+#ifndef BIOGPT_HIP_H
+#define BIOGPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct biogpt_hip_ctx biogpt_hip_ctx;
+
+/* header ints in file order (biogpt.cpp:54-60) + the merge count found in the file */
+typedef struct biogpt_hip_hparams {
+    int32_t n_vocab;
+    int32_t n_layer;
+    int32_t n_head;
+    int32_t n_positions;
+    int32_t d_ff;
+    int32_t d_model;
+    int32_t ftype;    /* ggml_ftype: 0 f32, 1 f16, 2 q4_0, 3 q4_1, 7 q8_0, 8 q5_0, 9 q5_1 */
+    int32_t n_merges;
+} biogpt_hip_hparams;
+
+/* Last error message of the calling thread ("" if none). */
+const char *biogpt_hip_last_error(void);
+
+/* Library / build identification, e.g. "biogpt-hip gfx950 r1". */
+const char *biogpt_hip_version(void);
+
+/* ---- load / free --------------------------------------------------------------------------
+ * biogpt_hip_load: parse `fname` (ggml-model.bin), repack every tensor into
+ * the device arena on HIP device `device`, allocate the F32 KV cache (biogpt.cpp:324-358).
+ * Replaces biogpt_model_load (biogpt.cpp:27-453); same validation and the same failure cases
+ * (bad magic, bad vocab size, bad ftype, unknown tensor, wrong shape/size, missing tensors);
+ * a file with zero tensors loads with a warning (biogpt.cpp:442-443) and cannot be evaluated.
+ * Unlike the reference the merge count is taken from the file (F6) and embed_positions is sized
+ * by the file (F5). */
+biogpt_hip_ctx *biogpt_hip_load(const char *fname, int device, int verbosity);
+
+/* Same, but the weight arena lives in caller-owned device memory (e.g. a torch uint8 tensor that
+ * is then broadcast over RCCL); arena_bytes must be >= biogpt_hip_arena_bytes_for(). */
+biogpt_hip_ctx *biogpt_hip_load_into(const char *fname, int device, int verbosity,
+                                     void *device_arena, size_t arena_bytes);
+
+/* Create a context around an arena that ALREADY holds repacked weights (received by broadcast from
+ * a rank that loaded the file): no file access.  hp must equal the loading rank's hparams. */
+biogpt_hip_ctx *biogpt_hip_attach(const biogpt_hip_hparams *hp, int device,
+                                  void *device_arena, size_t arena_bytes);
+
+/* Size in bytes of the device weight arena for these hparams (deterministic layout). */
+size_t biogpt_hip_arena_bytes_for(const biogpt_hip_hparams *hp);
+
+/* The context's arena (owned or external) -- what a multi-GPU launcher broadcasts. */
+void  *biogpt_hip_arena_ptr(biogpt_hip_ctx *ctx);
+size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx);
+
+void biogpt_hip_free(biogpt_hip_ctx *ctx);
+
+int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out);
+int biogpt_hip_n_tensors(const biogpt_hip_ctx *ctx); /* tensors found in the file (389 for BioGPT) */
+
+/* vocab / merges as read from the file (biogpt.cpp:72-156); pointers stay valid until free */
+int biogpt_hip_vocab_token(const biogpt_hip_ctx *ctx, int32_t id, const char **bytes, int32_t *len);
+int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes, int32_t *len);
+
+/* ---- eval ---------------------------------------------------------------------------------
+ * One forward pass over n_tokens tokens at offset n_past; writes the LAST token's n_vocab logits
+ * to host memory.  Replaces biogpt_eval (biogpt.cpp:812-847): same op order, no intra-chunk
+ * causal mask (F1), K/V rows appended to the F32 cache at [n_past, n_past+n_tokens).
+ * Requires 0 <= n_past, n_past + n_tokens <= n_positions, ids in [0, n_vocab).
+ * n_threads of the reference has no meaning here and is not a parameter. */
+int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
+                    float *logits_out);
+
+/* Same pass, logits stay in HBM (no PCIe); biogpt_hip_logits_device() returns the device pointer
+ * to the n_vocab floats of the last evaluated token.  eval_device is asynchronous on the
+ * context's stream; biogpt_hip_synchronize() waits for it. */
+int          biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past);
+const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx);
+int          biogpt_hip_synchronize(biogpt_hip_ctx *ctx);
+
+/* All-rows variant used by parity tests: logits_out is [n_tokens][n_vocab] on the host
+ * (the reference computes all rows and returns the last, biogpt.cpp:803,844; F8). */
+int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
+                        float *logits_out);
+
+/* Greedy generation harness = main.cpp:91-151 with --top_k 1: prompt fed in chunks of n_batch,
+ * then n_predict (clamped to n_positions - n_prompt, main.cpp:82) tokens are sampled by arg-max
+ * (lowest id wins ties) and fed back, all inside HBM (one captured hipGraph replay per token).
+ * out_ids receives the sampled ids; *seconds_out (may be NULL) the wall time of the eval part
+ * (main.cpp:96-103 equivalent: prompt evals + decode evals, the last sampled token is not
+ * evaluated).  Returns the number of ids written, negative on error. */
+int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt,
+                               int32_t n_batch, int32_t n_predict, int32_t *out_ids,
+                               double *seconds_out);
+
+/* ---- introspection for tests / profiling ---------------------------------------------------
+ * Copy `count` floats of the F32 KV cache (which: 0 = K, 1 = V) starting at element `offset` of
+ * the flat [n_layer][n_positions][d_model] array (biogpt.cpp:331-335) to host memory. */
+int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t count, float *out);
+
+/* Stand-alone launch of the block-quantized mat-vec kernel on a weight matrix of the loaded
+ * model, for kernel-level roofline timing: which = 0 fc1 of layer `layer`, 1 fc2,
+ * 2 q/k/v fused, 3 out_proj, 4 lm_head.  Runs `reps` back-to-back launches on the context's
+ * stream bracketed by HIP events and returns the average seconds per launch in *seconds_out and
+ * the algorithmic bytes of one launch in *bytes_out. */
+int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
+                            double *seconds_out, double *bytes_out);
+
+/* Timed replay of the captured single-token decode graph at a fixed n_past (no token feedback
+ * side effects beyond the KV row at n_past): average seconds per token over `reps` replays,
+ * HIP-event timed on the context's stream. */
+int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out);
+
+/* ---- host-side tools (no GPU needed) --------------------------------------------------------
+ * File -> file quantizer, replaces examples/quantize (quantize.cpp:8-135 + biogpt.cpp:459-621):
+ * ftype in {2,3,7,8,9}; every 2-D tensor whose name contains "weight" is quantized in rows of
+ * ne[0]; header ftype rewritten; vocab/merges copied verbatim. */
+int biogpt_hip_quantize_file(const char *fname_in, const char *fname_out, int32_t ftype);
+
+/* Write a synthetic seeded BioGPT model: F32 (ftype 0) or F16 (ftype 1) file in the
+ * reference's format, weights ~ N(0, 0.02^2), LayerNorm gains 1 + N(0, 0.02^2), biases N(0, 0.02^2),
+ * embed_tokens row 1 zero; n_merges merge records are written (40000 keeps the reference's
+ * loader happy, F6). */
+int biogpt_hip_write_synthetic(const char *fname, const biogpt_hip_hparams *hp, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOGPT_HIP_H */

@@ -1,0 +1,52 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU plumbing: replicas only, one arena broadcast,
+no steady-state collective."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import _pkg
+    m = _pkg.load()
+    from biogpt_cpp_amd import replicas
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist = replicas.init_process_group("gloo")
+    hp = replicas.broadcast_hparams([42384, 24, 16, 1024, 4096, 1024, 2, 40000] if rank == 0 else None)
+    n = 3 * 1000 * 1000 + 17
+    arena = torch.zeros(n, dtype=torch.uint8)
+    if rank == 0:
+        arena = torch.from_numpy((np.arange(n) * 2654435761 % 251).astype(np.uint8))
+    replicas.broadcast_arena(arena, src=0, chunk_bytes=1 << 20)
+    units = replicas.shard_units(8, rank, world)
+    ids = np.array([rank * 100 + u for u in units], dtype=np.int32)
+    allids = replicas.gather_ids(ids, 8)
+    tmax = replicas.max_over_ranks(1.0 + rank)
+    tot = replicas.sum_over_ranks(len(units) * 200)
+    q.put((rank, hp, int(arena.to(torch.int64).sum()), units, allids.tolist(), tmax, tot))
+    dist.destroy_process_group()
+
+
+def test_two_rank_replica_plumbing():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, hp0, s0, u0, ids0, t0, tot0), (r1, hp1, s1, u1, ids1, t1, tot1) = res
+    assert hp0 == hp1 == [42384, 24, 16, 1024, 4096, 1024, 2, 40000]
+    assert s0 == s1 and s0 > 0                       # identical arena bytes on both ranks
+    assert u0 == [0, 2, 4, 6] and u1 == [1, 3, 5, 7]   # disjoint, complete cover of the 8 prompts
+    assert ids0 == ids1 and ids0[0][:4] == [0, 2, 4, 6] and ids0[1][:4] == [101, 103, 105, 107]
+    assert t0 == t1 == 2.0 and tot0 == tot1 == 1600.0
