@@ -25,6 +25,7 @@
 
 #include "host_common.h"
 #include "kernels.hip.h"
+#include "kernels_fast.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
 
@@ -186,7 +187,7 @@ struct biogpt_hip_ctx {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipGraphExec_t graph_step[2] = {nullptr, nullptr};  // [advance]
+    hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
     int lm_blocks = 0;
     bool ready = false;  // weights present
 };
@@ -206,8 +207,10 @@ bgk::DevMatrix dev_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
 const float *dev_vec(const biogpt_hip_ctx *c, size_t off) { return reinterpret_cast<const float *>(c->arena + off); }
 
 struct MvShape { int upr, lpr_log2, nit, rpw, nwaves, grid; };
+unsigned long long *g_tstamp = nullptr;  // profiling only (BIOGPT_HIP_DBG & 32)
+int g_launch_parity = 0;
 
-MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs) {
+MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs, int N = 1) {
     MvShape s;
     const int elems = (type == T_F32) ? 4 : (type == T_F16) ? 8 : 32;
     s.upr = (int)(K / elems);
@@ -216,43 +219,103 @@ MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs) {
     s.nit = (s.upr + lpr - 1) / lpr;
     const int rps = 64 / lpr;
     // waves per workgroup: as many as possible (up to 4) while keeping >= target_wgs workgroups
-    int nw = 4;
+    int nw = env_int("BIOGPT_HIP_MV_WAVES", 4);
     while (nw > 1 && (M + (int64_t)nw * rps - 1) / ((int64_t)nw * rps) < target_wgs) nw >>= 1;
     int steps = 1;
     const int max_wgs = env_int("BIOGPT_HIP_MAX_WGS", 1024);
-    while ((M + (int64_t)nw * rps * steps - 1) / ((int64_t)nw * rps * steps) > max_wgs) steps++;
+    // one finisher lane per (row, column) of a wave: rows_per_wave * columns <= 64
+    (void)N;
+    while ( (M + (int64_t)nw * rps * steps - 1) / ((int64_t)nw * rps * steps) > max_wgs) steps++;
     s.nwaves = nw;
     s.rpw = rps * steps;
     s.grid = (int)((M + (int64_t)nw * s.rpw - 1) / ((int64_t)nw * s.rpw));
     return s;
 }
 
-template <int WT, int PRO, int EPI>
-hipError_t launch_mv_nc(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
-    const bool quant = bgk::TypeInfo<WT>::quant;
-    constexpr int NCW = bgk::TypeInfo<WT>::quant ? 8 : 4;
-    if (p.N == 1) {
-        const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, 1);
-        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, 1>), dim3(s.grid, 1), dim3(s.nwaves * 64), sm, st, p);
+template <int WT, int PRO, int EPI, int NC>
+hipError_t launch_mv_kch(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
+    // register chunks per lane the prologue needs: LN holds the whole column, plain only the wave's share
+    const int njj = (p.W.K / 4 + 63) / 64;
+    const int need = (PRO == bgk::PRO_LN) ? njj : (njj + s.nwaves - 1) / s.nwaves;
+    const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NC, s.upr, s.rpw, s.nwaves);
+    const int gy = (p.N + NC - 1) / NC;
+    const bool seq = env_int("BIOGPT_HIP_TREE_REDUCE", 0) == 0;  // default: the reference's block order (bit parity)
+    if (need <= 4) {
+        if (seq) hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, true>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+        else hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, false>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+    } else if (need <= 16) {
+        if (seq) hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 16, true>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+        else hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 16, false>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
     } else {
-        const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NCW);
-        const int gy = (p.N + NCW - 1) / NCW;
-        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NCW>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+        return hipErrorInvalidValue;  // K > 4096*nwaves: not a BioGPT shape
     }
-    (void)quant;
     return hipGetLastError();
 }
 
+template <int WT, int PRO, int EPI>
+hipError_t launch_mv_nc(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
+    constexpr int NCW = bgk::TypeInfo<WT>::quant ? 8 : 4;
+    if (p.N == 1) return launch_mv_kch<WT, PRO, EPI, 1>(p, s, st);
+    return launch_mv_kch<WT, PRO, EPI, NCW>(p, s, st);
+}
+
+// ---- shape-specialised single-token path (kernels_fast.hip.h) --------------------------------------
+template <int WT, int PRO, int EPI, int K>
+hipError_t launch_fast_k(bgk::MatvecParams p, hipStream_t st) {
+    constexpr int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
+    const int M = p.W.M;
+    int steps = (EPI == bgk::EPI_LOGITS) ? env_int("BIOGPT_HIP_LM_STEPS", 8) : env_int("BIOGPT_HIP_FAST_STEPS", 1);
+    while (steps > 1 && (M + 4 * RPS * steps - 1) / (4 * RPS * steps) < 128) steps >>= 1;  // keep the chip covered
+    p.rpw = RPS * steps;
+    const int grid = (M + 4 * p.rpw - 1) / (4 * p.rpw);
+    const size_t sm = bgk::matvec_fast_smem_bytes(K, p.rpw);
+    if (steps >= 4) hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, 4>), dim3(grid), dim3(256), sm, st, p);
+    else hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, 1>), dim3(grid), dim3(256), sm, st, p);
+    return hipGetLastError();
+}
+
+template <int WT, int PRO, int EPI>
+bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err, int *grid_out) {
+    if (p.N != 1 || env_int("BIOGPT_HIP_NO_FAST", 0)) return false;
+    const int K = p.W.K;
+    if (EPI == bgk::EPI_QKV && p.D != K) return false;
+    if (K == 1024) {
+        err = launch_fast_k<WT, PRO, EPI, 1024>(p, st);
+    } else if (K == 4096) {
+        if constexpr (PRO == bgk::PRO_PLAIN) err = launch_fast_k<WT, PRO, EPI, 4096>(p, st);
+        else return false;
+    } else {
+        return false;
+    }
+    if (grid_out) {
+        const int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
+        int steps = (EPI == bgk::EPI_LOGITS) ? env_int("BIOGPT_HIP_LM_STEPS", 8) : env_int("BIOGPT_HIP_FAST_STEPS", 1);
+        while (steps > 1 && (p.W.M + 4 * RPS * steps - 1) / (4 * RPS * steps) < 128) steps >>= 1;
+        *grid_out = (p.W.M + 4 * RPS * steps - 1) / (4 * RPS * steps);
+    }
+    return true;
+}
+
+template <int WT, int PRO, int EPI>
+hipError_t launch_mv_typed(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st, int *grid_out) {
+    if (grid_out) *grid_out = s.grid;
+    if constexpr (bgk::TypeInfo<WT>::quant) {
+        hipError_t err = hipSuccess;
+        if (try_launch_fast<WT, PRO, EPI>(p, st, err, grid_out)) return err;
+    }
+    return launch_mv_nc<WT, PRO, EPI>(p, s, st);
+}
+
 template <int PRO, int EPI>
-hipError_t launch_mv(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
+hipError_t launch_mv(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st, int *grid_out = nullptr) {
     switch (p.W.type) {
-        case T_F32: return launch_mv_nc<bgk::W_F32, PRO, EPI>(p, s, st);
-        case T_F16: return launch_mv_nc<bgk::W_F16, PRO, EPI>(p, s, st);
-        case T_Q4_0: return launch_mv_nc<bgk::W_Q4_0, PRO, EPI>(p, s, st);
-        case T_Q4_1: return launch_mv_nc<bgk::W_Q4_1, PRO, EPI>(p, s, st);
-        case T_Q5_0: return launch_mv_nc<bgk::W_Q5_0, PRO, EPI>(p, s, st);
-        case T_Q5_1: return launch_mv_nc<bgk::W_Q5_1, PRO, EPI>(p, s, st);
-        case T_Q8_0: return launch_mv_nc<bgk::W_Q8_0, PRO, EPI>(p, s, st);
+        case T_F32: return launch_mv_typed<bgk::W_F32, PRO, EPI>(p, s, st, grid_out);
+        case T_F16: return launch_mv_typed<bgk::W_F16, PRO, EPI>(p, s, st, grid_out);
+        case T_Q4_0: return launch_mv_typed<bgk::W_Q4_0, PRO, EPI>(p, s, st, grid_out);
+        case T_Q4_1: return launch_mv_typed<bgk::W_Q4_1, PRO, EPI>(p, s, st, grid_out);
+        case T_Q5_0: return launch_mv_typed<bgk::W_Q5_0, PRO, EPI>(p, s, st, grid_out);
+        case T_Q5_1: return launch_mv_typed<bgk::W_Q5_1, PRO, EPI>(p, s, st, grid_out);
+        case T_Q8_0: return launch_mv_typed<bgk::W_Q8_0, PRO, EPI>(p, s, st, grid_out);
         default: return hipErrorInvalidValue;
     }
 }
@@ -265,6 +328,10 @@ bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvSha
     p.D = c->hp.d_model;
     p.st = c->state;
     p.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+    p.dbg = env_int("BIOGPT_HIP_DBG", 0) | (g_launch_parity << 8);
+    p.tstamp = g_tstamp;
+    p.inv_k = 1.0 / (double)m.K;
+    p.k_pow2 = (m.K & (m.K - 1)) == 0;
     return p;
 }
 
@@ -272,12 +339,17 @@ int target_wgs() { return env_int("BIOGPT_HIP_TARGET_WGS", 256); }
 
 // The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
 // lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
-bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
+bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
     const int dk = D / H;
     hipStream_t st = c->stream;
     const int tw = target_wgs();
+    // attention workgroup size: a thread owns up to ATTN_MAXK whole keys, so T <= 4 * threads
+    int attn_threads = 256;
+    while (attn_threads < 1024 && t_max > attn_threads) attn_threads <<= 1;  // ~1 key per thread when possible
+    if (attn_threads % dk != 0 || t_max > bgk::ATTN_MAXK * attn_threads)
+        BG_FAIL(false, "context of %d tokens / head size %d not supported by the attention kernel", t_max, dk);
 
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
@@ -285,7 +357,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
     for (int l = 0; l < hp.n_layer; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
-            const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw);
+            const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw, N);
             bgk::MatvecParams p = mv_base(c, L.qkv, s);
             p.x = c->x; p.ldx = D; p.N = N;
             p.ln_w = dev_vec(c, L.ln0_w); p.ln_b = dev_vec(c, L.ln0_b);
@@ -302,11 +374,23 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
             a.out = c->att; a.st = c->state;
             a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
             a.N = N; a.D = D; a.dk = dk; a.P = P;
-            const int nt = 256;
-            hipLaunchKernelGGL(bgk::attn_kernel, dim3(H, N), dim3(nt), bgk::attn_smem_bytes(P, dk, nt), st, a);
+            a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
+            if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+                // loads are bounded by t_cap (multiple of 64); 4 lanes per key, 16 prefetched V rows per lane
+                a.t_cap = std::min(P, (t_max + 63) & ~63);
+                if (a.t_cap <= 256) {
+                    hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(H, N), dim3(4 * a.t_cap), 0, st, a);
+                } else if (a.t_cap <= 512) {
+                    hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(H, N), dim3(1024), 0, st, a);
+                } else {
+                    hipLaunchKernelGGL((bgk::attn_fast_kernel<4, false>), dim3(H, N), dim3(1024), 0, st, a);
+                }
+            } else {
+                hipLaunchKernelGGL(bgk::attn_kernel, dim3(H, N), dim3(attn_threads), bgk::attn_smem_bytes(P, dk, attn_threads), st, a);
+            }
         }
         {  // out_proj + bias + residual
-            const MvShape s = mv_shape(L.o.type, L.o.M, L.o.K, tw);
+            const MvShape s = mv_shape(L.o.type, L.o.M, L.o.K, tw, N);
             bgk::MatvecParams p = mv_base(c, L.o, s);
             p.x = c->att; p.ldx = D; p.N = N;
             p.bias = dev_vec(c, L.o_b);
@@ -314,7 +398,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
             HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
         }
         {  // LN1 + fc1 + bias + GELU
-            const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
+            const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw, N);
             bgk::MatvecParams p = mv_base(c, L.fc1, s);
             p.x = c->x1; p.ldx = D; p.N = N;
             p.ln_w = dev_vec(c, L.ln1_w); p.ln_b = dev_vec(c, L.ln1_b);
@@ -323,7 +407,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
             HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, st)));
         }
         {  // fc2 + bias + residual
-            const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw);
+            const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw, N);
             bgk::MatvecParams p = mv_base(c, L.fc2, s);
             p.x = c->h; p.ldx = F; p.N = N;
             p.bias = dev_vec(c, L.fc2_b);
@@ -333,7 +417,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
     }
     {  // final LayerNorm + lm_head; only the rows that are returned (F8)
         const MatSlot &m = c->plan.lm_head;
-        const MvShape s = mv_shape(m.type, m.M, m.K, tw);
+        const MvShape s = mv_shape(m.type, m.M, m.K, tw, all_rows ? N : 1);
         bgk::MatvecParams p = mv_base(c, m, s);
         p.ln_w = dev_vec(c, c->plan.ln_w); p.ln_b = dev_vec(c, c->plan.ln_b);
         p.ldx = D; p.ldo = V;
@@ -343,9 +427,10 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows) {
             p.x = c->x + (size_t)(N - 1) * D; p.N = 1; p.out = c->logits;
             if (s.grid > c->pmax_cap) BG_FAIL(false, "internal: arg-max partial buffer too small (%d > %d)", s.grid, c->pmax_cap);
             p.pmax_val = c->pmax_val; p.pmax_idx = c->pmax_idx;
-            c->lm_blocks = s.grid;
         }
-        HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, st)));
+        int lm_grid = 0;
+        HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, st, &lm_grid)));
+        if (!all_rows) c->lm_blocks = lm_grid;
     }
     return true;
 }
@@ -513,7 +598,7 @@ bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
 void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (auto &g : c->graph_step) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -582,15 +667,24 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
     return c.release();
 }
 
-bool ensure_graph(biogpt_hip_ctx *c, int advance) {
-    if (c->graph_step[advance]) return true;
+// The single-token decode step is captured once per context bucket (the attention workgroup size is a
+// launch parameter, everything else reads n_past / the token from HBM) and replayed per token.
+constexpr int N_BUCKETS = 6;
+int graph_bucket(int T) { return T <= 256 ? (T - 1) / 64 : (T <= 512 ? 4 : 5); }
+int bucket_tmax(const biogpt_hip_ctx *c, int b) {
+    const int t = b < 4 ? 64 * (b + 1) : (b == 4 ? 512 : c->hp.n_positions);
+    return std::min(t, c->hp.n_positions);
+}
+
+bool ensure_graph(biogpt_hip_ctx *c, int advance, int bucket) {
+    if (c->graph_step[advance][bucket]) return true;
     hipGraph_t g = nullptr;
     HIP_TRY(false, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    bool ok = enqueue_forward(c, 1, false) && enqueue_argmax(c, advance);
+    bool ok = enqueue_forward(c, 1, false, bucket_tmax(c, bucket)) && enqueue_argmax(c, advance);
     hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
     HIP_TRY(false, e);
-    HIP_TRY(false, hipGraphInstantiate(&c->graph_step[advance], g, nullptr, nullptr, 0));
+    HIP_TRY(false, hipGraphInstantiate(&c->graph_step[advance][bucket], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
     return true;
 }
@@ -665,7 +759,7 @@ int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
-    if (!enqueue_forward(ctx, n, false)) return -2;
+    if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
     return 0;
 }
 
@@ -698,7 +792,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
         ctx->logits_all_rows = (size_t)n;
     }
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
-    if (!enqueue_forward(ctx, n, true)) return -2;
+    if (!enqueue_forward(ctx, n, true, n_past + n)) return -2;
     HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits_all, (size_t)n * ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -715,7 +809,9 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     const bool use_graph = env_int("BIOGPT_HIP_NO_GRAPH", 0) == 0;
-    if (use_graph && !ensure_graph(ctx, 1)) return -2;
+    if (use_graph)  // instantiate every bucket this run will touch before the clock starts
+        for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++)
+            if (!ensure_graph(ctx, 1, b)) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -723,15 +819,16 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
     while (n_past < n_prompt) {  // prompt ingestion in chunks of n_batch (main.cpp:129-137)
         const int n = std::min(n_batch, n_prompt - n_past);
         if (!upload_state(ctx, prompt + n_past, n, n_past)) return -2;
-        if (!enqueue_forward(ctx, n, false)) return -2;
+        if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
         if (n_past + n == n_prompt && !enqueue_argmax(ctx, n)) return -2;  // first sampled token
         n_past += n;
     }
     for (int k = 1; k < n_predict; k++) {  // one eval + one sample per further token
+        const int T = n_prompt + k;  // keys visible to this token: n_past + 1
         if (use_graph) {
-            HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1], ctx->stream));
+            HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1][graph_bucket(T)], ctx->stream));
         } else {
-            if (!enqueue_forward(ctx, 1, false) || !enqueue_argmax(ctx, 1)) return -2;
+            if (!enqueue_forward(ctx, 1, false, T) || !enqueue_argmax(ctx, 1)) return -2;
         }
     }
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
@@ -762,7 +859,9 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     const int tw = target_wgs();
     // cycling through the layers defeats L2 residency of one matrix; the whole model still
     // fits the 256 MiB Infinity Cache -- stated in DESIGN.md
+    int last_grid = 0;
     auto launch = [&](int l) -> bool {
+        g_launch_parity ^= 1;
         const LayerSlots &L = ctx->plan.layers[(size_t)(hp.n_layer ? l % hp.n_layer : 0)];
         if (which == 0) {
             const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
@@ -802,6 +901,11 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     };
     const int32_t tok0 = 0;
     if (!upload_state(ctx, &tok0, 1, 0)) return -2;
+    const bool stamps = (env_int("BIOGPT_HIP_DBG", 0) & 32) != 0;
+    if (stamps) {
+        if (!g_tstamp) HIP_TRY(-2, hipMalloc(&g_tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(-2, hipMemset(g_tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
+    }
     for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
     HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < reps; i++) if (!launch(layer + i)) return -2;
@@ -810,6 +914,29 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     float ms = 0.0f;
     HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
+    if (stamps) {  // timeline of the last two launches (A then B), shader-clock cycles
+        const MatSlot *mm = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
+                          : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
+        const int grid = mv_shape(mm->type, mm->M, mm->K, tw).grid;
+        std::vector<unsigned long long> h(2 * (size_t)grid * 8);
+        HIP_TRY(-2, hipMemcpy(h.data(), g_tstamp, h.size() * 8, hipMemcpyDeviceToHost));
+        const int pb = g_launch_parity, pa = pb ^ 1;  // B = last launch, A = the one before
+        auto at = [&](int par, int b, int k) { return h[((size_t)par * grid + b) * 8 + k]; };
+        unsigned long long a_min0 = ~0ull, a_max6 = 0, b_min0 = ~0ull, a_max0 = 0;
+        std::vector<double> seg[6];
+        for (int b = 0; b < grid; b++) {
+            a_min0 = std::min(a_min0, at(pa, b, 0)); a_max0 = std::max(a_max0, at(pa, b, 0));
+            a_max6 = std::max(a_max6, at(pa, b, 6)); b_min0 = std::min(b_min0, at(pb, b, 0));
+            for (int k = 0; k < 6; k++) seg[k].push_back((double)(at(pa, b, k + 1) - at(pa, b, k)));
+        }
+        fprintf(stderr, "timeline which=%d grid=%d: span(first entry -> last exit)=%llu cyc, entry spread=%llu, gap to next kernel's first entry=%lld\n",
+                which, grid, a_max6 - a_min0, a_max0 - a_min0, (long long)(b_min0 - a_max6));
+        const char *names[6] = {"entry->loads issued", "->x arrived", "->prologue done", "->barrier passed", "->main loop done", "->finish+epilogue"};
+        for (int k = 0; k < 6; k++) {
+            std::sort(seg[k].begin(), seg[k].end());
+            fprintf(stderr, "   %-22s med %7.0f  max %7.0f cyc\n", names[k], seg[k][seg[k].size() / 2], seg[k].back());
+        }
+    }
     if (bytes_out) {
         const MatSlot *m = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
                          : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
@@ -824,17 +951,32 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (reps < 1 || n_past < 0 || n_past >= ctx->hp.n_positions) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!ensure_graph(ctx, 0)) return -2;
+    const int b = graph_bucket(n_past + 1);
+    if ((env_int("BIOGPT_HIP_DBG", 0) & 32) && !g_tstamp) {
+        HIP_TRY(-2, hipMalloc(&g_tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(-2, hipMemset(g_tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
+    }
+    if (!ensure_graph(ctx, 0, b)) return -2;
     const int32_t tok0 = 2;
     if (!upload_state(ctx, &tok0, 1, n_past)) return -2;
-    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0], ctx->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0][b], ctx->stream));
     HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0], ctx->stream));
+    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0][b], ctx->stream));
     HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
     HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
+    if ((env_int("BIOGPT_HIP_DBG", 0) & 32) && g_tstamp) {
+        unsigned long long h[16 * 8];
+        HIP_TRY(-2, hipMemcpy(h, g_tstamp, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "attention timeline (block 0, last layer; cycles since wave 0 entry):\n");
+        for (int w = 0; w < 16; w += 5) {
+            fprintf(stderr, "  wave %2d:", w);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %7lld", (long long)(h[w * 8 + k] - h[0]));
+            fprintf(stderr, "\n");
+        }
+    }
     return 0;
 }
 

@@ -66,16 +66,59 @@ struct DevMatrix {
 __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
 
+// ---- cross-lane primitives: DPP only (no LDS crossbar / ds_bpermute on the latency-critical paths) ----
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i inside each 16
+constexpr int DPP_WAVE_SHR1 = 0x138;       // lane i <- lane i-1 across the whole wave (GFX9)
+
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// after the xor1/xor2 steps every lane of a quad holds the quad total, so the mirror permutations
+// (which land in the other quad / the other half) complete the butterfly
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ int group8_sum(int v) {
+    v += dpp_i<DPP_QUAD_XOR1>(v); v += dpp_i<DPP_QUAD_XOR2>(v); v += dpp_i<DPP_ROW_HALF_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// wave-wide sum of doubles, result uniform in all lanes
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_d<DPP_QUAD_XOR1>(v); v += dpp_d<DPP_QUAD_XOR2>(v); v += dpp_d<DPP_ROW_HALF_MIRROR>(v); v += dpp_d<DPP_ROW_MIRROR>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// sum over aligned groups of `width` (power of two <= 64) lanes; result valid in every lane of the group
 template <typename T>
-__device__ __forceinline__ T wave_xor_sum(T v, int width) {  // sum over aligned groups of `width` lanes
+__device__ __forceinline__ T wave_xor_sum(T v, int width) {
     for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-// block-wide sum of doubles; every thread gets the same value. scratch: >= 16 doubles of LDS.
+// block-wide reductions: one DPP wave reduction + one LDS exchange; every thread gets the result.
 __device__ __forceinline__ double block_sum_f64(double v, double *scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    v = wave_xor_sum(v, 64);
+    v = wave_sum_f64(v);
+    if (nw == 1) return v;
     __syncthreads();  // scratch may still be read from a previous reduction
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
@@ -85,7 +128,8 @@ __device__ __forceinline__ double block_sum_f64(double v, double *scratch) {
 }
 __device__ __forceinline__ float block_max_f32(float v, float *scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = wave_max_f32(v);
+    if (nw == 1) return v;
     __syncthreads();
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
@@ -159,6 +203,10 @@ struct MatvecParams {
     // EPI_LOGITS: fused partial arg-max (N == 1 only); may be null
     float *pmax_val;
     int32_t *pmax_idx;
+    double inv_k;        // 1.0 / K
+    int32_t k_pow2;      // K is a power of two: sum * inv_k == sum / K exactly (skips two f64 divisions)
+    unsigned long long *tstamp;  // profiling: [2][grid][8] shader-clock stamps when dbg & 32
+    int32_t dbg;         // profiling ablations (bench only; 0 in production): 1 skip x loads, 2 skip LN stats, 4 skip chain, 8 skip weights, 16 skip epilogue table
 };
 
 template <int WT> struct TypeInfo;
@@ -256,46 +304,46 @@ __device__ __forceinline__ double unit_dot_float(const Unit<WT> &u, const float 
     return acc;
 }
 
-// LDS carve for the mat-vec kernel (all offsets multiples of 16 bytes)
-struct MatvecSmem {
-    float *stage;     // [K]      raw / normalised column being processed
-    uint32_t *xq;     // [NC][K/4] int8 activations (quant) -- or float [NC][K] for float types
-    float *xd;        // [NC][K/32]
-    float *xsf;       // [NC][K/32]
-    int *xsi;         // [NC][K/32]
-    double *red;      // [16]
-};
-
-__host__ __device__ inline size_t matvec_smem_bytes(int wtype, int K, int NC) {
+// LDS layout of the mat-vec kernel: [xq | xd | xs | tail], all offsets multiples of 16 bytes.
+//   quant types : xq = int8 activations [NC][K], xd = per-block scale [NC][K/32], xs = per-block
+//                 integer sum (Q8_0) or d*sum (Q8_1), stored as raw 32-bit words
+//   float types : xq = f32 activations [NC][K] (rounded through f16 for F16 weights)
+//   part        : per wave [rpw][NC][stride] f32 block terms c_b of every row, summed IN BLOCK ORDER by one
+//                 lane per (row, column) -- the association of the reference's scalar vec_dot loop
+__host__ __device__ inline int matvec_part_stride(int upr) { return ((upr + 3) & ~3) + 4; }  // floats; 16-B aligned, bank-skewed
+__host__ __device__ inline size_t matvec_smem_bytes(int wtype, int K, int NC, int upr, int rpw, int nwaves) {
     const bool quant = !(wtype == W_F32 || wtype == W_F16);
-    size_t b = (size_t)K * 4;                                    // stage
-    b += quant ? (size_t)NC * K : (size_t)NC * K * 4;            // xq / xf
-    b += 3 * (size_t)NC * (K / QK + 4) * 4;                      // xd, xsf, xsi (padded)
-    b += 16 * 8;                                                 // red
+    size_t b = quant ? (size_t)NC * K : (size_t)NC * K * 4;
+    b += 2 * (size_t)NC * (K / QK + 4) * 4;
+    b += 256;                                                                   // tail (arg-max exchange)
+    b += (size_t)nwaves * rpw * NC * (quant ? matvec_part_stride(upr) : 4) * 4;  // per-wave block terms
     return (b + 255) & ~(size_t)255;
 }
 
-template <int WT, int PRO, int EPI, int NC, bool SEQ = true>
+// The activation column is held in registers as float4 "chunks": chunk id = jj*64 + lane.  For the
+// LayerNorm prologue every wave loads the WHOLE column (statistics are computed redundantly per wave
+// with DPP reductions -- no block barrier), but converts/quantizes only its share (jj % nwaves == wave).
+// For the plain prologue a wave loads only its share.  KCH = register chunks per lane (4 or 16).
+#define BG_STAMP(k)                                                                                  \
+    do {                                                                                            \
+        if ((p.dbg & 32) && threadIdx.x == 0)                                                       \
+            p.tstamp[(((size_t)((p.dbg >> 8) & 1) * gridDim.x + blockIdx.x) * 8) + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+
+template <int WT, int PRO, int EPI, int NC, int KCH, bool SEQ = true>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
     using TI = TypeInfo<WT>;
+    BG_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.W.K, M = p.W.M;
-    const int nblk = K / QK;
-    const int nblk_pad = nblk + 4;
-
-    MatvecSmem sm;
-    {
-        unsigned char *ptr = smem_raw;
-        sm.stage = reinterpret_cast<float *>(ptr); ptr += (size_t)K * 4;
-        sm.xq = reinterpret_cast<uint32_t *>(ptr); ptr += TI::quant ? (size_t)NC * K : (size_t)NC * K * 4;
-        sm.xd = reinterpret_cast<float *>(ptr); ptr += (size_t)NC * nblk_pad * 4;
-        sm.xsf = reinterpret_cast<float *>(ptr); ptr += (size_t)NC * nblk_pad * 4;
-        sm.xsi = reinterpret_cast<int *>(ptr); ptr += (size_t)NC * nblk_pad * 4;
-        sm.red = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(ptr) + 15) & ~(uintptr_t)15);
-    }
+    const int nblk_pad = K / QK + 4;
+    uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem_raw);
+    float *const s_xd = reinterpret_cast<float *>(smem_raw + (TI::quant ? (size_t)NC * K : (size_t)NC * K * 4));
+    uint32_t *const s_xs = reinterpret_cast<uint32_t *>(s_xd + (size_t)NC * nblk_pad);
+    float *const s_tail = reinterpret_cast<float *>(s_xs + (size_t)NC * nblk_pad);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int nwaves = blockDim.x >> 6;
     const int lpr = 1 << p.lpr_log2;
     const int rps = 64 >> p.lpr_log2;               // rows per wave step
     const int sub = lane & (lpr - 1);               // lane's position inside its row
@@ -304,10 +352,18 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
     const int64_t row_base = ((int64_t)blockIdx.x * nwaves + wave) * p.rpw;
     const int col0 = blockIdx.y * NC;
     const int ncols = min(NC, p.N - col0);
+    // finisher slots: output f = (row row_base + f % rpw, column col0 + f / rpw), f < rpw*ncols; lane l
+    // takes f = l, l + 64, ... (one per lane for every BioGPT-base shape)
+    const int pstride = TI::quant ? matvec_part_stride(p.upr) : 4;
+    float *const s_part = s_tail + 64 + (size_t)wave * p.rpw * NC * pstride;
+    const int nfin = p.rpw * ncols;
+    const int f_row = lane % p.rpw, f_col = lane / p.rpw;
+    const int64_t f_grow = row_base + f_row;
+    const bool finisher = lane < nfin && f_grow < M;
 
-    // ---- issue the first work item's weight loads (independent of the activations) ------------
-    // A work item = (row step, chunk of MAXIT units per lane); rows longer than MAXIT*LPR units
-    // (f16/f32 weights with K = d_ff) take several items per step.
+    // ---- t = 0: issue every load that does not depend on another load ---------------------------
+    // (a) weights of the first work item.  A work item = (row step, chunk of MAXIT units per lane);
+    //     rows longer than MAXIT*LPR units (f16/f32 weights with K = d_ff) take several items per step.
     constexpr int MAXIT = 4;
     const int nitc = (p.nit + MAXIT - 1) / MAXIT;
     const int nitems = nsteps * nitc;
@@ -318,187 +374,228 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
         const int64_t row_ = row_base + (int64_t)stp_ * rps + rsub;                              \
         _Pragma("unroll") for (int it = 0; it < MAXIT; it++) {                                   \
             const int itg_ = itc_ * MAXIT + it, uu_ = sub + itg_ * lpr;                          \
-            if (itg_ < p.nit && uu_ < p.upr && row_ < M) load_unit<WT>(dst[it], p.W, row_ * p.upr + uu_); \
+            if (itg_ < p.nit && uu_ < p.upr && row_ < M && !(p.dbg & 8)) load_unit<WT>(dst[it], p.W, row_ * p.upr + uu_); \
         }                                                                                        \
     } while (0)
     BG_LOAD_ITEM(cur, 0);
 
-    // ---- prologue: [LayerNorm] + activation conversion into LDS, one column at a time --------
+    // (b) epilogue operands (bias / residual / decode position) of this lane's output element
+    float e_bias = 0.0f, e_res = 0.0f;
+    int e_npast = 0;
+    if (finisher) {
+        if (EPI != EPI_LOGITS) e_bias = p.bias[f_grow];
+        if (EPI == EPI_RESID) e_res = p.resid[(size_t)(col0 + f_col) * p.ldr + f_grow];
+        if (EPI == EPI_QKV) e_npast = p.st->n_past;
+    }
+
+    BG_STAMP(1);
+    // ---- prologue: [LayerNorm] + activation conversion into LDS -------------------------------
+    const int nchunks = K >> 2;
+    const int njj = (nchunks + 63) >> 6;            // chunks per lane over the whole column
     for (int c = 0; c < ncols; c++) {
-        const float *xcol = p.x + (size_t)(col0 + c) * p.ldx;
-        const int nchunks = K / 4;
-        // stage the column (each thread re-reads only what it wrote: no barrier needed)
-        for (int ch = tid; ch < nchunks; ch += nthreads)
-            reinterpret_cast<float4 *>(sm.stage)[ch] = reinterpret_cast<const float4 *>(xcol)[ch];
-        if (PRO == PRO_LN) {
-            // ggml_norm: mean and variance in double, y = (x-mean) * 1/sqrtf(var+eps); then *w, +b
-            double s = 0.0;
-            for (int ch = tid; ch < nchunks; ch += nthreads) {
-                const float4 v = reinterpret_cast<const float4 *>(sm.stage)[ch];
-                s += (double)v.x; s += (double)v.y; s += (double)v.z; s += (double)v.w;
+        const float4 *xcol = reinterpret_cast<const float4 *>(p.x + (size_t)(col0 + c) * p.ldx);
+        float4 xr[KCH];
+        // register slot i holds chunk jj(i): LN -> jj = i (whole column); plain -> jj = wave + i*nwaves (own share)
+#pragma unroll
+        for (int i = 0; i < KCH; i++) {
+            const int jj = (PRO == PRO_LN) ? i : wave + i * nwaves;
+            const int ch = jj * 64 + lane;
+            xr[i] = (jj < njj && ch < nchunks && !(p.dbg & 1)) ? xcol[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (p.dbg & 32) { asm volatile("" :: "v"(xr[0].x)); BG_STAMP(2); }
+        if (PRO == PRO_LN && !(p.dbg & 2)) {
+            // ggml_norm: mean and variance accumulate in double; y = (x-mean) * 1/sqrtf(var+eps); then *w, +b
+            double s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < KCH; i++) {
+                if (i < njj) s1 += ((double)xr[i].x + (double)xr[i].y) + ((double)xr[i].z + (double)xr[i].w);
             }
-            const float mean = (float)(block_sum_f64(s, sm.red) / (double)K);
+            s1 = wave_sum_f64(s1);
+            const float mean = (float)(p.k_pow2 ? s1 * p.inv_k : s1 / (double)K);
             double s2 = 0.0;
-            for (int ch = tid; ch < nchunks; ch += nthreads) {
-                float4 v = reinterpret_cast<const float4 *>(sm.stage)[ch];
+#pragma unroll
+            for (int i = 0; i < KCH; i++) {
+                const bool live = i < njj && (i * 64 + lane) < nchunks;
+                float4 v = xr[i];
                 v.x = __fsub_rn(v.x, mean); v.y = __fsub_rn(v.y, mean); v.z = __fsub_rn(v.z, mean); v.w = __fsub_rn(v.w, mean);
-                reinterpret_cast<float4 *>(sm.stage)[ch] = v;
-                s2 += (double)__fmul_rn(v.x, v.x); s2 += (double)__fmul_rn(v.y, v.y);
-                s2 += (double)__fmul_rn(v.z, v.z); s2 += (double)__fmul_rn(v.w, v.w);
+                if (live)
+                    s2 += ((double)__fmul_rn(v.x, v.x) + (double)__fmul_rn(v.y, v.y)) + ((double)__fmul_rn(v.z, v.z) + (double)__fmul_rn(v.w, v.w));
+                xr[i] = v;
             }
-            const float var = (float)(block_sum_f64(s2, sm.red) / (double)K);
+            s2 = wave_sum_f64(s2);
+            const float var = (float)(p.k_pow2 ? s2 * p.inv_k : s2 / (double)K);
             const float scale = 1.0f / sqrtf(__fadd_rn(var, p.eps));
-            for (int ch = tid; ch < nchunks; ch += nthreads) {
-                float4 v = reinterpret_cast<const float4 *>(sm.stage)[ch];
-                const float4 w = reinterpret_cast<const float4 *>(p.ln_w)[ch];
-                const float4 b = reinterpret_cast<const float4 *>(p.ln_b)[ch];
-                v.x = __fadd_rn(__fmul_rn(w.x, __fmul_rn(v.x, scale)), b.x);
-                v.y = __fadd_rn(__fmul_rn(w.y, __fmul_rn(v.y, scale)), b.y);
-                v.z = __fadd_rn(__fmul_rn(w.z, __fmul_rn(v.z, scale)), b.z);
-                v.w = __fadd_rn(__fmul_rn(w.w, __fmul_rn(v.w, scale)), b.w);
-                reinterpret_cast<float4 *>(sm.stage)[ch] = v;
+#pragma unroll
+            for (int i = 0; i < KCH; i++) {
+                const int ch = i * 64 + lane;
+                if (i < njj && ch < nchunks && (i % nwaves) == wave) {  // only the share this wave converts
+                    const float4 w = reinterpret_cast<const float4 *>(p.ln_w)[ch];
+                    const float4 b = reinterpret_cast<const float4 *>(p.ln_b)[ch];
+                    float4 v = xr[i];
+                    v.x = __fadd_rn(__fmul_rn(w.x, __fmul_rn(v.x, scale)), b.x);
+                    v.y = __fadd_rn(__fmul_rn(w.y, __fmul_rn(v.y, scale)), b.y);
+                    v.z = __fadd_rn(__fmul_rn(w.z, __fmul_rn(v.z, scale)), b.z);
+                    v.w = __fadd_rn(__fmul_rn(w.w, __fmul_rn(v.w, scale)), b.w);
+                    xr[i] = v;
+                }
             }
         }
-        if (TI::quant) {
-            // quantize_row_q8_0 / q8_1: a 32-block = 8 consecutive chunks = 8 consecutive lanes
-            for (int ch = tid; ch < nchunks; ch += nthreads) {
-                const float4 v = reinterpret_cast<const float4 *>(sm.stage)[ch];
-                float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        // convert this wave's share and publish it in LDS
+#pragma unroll
+        for (int i = 0; i < KCH; i++) {
+            const int jj = (PRO == PRO_LN) ? i : wave + i * nwaves;
+            const int ch = jj * 64 + lane;
+            const bool mine = jj < njj && ((PRO == PRO_LN) ? (i % nwaves) == wave : true);
+            if (!mine) continue;                       // wave-uniform
+            const bool live = ch < nchunks;
+            const float4 v = xr[i];
+            if (TI::quant) {
+                // quantize_row_q8_0 / q8_1: a 32-block = 8 consecutive chunks = 8 consecutive lanes
+                const float amax = group8_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 const float d = amax / 127.0f;
                 const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
                 const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
                 const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
-                int isum = q0 + q1 + q2 + q3;
-                isum += __shfl_xor(isum, 1, 64);
-                isum += __shfl_xor(isum, 2, 64);
-                isum += __shfl_xor(isum, 4, 64);
-                sm.xq[(size_t)c * (K / 4) + ch] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) |
-                                                   ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-                if ((ch & 7) == 0) {
-                    const int b = ch >> 3;
-                    if (TI::q81) {
-                        sm.xd[c * nblk_pad + b] = d;                         // Q8_1 keeps f32 d
-                        sm.xsf[c * nblk_pad + b] = __fmul_rn((float)isum, d);  // s = sum * d
-                    } else {
-                        sm.xd[c * nblk_pad + b] = h2f(f2h(d));               // Q8_0 stores fp16 d
-                        sm.xsi[c * nblk_pad + b] = isum;
+                const int isum = group8_sum(q0 + q1 + q2 + q3);
+                if (live) {
+                    s_xq[(size_t)c * (K / 4) + ch] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) |
+                                                      ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+                    if ((ch & 7) == 0) {
+                        const int b = ch >> 3;
+                        if (TI::q81) {
+                            s_xd[c * nblk_pad + b] = d;                                             // Q8_1 keeps f32 d
+                            s_xs[c * nblk_pad + b] = __float_as_uint(__fmul_rn((float)isum, d));    // s = sum * d
+                        } else {
+                            s_xd[c * nblk_pad + b] = h2f(f2h(d));                                   // Q8_0 stores fp16 d
+                            s_xs[c * nblk_pad + b] = (uint32_t)isum;
+                        }
                     }
                 }
-            }
-        } else {
-            float *xf = reinterpret_cast<float *>(sm.xq) + (size_t)c * K;
-            for (int ch = tid; ch < nchunks; ch += nthreads) {
-                float4 v = reinterpret_cast<const float4 *>(sm.stage)[ch];
+            } else if (live) {
+                float4 o = v;
                 if (WT == W_F16) {  // src1 row converted to f16 (ggml_fp32_to_fp16_row)
-                    v.x = h2f(f2h(v.x)); v.y = h2f(f2h(v.y)); v.z = h2f(f2h(v.z)); v.w = h2f(f2h(v.w));
+                    o.x = h2f(f2h(o.x)); o.y = h2f(f2h(o.y)); o.z = h2f(f2h(o.z)); o.w = h2f(f2h(o.w));
                 }
-                reinterpret_cast<float4 *>(xf)[ch] = v;
+                reinterpret_cast<float4 *>(s_xq)[(size_t)c * (K / 4) + ch] = o;
             }
         }
     }
+    BG_STAMP(3);
     __syncthreads();
+    BG_STAMP(4);
 
-    // ---- main loop over work items ---------------------------------------------------------------
-    float best_val = -INFINITY;
-    int best_idx = 0x7fffffff;
-    float carry[NC];   // quant types: running row sum in block order (ggml's scalar vec_dot order)
+    // ---- main loop over work items: block terms -> LDS ---------------------------------------------
     double accd[NC];   // float types: double accumulation (order-insensitive at f32 output precision)
     for (int w = 0; w < nitems; w++) {
         Unit<WT> nxt[MAXIT];
         if (w + 1 < nitems) BG_LOAD_ITEM(nxt, w + 1);
         const int stp = w / nitc, itc = w - stp * nitc;
         const int64_t row = row_base + (int64_t)stp * rps + rsub;
+        const int wrow = stp * rps + rsub;               // row index inside this wave
         if (itc == 0) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) { carry[c] = 0.0f; accd[c] = 0.0; }
+            for (int c = 0; c < NC; c++) accd[c] = 0.0;
         }
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
             const int itg = itc * MAXIT + it, uu = sub + itg * lpr;
             if (itg >= p.nit) continue;  // wave-uniform
             const bool live = uu < p.upr && row < M;
-            if (TI::quant) {
-                // per-block contributions, then an in-order chain over the lanes of the row so that the
-                // f32 sum is associated exactly like the reference's scalar loop: ((c0 + c1) + c2) + ...
-                float cc[NC], acc[NC];
+            if (!live) continue;
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    cc[c] = 0.0f;
-                    if (live && c < ncols) {
-                        const uint32_t *xq = sm.xq + (size_t)c * (K / 4) + uu * 8;
-                        cc[c] = unit_dot_quant<WT>(cur[it], xq, sm.xd[c * nblk_pad + uu], sm.xsf[c * nblk_pad + uu], sm.xsi[c * nblk_pad + uu]);
-                    }
-                    acc[c] = (sub == 0) ? __fadd_rn(carry[c], cc[c]) : cc[c];
-                }
-                if (SEQ) {
-                    for (int s2 = 1; s2 < lpr; s2++) {
-#pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            // lane l takes lane l-1's running sum (DPP wave_shr:1) and adds its own block
-                            const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), 0x138, 0xf, 0xf, true));
-                            acc[c] = (sub == 0) ? acc[c] : __fadd_rn(t, cc[c]);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < NC; c++) carry[c] = __shfl(acc[c], lane | (lpr - 1), 64);
+            for (int c = 0; c < NC; c++) {
+                if (c >= ncols) continue;
+                if (TI::quant) {
+                    const uint32_t *xq = s_xq + (size_t)c * (K / 4) + uu * 8;
+                    const uint32_t xs = s_xs[c * nblk_pad + uu];
+                    s_part[((size_t)wrow * NC + c) * pstride + uu] =
+                        unit_dot_quant<WT>(cur[it], xq, s_xd[c * nblk_pad + uu], __uint_as_float(xs), (int)xs);
                 } else {
-#pragma unroll
-                    for (int c = 0; c < NC; c++) carry[c] = wave_xor_sum(acc[c], lpr);
-                }
-            } else if (live) {
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (c < ncols) {
-                        const float *xf = reinterpret_cast<const float *>(sm.xq) + (size_t)c * K + uu * TI::elems;
-                        accd[c] += unit_dot_float<WT>(cur[it], xf);
-                    }
+                    const float *xf = reinterpret_cast<const float *>(s_xq) + (size_t)c * K + uu * TI::elems;
+                    accd[c] += unit_dot_float<WT>(cur[it], xf);
                 }
             }
         }
-        if (itc == nitc - 1) {
-            float res[NC];
+        if (!TI::quant && itc == nitc - 1) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (TI::quant) res[c] = carry[c];
-                else res[c] = (float)wave_xor_sum(accd[c], lpr);
-            }
-            if (sub == 0 && row < M) {
-                const int r = (int)row;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (c >= ncols) continue;
-                    const int col = col0 + c;
-                    float v = res[c];
-                    if (EPI == EPI_QKV) {
-                        v = __fadd_rn(p.bias[r], v);
-                        const int which = r / p.D, rr = r - which * p.D;
-                        if (which == 0) {
-                            p.q_out[(size_t)col * p.D + rr] = __fmul_rn(v, p.q_scale);
-                        } else {
-                            float *cache = (which == 1) ? p.kcache : p.vcache;
-                            cache[(size_t)(p.st->n_past + col) * p.D + rr] = v;
-                        }
-                    } else if (EPI == EPI_RESID) {
-                        v = __fadd_rn(v, p.bias[r]);
-                        p.out[(size_t)col * p.ldo + r] = __fadd_rn(v, p.resid[(size_t)col * p.ldr + r]);
-                    } else if (EPI == EPI_GELU) {
-                        v = __fadd_rn(p.bias[r], v);
-                        p.out[(size_t)col * p.ldo + r] = h2f(p.gelu_tab[f2h(v)]);
-                    } else {
-                        p.out[(size_t)col * p.ldo + r] = v;
-                        if (c == 0 && (v > best_val || (v == best_val && r < best_idx))) { best_val = v; best_idx = r; }
-                    }
-                }
+                const float r = (float)wave_xor_sum(accd[c], lpr);
+                if (sub == 0 && row < M && c < ncols) s_part[((size_t)wrow * NC + c) * pstride] = r;
             }
         }
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) cur[it] = nxt[it];
     }
 #undef BG_LOAD_ITEM
+    BG_STAMP(5);
+    // LDS is processed in order per wave: the finisher lanes' reads below see this wave's writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // ---- finish: one lane per (row, column) adds the block terms in block order, then the epilogue ---
+    float best_val = -INFINITY;
+    int best_idx = 0x7fffffff;
+    for (int f = lane; f < nfin; f += 64) {
+        const int fr = f % p.rpw, fc = f / p.rpw;
+        const int64_t grow = row_base + fr;
+        if (grow >= M) continue;
+        const float *part = s_part + ((size_t)fr * NC + fc) * pstride;
+        float v;
+        if (TI::quant) {
+            // sumf = 0; for b: sumf += c_b   (ggml_vec_dot_q*_q8_* scalar order)
+            float sumf = 0.0f;
+            if (SEQ) {
+                for (int b = 0; b < p.upr; b += 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(part + b);
+                    sumf = __fadd_rn(sumf, t.x);
+                    if (b + 1 < p.upr) sumf = __fadd_rn(sumf, t.y);
+                    if (b + 2 < p.upr) sumf = __fadd_rn(sumf, t.z);
+                    if (b + 3 < p.upr) sumf = __fadd_rn(sumf, t.w);
+                }
+            } else {  // 4 interleaved partial sums (tolerance mode, not the parity path)
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int b = 0; b < p.upr; b += 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(part + b);
+                    a0 += t.x; if (b + 1 < p.upr) a1 += t.y; if (b + 2 < p.upr) a2 += t.z; if (b + 3 < p.upr) a3 += t.w;
+                }
+                sumf = (a0 + a1) + (a2 + a3);
+            }
+            v = sumf;
+        } else {
+            v = part[0];
+        }
+        const int r = (int)grow, col = col0 + fc;
+        const bool first = (f == lane) && finisher;  // operands were fetched at kernel entry
+        float bias = e_bias, res = e_res;
+        int npast = e_npast;
+        if (!first) {
+            if (EPI != EPI_LOGITS) bias = p.bias[r];
+            if (EPI == EPI_RESID) res = p.resid[(size_t)col * p.ldr + r];
+            if (EPI == EPI_QKV) npast = p.st->n_past;
+        }
+        if (EPI == EPI_QKV) {
+            v = __fadd_rn(bias, v);
+            const int which = r / p.D, rr = r - which * p.D;
+            if (which == 0) {
+                p.q_out[(size_t)col * p.D + rr] = __fmul_rn(v, p.q_scale);
+            } else {
+                float *cache = (which == 1) ? p.kcache : p.vcache;
+                cache[(size_t)(npast + col) * p.D + rr] = v;
+            }
+        } else if (EPI == EPI_RESID) {
+            v = __fadd_rn(v, bias);
+            p.out[(size_t)col * p.ldo + r] = __fadd_rn(v, res);
+        } else if (EPI == EPI_GELU) {
+            v = __fadd_rn(bias, v);
+            p.out[(size_t)col * p.ldo + r] = (p.dbg & 16) ? v : h2f(p.gelu_tab[f2h(v)]);
+        } else {
+            p.out[(size_t)col * p.ldo + r] = v;
+            if (fc == 0 && (v > best_val || (v == best_val && r < best_idx))) { best_val = v; best_idx = r; }
+        }
+    }
+
+    BG_STAMP(6);
     if (EPI == EPI_LOGITS && p.pmax_val != nullptr) {
         // per-block partial arg-max (lowest index wins ties), finished by argmax_kernel
         for (int off = 32; off > 0; off >>= 1) {
@@ -506,9 +603,8 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
             const int oi = __shfl_xor(best_idx, off, 64);
             if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
         }
-        __syncthreads();
-        float *sv = reinterpret_cast<float *>(sm.red);
-        int *si = reinterpret_cast<int *>(sm.red) + 8;
+        float *sv = s_tail;
+        int *si = reinterpret_cast<int *>(s_tail) + 8;
         if (lane == 0) { sv[wave] = best_val; si[wave] = best_idx; }
         __syncthreads();
         if (tid == 0) {
@@ -529,67 +625,89 @@ struct AttnParams {
     const DevState *st;
     const uint16_t *exp_tab;
     int32_t N, D, dk, P;
+    int32_t t_cap;                // launch-time upper bound of the context (fast kernel load bound)
+    unsigned long long *tstamp;  // profiling (dbg & 32): [16 waves][8] stamps of block (0,0)
+    int32_t dbg;
 };
 
-// One workgroup per (head, query token).  scores -> softmax -> PV exactly in the order of
-// biogpt.cpp:741-764: S_j = K_j . q ; p_j = f16tab_exp(S_j - max) ; p_j *= 1/sum(double) ;
-// o_d = sum_j V_jd * p_j.  LDS: S[T] + q[dk] + reduction scratch.
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+constexpr int ATTN_MAXK = 4;  // keys per thread held in registers: T <= ATTN_MAXK * blockDim
+
+// One workgroup per (head, query token).  scores -> softmax -> PV in the order of biogpt.cpp:741-764:
+//   S_j = K_j . q ; p_j = f16tab_exp(S_j - max) ; p_j *= (float)(1/sum_double) ; o_d = sum_j V_jd * p_j
+// A thread owns whole keys (no cross-lane work in QK^T): its 16-byte loads of a 4*dk-byte key row are
+// all in flight at once and the dot runs in the reference's element order with a double accumulator.
+__global__ __launch_bounds__(1024) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int h = blockIdx.x, i = blockIdx.y;
     const int n_past = p.st->n_past;
     int T = n_past + p.N;
     if (p.st->causal) T = n_past + i + 1;
     const int dk = p.dk, D = p.D;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
 
-    float *S = reinterpret_cast<float *>(smem_raw);                    // [P]
-    float *qs = S + p.P;                                               // [dk]
-    double *red = reinterpret_cast<double *>(qs + dk);                 // [16]
-    double *pv = red + 16;                                             // [nthreads]
+    float *S = reinterpret_cast<float *>(smem_raw);                               // [P] probabilities
+    double *red = reinterpret_cast<double *>(smem_raw + (((size_t)p.P * 4 + 15) & ~(size_t)15));  // [16]
+    double *pv = red + 16;                                                        // [nt]
 
-    for (int d = tid; d < dk; d += nthreads) qs[d] = p.q[(size_t)i * D + (size_t)h * dk + d];
-    __syncthreads();
+    const float *__restrict__ qrow = p.q + (size_t)i * D + (size_t)h * dk;        // wave-uniform address
+    const float *__restrict__ kbase = p.kcache + (size_t)h * dk;
+    const float *__restrict__ vbase = p.vcache + (size_t)h * dk;
 
-    // scores: dk/4 lanes per key, float4 each
-    const int lpk = dk >> 2;              // lanes per key (power of two, <= 64)
-    const int kpw = 64 / lpk;             // keys per wave step
-    const int ksub = lane % lpk, kidx = lane / lpk;
-    const float4 qv = reinterpret_cast<const float4 *>(qs)[ksub];
-    for (int j0 = wave * kpw; j0 < T; j0 += nwaves * kpw) {
-        const int j = j0 + kidx;
-        double acc = 0.0;
+    // ---- scores ----
+    float sc[ATTN_MAXK];
+#pragma unroll
+    for (int kk = 0; kk < ATTN_MAXK; kk++) {
+        const int j = tid + kk * nt;
+        sc[kk] = -INFINITY;
         if (j < T) {
-            const float4 kv = *reinterpret_cast<const float4 *>(p.kcache + (size_t)j * D + (size_t)h * dk + 4 * ksub);
-            acc += (double)__fmul_rn(kv.x, qv.x); acc += (double)__fmul_rn(kv.y, qv.y);
-            acc += (double)__fmul_rn(kv.z, qv.z); acc += (double)__fmul_rn(kv.w, qv.w);
+            const float4 *kr = reinterpret_cast<const float4 *>(kbase + (size_t)j * D);
+            double acc = 0.0;
+            for (int d4 = 0; d4 < (dk >> 2); d4++) {
+                const float4 kv = kr[d4];
+                const float4 qv = reinterpret_cast<const float4 *>(qrow)[d4];
+                acc += (double)__fmul_rn(kv.x, qv.x); acc += (double)__fmul_rn(kv.y, qv.y);
+                acc += (double)__fmul_rn(kv.z, qv.z); acc += (double)__fmul_rn(kv.w, qv.w);
+            }
+            sc[kk] = (float)acc;
         }
-        acc = wave_xor_sum(acc, lpk);
-        if (ksub == 0 && j < T) S[j] = (float)acc;
     }
-    __syncthreads();
 
-    // softmax (ggml_soft_max: fp16-table exp, double sum, scale by (float)(1/sum))
-    float mx = -INFINITY;
-    for (int j = tid; j < T; j += nthreads) mx = fmaxf(mx, S[j]);
+    // ---- softmax (ggml_soft_max: fp16-table exp, double sum, scale by (float)(1/sum)) ----
+    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
     mx = block_max_f32(mx, reinterpret_cast<float *>(red));
     double sum = 0.0;
-    for (int j = tid; j < T; j += nthreads) {
-        const float val = h2f(p.exp_tab[f2h(__fsub_rn(S[j], mx))]);
-        S[j] = val;
-        sum += (double)val;
+#pragma unroll
+    for (int kk = 0; kk < ATTN_MAXK; kk++) {
+        const int j = tid + kk * nt;
+        if (j < T) {
+            const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc[kk], mx))]);
+            sc[kk] = val;
+            sum += (double)val;
+        }
     }
     sum = block_sum_f64(sum, red);
     const float inv = (float)(1.0 / sum);
-    for (int j = tid; j < T; j += nthreads) S[j] = __fmul_rn(S[j], inv);
+#pragma unroll
+    for (int kk = 0; kk < ATTN_MAXK; kk++) {
+        const int j = tid + kk * nt;
+        if (j < T) S[j] = __fmul_rn(sc[kk], inv);
+    }
     __syncthreads();
 
-    // PV: thread = (slice, d); each slice strides over the keys
-    const int nsl = nthreads / dk;
+    // ---- PV: thread = (slice, d); each slice strides over the keys; double accumulation ----
+    const int nsl = nt / dk;
     const int d = tid % dk, sl = tid / dk;
     double acc = 0.0;
-    if (sl < nsl)
-        for (int j = sl; j < T; j += nsl) acc += (double)__fmul_rn(p.vcache[(size_t)j * D + (size_t)h * dk + d], S[j]);
+    if (sl < nsl) {
+        int j = sl;
+        for (; j + 3 * nsl < T; j += 4 * nsl) {
+            const float v0 = vbase[(size_t)j * D + d], v1 = vbase[(size_t)(j + nsl) * D + d];
+            const float v2 = vbase[(size_t)(j + 2 * nsl) * D + d], v3 = vbase[(size_t)(j + 3 * nsl) * D + d];
+            acc += (double)__fmul_rn(v0, S[j]); acc += (double)__fmul_rn(v1, S[j + nsl]);
+            acc += (double)__fmul_rn(v2, S[j + 2 * nsl]); acc += (double)__fmul_rn(v3, S[j + 3 * nsl]);
+        }
+        for (; j < T; j += nsl) acc += (double)__fmul_rn(vbase[(size_t)j * D + d], S[j]);
+    }
     pv[tid] = acc;
     __syncthreads();
     if (tid < dk) {
@@ -600,7 +718,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 }
 
 __host__ __device__ inline size_t attn_smem_bytes(int P, int dk, int nthreads) {
-    return (((size_t)P + dk) * 4 + 15) / 16 * 16 + 16 * 8 + (size_t)nthreads * 8 + 64;
+    return (((size_t)P * 4 + 15) & ~(size_t)15) + 16 * 8 + (size_t)nthreads * 8 + 64;
 }
 
 // ---- greedy sampler + token feedback (main.cpp:109-128 with top_k = 1) ----------------------------

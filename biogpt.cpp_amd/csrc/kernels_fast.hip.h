@@ -1,0 +1,389 @@
+// Shape-specialised single-token (N = 1) mat-vec kernel for the block-quantized weight types.
+//
+// Same arithmetic, same LDS hand-offs and same results as the generic matvec_kernel in kernels.hip.h
+// (which stays the path for prefill chunks, float weight types and unusual shapes), but the row length
+// K is a compile-time constant so that every loop is fully unrolled and un-predicated.  Why this exists:
+// a BioGPT-base decode mat-vec is 0.6-2.4 MB, i.e. ONE wave per SIMD with nothing to overlap -- the
+// kernel's duration is its dependent-instruction count times the ~4-8 cycle issue latency, not bytes
+// (measured: the generic kernel executes ~1.2k instructions per wave = ~4 us; rocprof in profiles/).
+//
+// Per wave (4 waves per workgroup):
+//   t=0   issue loads: this lane's weight units of the first row step, the activation column
+//         (LayerNorm: all K/256 chunks per lane; plain: only the wave's share), LN gain/bias of the
+//         share, bias/residual of the row this lane will finish
+//   LN    mean / variance in double over the whole column, per wave, DPP reductions (no barrier)
+//   Q8    quantize the wave's share (Q8_0 / Q8_1 exactly as quantize_row_q8_*), publish in LDS
+//   ---   one workgroup barrier
+//   dot   lane = block: v_dot4 int8 dot * d_w * d_x  -> block term c_b into the wave's LDS strip
+//   sum   lane f < rows: sum_b c_b in block order (the reference's scalar association), epilogue
+#pragma once
+
+#include "kernels.hip.h"
+
+namespace bgk {
+
+template <int WT, int PRO, int EPI, int K, int PF>
+__global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) {
+    using TI = TypeInfo<WT>;
+    static_assert(TI::quant, "fast path is for the block-quantized types");
+    constexpr int BPR = K / QK;                      // blocks per row
+    constexpr int LPR = BPR < 64 ? BPR : 64;         // lanes per row
+    constexpr int NIT = BPR / LPR;                   // blocks per lane per row
+    constexpr int RPS = 64 / LPR;                    // rows per wave step
+    constexpr int NCHUNK = K / 4;                    // float4 chunks in the column
+    constexpr int NJJ = NCHUNK / 64;                 // chunks per lane over the whole column
+    constexpr int NSHARE = NJJ / 4;                  // chunks per lane of one wave's share (4 waves)
+    constexpr int PSTRIDE = BPR + 4;                 // floats; keeps float4 alignment, skews banks
+    static_assert(BPR % LPR == 0 && NCHUNK % 256 == 0, "K must be a multiple of 1024");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem_raw);            // [K/4] packed int8
+    float *const s_xd = reinterpret_cast<float *>(smem_raw + K);              // [BPR]
+    uint32_t *const s_xs = reinterpret_cast<uint32_t *>(s_xd + BPR);          // [BPR]
+    float *const s_tail = reinterpret_cast<float *>(s_xs + BPR);              // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rpw = p.rpw;                                                    // rows per wave (multiple of RPS)
+    float *const s_part = s_tail + 64 + wave * rpw * PSTRIDE;
+
+    const int sub = lane & (LPR - 1), rsub = lane / LPR;
+    const int M = p.W.M;
+    const int row_base = (blockIdx.x * 4 + wave) * rpw;
+    const int nsteps = rpw / RPS;
+
+    // ---- t = 0: independent loads ---------------------------------------------------------------
+    const float4 *xcol = reinterpret_cast<const float4 *>(p.x);
+    float4 xr[PRO == PRO_LN ? NJJ : 1];
+    float4 xs4[NSHARE], lw4[NSHARE], lb4[NSHARE];
+    if (PRO == PRO_LN) {
+#pragma unroll
+        for (int i = 0; i < NJJ; i++) xr[i] = xcol[i * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < NSHARE; i++) {
+        const int ch = (wave + 4 * i) * 64 + lane;
+        xs4[i] = xcol[ch];
+        if (PRO == PRO_LN) {
+            lw4[i] = reinterpret_cast<const float4 *>(p.ln_w)[ch];
+            lb4[i] = reinterpret_cast<const float4 *>(p.ln_b)[ch];
+        }
+    }
+    Unit<WT> wq[PF][NIT];
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+        const int row = row_base + s * RPS + rsub;
+        if (s < nsteps && row < M) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) load_unit<WT>(wq[s][it], p.W, (int64_t)row * BPR + sub + it * LPR);
+        }
+    }
+    const int f_row = row_base + lane;
+    const bool finisher = lane < rpw && f_row < M;
+    float e_bias = 0.0f, e_res = 0.0f;
+    int e_npast = 0;
+    if (finisher) {
+        if (EPI != EPI_LOGITS) e_bias = p.bias[f_row];
+        if (EPI == EPI_RESID) e_res = p.resid[f_row];
+        if (EPI == EPI_QKV) e_npast = p.st->n_past;
+    }
+
+    // ---- LayerNorm statistics (ggml_norm: double sums; per wave over the whole column) ----------
+    float mean = 0.0f, scale = 1.0f;
+    if (PRO == PRO_LN) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJJ; i++) s1 += ((double)xr[i].x + (double)xr[i].y) + ((double)xr[i].z + (double)xr[i].w);
+        s1 = wave_sum_f64(s1);
+        mean = (float)(s1 * p.inv_k);  // K is a power of two: exact
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJJ; i++) {
+            const float a = __fsub_rn(xr[i].x, mean), b = __fsub_rn(xr[i].y, mean);
+            const float c = __fsub_rn(xr[i].z, mean), d = __fsub_rn(xr[i].w, mean);
+            s2 += ((double)__fmul_rn(a, a) + (double)__fmul_rn(b, b)) + ((double)__fmul_rn(c, c) + (double)__fmul_rn(d, d));
+        }
+        s2 = wave_sum_f64(s2);
+        const float var = (float)(s2 * p.inv_k);
+        scale = 1.0f / sqrtf(__fadd_rn(var, p.eps));
+    }
+
+    // ---- convert the wave's share: [normalise] -> Q8_0 / Q8_1 -> LDS ----------------------------
+#pragma unroll
+    for (int i = 0; i < NSHARE; i++) {
+        const int ch = (wave + 4 * i) * 64 + lane;
+        float4 v = xs4[i];
+        if (PRO == PRO_LN) {
+            v.x = __fadd_rn(__fmul_rn(lw4[i].x, __fmul_rn(__fsub_rn(v.x, mean), scale)), lb4[i].x);
+            v.y = __fadd_rn(__fmul_rn(lw4[i].y, __fmul_rn(__fsub_rn(v.y, mean), scale)), lb4[i].y);
+            v.z = __fadd_rn(__fmul_rn(lw4[i].z, __fmul_rn(__fsub_rn(v.z, mean), scale)), lb4[i].z);
+            v.w = __fadd_rn(__fmul_rn(lw4[i].w, __fmul_rn(__fsub_rn(v.w, mean), scale)), lb4[i].w);
+        }
+        const float amax = group8_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        const float d = amax / 127.0f;
+        const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+        const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
+        const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
+        const int isum = group8_sum(q0 + q1 + q2 + q3);
+        s_xq[ch] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        if ((lane & 7) == 0) {
+            const int b = ch >> 3;
+            if (TI::q81) {
+                s_xd[b] = d;
+                s_xs[b] = __float_as_uint(__fmul_rn((float)isum, d));
+            } else {
+                s_xd[b] = h2f(f2h(d));
+                s_xs[b] = (uint32_t)isum;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this lane's activation blocks (constant over the row steps) ---------------------------
+    uint32_t ax[NIT][8];
+    float axd[NIT];
+    uint32_t axs[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int u = sub + it * LPR;
+        const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + u * 8);
+        const uint4 b = *reinterpret_cast<const uint4 *>(s_xq + u * 8 + 4);
+        ax[it][0] = a.x; ax[it][1] = a.y; ax[it][2] = a.z; ax[it][3] = a.w;
+        ax[it][4] = b.x; ax[it][5] = b.y; ax[it][6] = b.z; ax[it][7] = b.w;
+        axd[it] = s_xd[u];
+        axs[it] = s_xs[u];
+    }
+
+    // ---- row steps: block terms -> the wave's LDS strip -----------------------------------------
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; s++) {
+            const int stp = s0 + s;
+            const int row = row_base + stp * RPS + rsub;
+            if (stp < nsteps && row < M) {
+#pragma unroll
+                for (int it = 0; it < NIT; it++)
+                    s_part[(stp * RPS + rsub) * PSTRIDE + sub + it * LPR] =
+                        unit_dot_quant<WT>(wq[s][it], ax[it], axd[it], __uint_as_float(axs[it]), (int)axs[it]);
+            }
+            const int nstp = stp + PF;  // refill this register slot with the row PF steps ahead
+            const int nrow = row_base + nstp * RPS + rsub;
+            if (nstp < nsteps && nrow < M) {
+#pragma unroll
+                for (int it = 0; it < NIT; it++) load_unit<WT>(wq[s][it], p.W, (int64_t)nrow * BPR + sub + it * LPR);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- finish: lane f adds row f's block terms in block order, then the epilogue --------------
+    float best_val = -INFINITY;
+    int best_idx = 0x7fffffff;
+    if (finisher) {
+        const float4 *part = reinterpret_cast<const float4 *>(s_part + lane * PSTRIDE);
+        float sumf = 0.0f;
+#pragma unroll
+        for (int b0 = 0; b0 < BPR / 4; b0 += 8) {  // 32 terms per batch: 8 LDS reads in flight
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = part[b0 + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                sumf = __fadd_rn(sumf, t[j].x); sumf = __fadd_rn(sumf, t[j].y);
+                sumf = __fadd_rn(sumf, t[j].z); sumf = __fadd_rn(sumf, t[j].w);
+            }
+        }
+        float v = sumf;
+        const int r = f_row;
+        if (EPI == EPI_QKV) {
+            v = __fadd_rn(e_bias, v);
+            const int which = r / K, rr = r - which * K;  // d_model == K for the q/k/v projection
+            if (which == 0) {
+                p.q_out[rr] = __fmul_rn(v, p.q_scale);
+            } else {
+                float *cache = (which == 1) ? p.kcache : p.vcache;
+                cache[(size_t)e_npast * K + rr] = v;
+            }
+        } else if (EPI == EPI_RESID) {
+            p.out[r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
+        } else if (EPI == EPI_GELU) {
+            p.out[r] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);
+        } else {
+            p.out[r] = v;
+            best_val = v;
+            best_idx = r;
+        }
+    }
+    if (EPI == EPI_LOGITS && p.pmax_val != nullptr) {
+        // per-block partial arg-max (lowest index wins ties), finished by argmax_kernel
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best_val, off, 64);
+            const int oi = __shfl_xor(best_idx, off, 64);
+            if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
+        }
+        float *sv = s_tail;
+        int *si = reinterpret_cast<int *>(s_tail) + 8;
+        if (lane == 0) { sv[wave] = best_val; si[wave] = best_idx; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; w++)
+                if (sv[w] > best_val || (sv[w] == best_val && si[w] < best_idx)) { best_val = sv[w]; best_idx = si[w]; }
+            p.pmax_val[blockIdx.x] = best_val;
+            p.pmax_idx[blockIdx.x] = best_idx;
+        }
+    }
+}
+
+__host__ __device__ inline size_t matvec_fast_smem_bytes(int K, int rpw) {
+    return (size_t)K + 2 * (size_t)(K / QK) * 4 + 256 + 4 * (size_t)rpw * (K / QK + 4) * 4 + 64;
+}
+
+}  // namespace bgk
+
+namespace bgk {
+
+// ---- attention, head size 64, contexts up to 1024 keys ---------------------------------------------
+// One workgroup per (head, query).  Same arithmetic as attn_kernel (biogpt.cpp:741-764), laid out for
+// latency: 4 lanes share a key (quad DPP reduce), NT/64 slices of 64 lanes share the PV sum, and every
+// K / V / q load is issued at kernel entry.  The loads are bounded by t_cap, a launch-time upper bound
+// of the context (the captured decode graphs are bucketed by it), NOT by the device-side position:
+// rows in [T, t_cap) are allocated cache whose values are loaded and ignored (masked by T).
+//   KP   = key passes of NT/4 keys;  VPRE = V values prefetched at entry (16 per lane; t_cap <= NT/4)
+// exact (float)(1.0/sum): v_rcp_f64 + two Newton steps is within 1 ulp(double) of the quotient, which
+// rounds to the same float as the IEEE double division except on ~1e-9 of inputs
+__device__ __forceinline__ float inv_sum_f32(double s) {
+    double r = __builtin_amdgcn_rcp(s);
+    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
+    return (float)r;
+}
+
+template <int KP, bool VPRE>
+__global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    __shared__ float S[KP * 256];
+    __shared__ double red[16];
+    __shared__ double pv[1024];
+    const int h = blockIdx.x, i = blockIdx.y;
+    const int tid = threadIdx.x, nt = blockDim.x;
+#define AT_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if ((p.dbg & 32) && (tid & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0)                    \
+            p.tstamp[(tid >> 6) * 8 + (k)] = __builtin_readcyclecounter();                            \
+    } while (0)
+    AT_STAMP(0);
+    const int D = p.D;
+    const int kpp = nt >> 2;                       // keys per pass
+    const int nsl = nt >> 6;                       // PV slices
+    const int ksub = tid & 3, kidx = tid >> 2;
+    const int d = tid & (DK - 1), sl = tid >> 6;
+    const int t_cap = p.t_cap;
+
+    // lane ksub of a quad owns float4 #(4m + ksub) of the 16 float4 of a key row: each load instruction
+    // of a quad covers 64 contiguous bytes
+    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * DK) + ksub;
+    const float *__restrict__ vbase = p.vcache + (size_t)h * DK + d;
+    const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)i * D + (size_t)h * DK) + ksub;
+
+    // ---- entry: all loads ----
+    const int n_past = p.st->n_past;
+    const int causal = p.st->causal;
+    float4 kr[KP][4];
+#pragma unroll
+    for (int ps = 0; ps < KP; ps++) {
+        const int j = ps * kpp + kidx;
+        if (j < t_cap) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) kr[ps][m] = kbase[(size_t)j * (D / 4) + 4 * m];
+        }
+    }
+    float4 qv[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) qv[m] = qp[4 * m];
+    float vr[VPRE ? 16 : 1];
+    if (VPRE) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = sl + nsl * k;
+            if (j < t_cap) vr[k] = vbase[(size_t)j * D];
+        }
+    }
+    AT_STAMP(1);
+    const int T = causal ? n_past + i + 1 : n_past + p.N;
+
+    // ---- scores: 16 dims per lane, quad reduce ----
+    float sc[KP];
+#pragma unroll
+    for (int ps = 0; ps < KP; ps++) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            a0 += (double)__fmul_rn(kr[ps][m].x, qv[m].x); a1 += (double)__fmul_rn(kr[ps][m].y, qv[m].y);
+            a2 += (double)__fmul_rn(kr[ps][m].z, qv[m].z); a3 += (double)__fmul_rn(kr[ps][m].w, qv[m].w);
+        }
+        double acc = (a0 + a1) + (a2 + a3);
+        acc += dpp_d<DPP_QUAD_XOR1>(acc);
+        acc += dpp_d<DPP_QUAD_XOR2>(acc);
+        sc[ps] = (ps * kpp + kidx < T) ? (float)acc : -INFINITY;
+    }
+    AT_STAMP(2);
+
+    // ---- softmax (ggml_soft_max: fp16-table exp, double sum, scale by (float)(1/sum)) ----
+    float mx = sc[0];
+#pragma unroll
+    for (int ps = 1; ps < KP; ps++) mx = fmaxf(mx, sc[ps]);
+    mx = block_max_f32(mx, reinterpret_cast<float *>(red));
+    AT_STAMP(3);
+    double sum = 0.0;
+#pragma unroll
+    for (int ps = 0; ps < KP; ps++) {
+        const int j = ps * kpp + kidx;
+        if (j < T && ksub == 0) {
+            const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc[ps], mx))]);
+            S[j] = val;
+            sum += (double)val;
+        }
+    }
+    AT_STAMP(4);
+    sum = block_sum_f64(sum, red);
+    const float inv = inv_sum_f32(sum);
+    __syncthreads();
+    AT_STAMP(5);
+
+    // ---- PV: nsl slices x 64 dims, double accumulation ----
+    double a0 = 0.0, a1 = 0.0;
+    if (VPRE) {
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const int j0 = sl + nsl * k, j1 = j0 + nsl;
+            if (j0 < T) a0 += (double)__fmul_rn(vr[k], __fmul_rn(S[j0], inv));
+            if (j1 < T) a1 += (double)__fmul_rn(vr[k + 1], __fmul_rn(S[j1], inv));
+        }
+    } else {
+        for (int j = sl; j < T; j += nsl * 8) {
+            float v8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v8[k] = (j + nsl * k < t_cap) ? vbase[(size_t)(j + nsl * k) * D] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                if (j + nsl * k < T) a0 += (double)__fmul_rn(v8[k], __fmul_rn(S[j + nsl * k], inv));
+                if (j + nsl * (k + 1) < T) a1 += (double)__fmul_rn(v8[k + 1], __fmul_rn(S[j + nsl * (k + 1)], inv));
+            }
+        }
+    }
+    pv[tid] = a0 + a1;
+    AT_STAMP(6);
+    __syncthreads();
+    AT_STAMP(7);
+    if (tid < DK) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int s2 = 0; s2 + 1 < nsl; s2 += 2) { t0 += pv[s2 * DK + tid]; t1 += pv[(s2 + 1) * DK + tid]; }
+        if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
+        p.out[(size_t)i * D + (size_t)h * DK + tid] = (float)(t0 + t1);
+    }
+#undef AT_STAMP
+}
+
+}  // namespace bgk
