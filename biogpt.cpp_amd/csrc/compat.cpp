@@ -1,0 +1,106 @@
+// C++ wrappers with the reference's signatures (include/biogpt_compat.h) over the C-ABI, plus the
+// shims for the 11 ggml symbols examples/main/main.cpp calls directly.
+#include "../../include/biogpt_compat.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+// distinct non-null addresses for the opaque handles callers only pass around / free
+char g_backend_tag, g_buffer_tag, g_allocr_tag, g_graph_tag;
+std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+}  // namespace
+
+extern "C" {
+void ggml_time_init(void) { g_t0 = std::chrono::steady_clock::now(); }
+int64_t ggml_time_us(void) { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g_t0).count(); }
+size_t ggml_backend_get_alignment(ggml_backend_t) { return 256; }
+struct ggml_allocr *ggml_allocr_new_measure(size_t) { return reinterpret_cast<ggml_allocr *>(&g_allocr_tag); }
+size_t ggml_allocr_alloc_graph(struct ggml_allocr *, struct ggml_cgraph *) { return 0; }  // scratch lives in the engine
+void ggml_allocr_free(struct ggml_allocr *) {}
+ggml_backend_buffer_t ggml_backend_alloc_buffer(ggml_backend_t, size_t) { return reinterpret_cast<ggml_backend_buffer_t>(&g_buffer_tag); }
+struct ggml_allocr *ggml_allocr_new_from_buffer(ggml_backend_buffer_t) { return reinterpret_cast<ggml_allocr *>(&g_allocr_tag); }
+void ggml_free(struct ggml_context *ctx) { biogpt_hip_free(reinterpret_cast<biogpt_hip_ctx *>(ctx)); }
+void ggml_backend_buffer_free(ggml_backend_buffer_t) {}
+void ggml_backend_free(ggml_backend_t) {}
+}
+
+bool biogpt_model_load(const std::string &fname, biogpt_model &model, biogpt_vocab &vocab, const uint8_t verbosity) {
+    const char *dev = std::getenv("BIOGPT_HIP_DEVICE");
+    biogpt_hip_ctx *ctx = biogpt_hip_load(fname.c_str(), dev ? std::atoi(dev) : 0, verbosity);
+    if (!ctx) return false;  // message already printed, reference-style
+    biogpt_hip_hparams hp;
+    biogpt_hip_get_hparams(ctx, &hp);
+    model.hparams.n_vocab = hp.n_vocab; model.hparams.n_layer = hp.n_layer; model.hparams.n_head = hp.n_head;
+    model.hparams.n_positions = hp.n_positions; model.hparams.d_ff = hp.d_ff; model.hparams.d_model = hp.d_model;
+    model.hparams.ftype = hp.ftype; model.hparams.n_merges = hp.n_merges;
+    model.layers_decoder.assign((size_t)hp.n_layer, biogpt_layer_decoder());
+    model.n_loaded = biogpt_hip_n_tensors(ctx);
+    model.ctx = reinterpret_cast<ggml_context *>(ctx);
+    model.backend = reinterpret_cast<ggml_backend_t>(&g_backend_tag);
+    model.buffer_w = model.buffer_kv = reinterpret_cast<ggml_backend_buffer_t>(&g_buffer_tag);
+
+    vocab.n_vocab = hp.n_vocab;
+    vocab.n_merges = hp.n_merges;
+    for (int32_t i = 0; i < hp.n_vocab; i++) {  // biogpt.cpp:86-100
+        const char *p = nullptr; int32_t n = 0;
+        if (biogpt_hip_vocab_token(ctx, i, &p, &n) != 0) break;
+        std::string w(p, (size_t)n);
+        vocab.token_to_id[w] = i;
+        vocab.id_to_token[i] = w;
+    }
+    for (int32_t r = 0; r < hp.n_merges; r++) {  // biogpt.cpp:131-155: "left right" -> rank
+        const char *p = nullptr; int32_t n = 0;
+        if (biogpt_hip_merge(ctx, r, &p, &n) != 0) break;
+        const std::string m(p, (size_t)n);
+        const size_t sp = m.find(' ');
+        if (sp == std::string::npos) continue;
+        vocab.bpe_ranks[word_pair(m.substr(0, sp), m.substr(sp + 1))] = r;
+    }
+    return true;
+}
+
+struct ggml_cgraph *biogpt_graph(const biogpt_model &, struct ggml_allocr *, const token_sequence &, const int) {
+    return reinterpret_cast<ggml_cgraph *>(&g_graph_tag);  // main.cpp:59 only feeds it to ggml_allocr_alloc_graph
+}
+
+bool biogpt_eval(const biogpt_model &model, const token_sequence &embed_inp, std::vector<float> &logits,
+                 struct ggml_allocr *, const int n_past, const int /*n_threads: CPU-backend knob*/) {
+    biogpt_hip_ctx *ctx = biogpt_model_hip(model);
+    logits.resize((size_t)model.hparams.n_vocab);  // biogpt.cpp:843
+    return biogpt_hip_eval(ctx, embed_inp.data(), (int32_t)embed_inp.size(), n_past, logits.data()) == 0;
+}
+
+// temperature -> top-k (partial sort) -> softmax in double -> top-p cut + renormalise -> one draw
+// (biogpt.cpp:908-980).  With top_k == 1 this is arg-max, the draw is still consumed.
+biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
+                                           double temp, std::mt19937 &rng) {
+    const int n = (int)vocab.id_to_token.size();
+    typedef std::pair<double, biogpt_vocab::id> scored;
+    std::vector<scored> cand((size_t)n);
+    const double inv_t = 1.0 / temp;
+    for (int i = 0; i < n; i++) cand[(size_t)i] = scored(logits[i] * inv_t, i);
+    top_k = std::max(1, std::min(top_k, n));
+    std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(), [](const scored &a, const scored &b) { return a.first > b.first; });
+    cand.resize((size_t)top_k);
+    double peak = -INFINITY;
+    for (const scored &c : cand) peak = std::max(peak, c.first);
+    std::vector<double> prob(cand.size());
+    double total = 0.0;
+    for (size_t i = 0; i < cand.size(); i++) { prob[i] = std::exp(cand[i].first - peak); total += prob[i]; }
+    for (double &p : prob) p /= total;
+    if (top_p < 1.0f) {
+        double run = 0.0;
+        for (int i = 0; i < top_k; i++) {
+            run += prob[(size_t)i];
+            if (run >= top_p) { prob.resize((size_t)i + 1); cand.resize((size_t)i + 1); break; }
+        }
+        const double renorm = 1.0 / run;
+        for (double &p : prob) p *= renorm;
+    }
+    std::discrete_distribution<> pick(prob.begin(), prob.end());
+    return cand[(size_t)pick(rng)].second;
+}

@@ -326,6 +326,8 @@ bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvSha
     p.upr = s.upr; p.lpr_log2 = s.lpr_log2; p.nit = s.nit; p.rpw = s.rpw;
     p.eps = 1e-5f;  // NORM_EPS biogpt.cpp:24
     p.D = c->hp.d_model;
+    p.dk = c->hp.d_model / c->hp.n_head;
+    p.P = c->hp.n_positions;
     p.st = c->state;
     p.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
     p.dbg = env_int("BIOGPT_HIP_DBG", 0) | (g_launch_parity << 8);
@@ -841,11 +843,19 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
 
 int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t count, float *out) {
     if (!ctx || !out) BG_FAIL(-1, "null argument");
-    const size_t total = (size_t)ctx->hp.n_layer * ctx->hp.n_positions * ctx->hp.d_model;
+    const size_t L = (size_t)ctx->hp.n_layer, P = (size_t)ctx->hp.n_positions, D = (size_t)ctx->hp.d_model, H = (size_t)ctx->hp.n_head;
+    const size_t dk = D / H, total = L * P * D;
     if (offset + count > total) BG_FAIL(-1, "KV range out of bounds");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(-2, hipMemcpy(out, (which ? ctx->memory_v : ctx->memory_k) + offset, count * 4, hipMemcpyDeviceToHost));
+    // the device cache is head-major [layer][head][pos][dk]; present the reference's flat
+    // [layer][pos][d_model] view (biogpt.cpp:331-335) to the caller
+    std::vector<float> dev(total);
+    HIP_TRY(-2, hipMemcpy(dev.data(), which ? ctx->memory_v : ctx->memory_k, total * 4, hipMemcpyDeviceToHost));
+    for (size_t e = offset; e < offset + count; e++) {
+        const size_t l = e / (P * D), pos = (e / D) % P, dm = e % D, h = dm / dk, dd = dm % dk;
+        out[e - offset] = dev[((l * H + h) * P + pos) * dk + dd];
+    }
     return 0;
 }
 

@@ -17,6 +17,9 @@
 // scaled by d_w * d_x; LayerNorm statistics and the F32 attention dots accumulate in double;
 // GELU / softmax-exp go through 65536-entry fp16 tables uploaded by the host.
 //
+// KV cache: F32 like the reference (F4) but HEAD-MAJOR [layer][head][position][dk] -- the reference's
+// [layer][position][d_model] puts one head's rows 4 KB apart, which serialises on a memory channel.
+//
 // Device data layout (ours; the file format is only the drop-in boundary): every quantized matrix
 // is repacked at load time into structure-of-arrays form so that a wave reads 16 aligned bytes per
 // lane:  qs[row][block] = 16 B of nibbles (32 B of int8 for Q8_0), sc[row][block] = fp16 d
@@ -193,8 +196,10 @@ struct MatvecParams {
     int32_t ldo;
     // EPI_QKV
     float *q_out;        // [N][D]
-    float *kcache;       // layer slice of memory_k: [P][D]
+    float *kcache;       // layer slice of memory_k, head-major: [H][P][dk]
     float *vcache;
+    int32_t dk;          // head size
+    int32_t P;           // n_positions
     int32_t D;
     float q_scale;
     const DevState *st;
@@ -581,7 +586,8 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
                 p.q_out[(size_t)col * p.D + rr] = __fmul_rn(v, p.q_scale);
             } else {
                 float *cache = (which == 1) ? p.kcache : p.vcache;
-                cache[(size_t)(npast + col) * p.D + rr] = v;
+                const int hh = rr / p.dk, dd = rr - hh * p.dk;  // head-major cache: [H][P][dk]
+                cache[((size_t)hh * p.P + (npast + col)) * p.dk + dd] = v;
             }
         } else if (EPI == EPI_RESID) {
             v = __fadd_rn(v, bias);
@@ -650,8 +656,8 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnParams p) {
     double *pv = red + 16;                                                        // [nt]
 
     const float *__restrict__ qrow = p.q + (size_t)i * D + (size_t)h * dk;        // wave-uniform address
-    const float *__restrict__ kbase = p.kcache + (size_t)h * dk;
-    const float *__restrict__ vbase = p.vcache + (size_t)h * dk;
+    const float *__restrict__ kbase = p.kcache + (size_t)h * p.P * dk;   // head-major cache: [H][P][dk]
+    const float *__restrict__ vbase = p.vcache + (size_t)h * p.P * dk;
 
     // ---- scores ----
     float sc[ATTN_MAXK];
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnParams p) {
         const int j = tid + kk * nt;
         sc[kk] = -INFINITY;
         if (j < T) {
-            const float4 *kr = reinterpret_cast<const float4 *>(kbase + (size_t)j * D);
+            const float4 *kr = reinterpret_cast<const float4 *>(kbase + (size_t)j * dk);
             double acc = 0.0;
             for (int d4 = 0; d4 < (dk >> 2); d4++) {
                 const float4 kv = kr[d4];
@@ -701,12 +707,12 @@ __global__ __launch_bounds__(1024) void attn_kernel(const AttnParams p) {
     if (sl < nsl) {
         int j = sl;
         for (; j + 3 * nsl < T; j += 4 * nsl) {
-            const float v0 = vbase[(size_t)j * D + d], v1 = vbase[(size_t)(j + nsl) * D + d];
-            const float v2 = vbase[(size_t)(j + 2 * nsl) * D + d], v3 = vbase[(size_t)(j + 3 * nsl) * D + d];
+            const float v0 = vbase[(size_t)j * dk + d], v1 = vbase[(size_t)(j + nsl) * dk + d];
+            const float v2 = vbase[(size_t)(j + 2 * nsl) * dk + d], v3 = vbase[(size_t)(j + 3 * nsl) * dk + d];
             acc += (double)__fmul_rn(v0, S[j]); acc += (double)__fmul_rn(v1, S[j + nsl]);
             acc += (double)__fmul_rn(v2, S[j + 2 * nsl]); acc += (double)__fmul_rn(v3, S[j + 3 * nsl]);
         }
-        for (; j < T; j += nsl) acc += (double)__fmul_rn(vbase[(size_t)j * D + d], S[j]);
+        for (; j < T; j += nsl) acc += (double)__fmul_rn(vbase[(size_t)j * dk + d], S[j]);
     }
     pv[tid] = acc;
     __syncthreads();

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
                 p.q_out[rr] = __fmul_rn(v, p.q_scale);
             } else {
                 float *cache = (which == 1) ? p.kcache : p.vcache;
-                cache[(size_t)e_npast * K + rr] = v;
+                const int hh = rr / p.dk, dd = rr - hh * p.dk;  // head-major cache: [H][P][dk]
+                cache[((size_t)hh * p.P + e_npast) * p.dk + dd] = v;
             }
         } else if (EPI == EPI_RESID) {
             p.out[r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
     // lane ksub of a quad owns float4 #(4m + ksub) of the 16 float4 of a key row: each load instruction
     // of a quad covers 64 contiguous bytes
-    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * DK) + ksub;
-    const float *__restrict__ vbase = p.vcache + (size_t)h * DK + d;
+    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + ksub;   // [H][P][dk]
+    const float *__restrict__ vbase = p.vcache + (size_t)h * p.P * DK + d;
     const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)i * D + (size_t)h * DK) + ksub;
 
     // ---- entry: all loads ----
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         const int j = ps * kpp + kidx;
         if (j < t_cap) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) kr[ps][m] = kbase[(size_t)j * (D / 4) + 4 * m];
+            for (int m = 0; m < 4; m++) kr[ps][m] = kbase[(size_t)j * (DK / 4) + 4 * m];
         }
     }
     float4 qv[4];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = sl + nsl * k;
-            if (j < t_cap) vr[k] = vbase[(size_t)j * D];
+            if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
         }
     }
     AT_STAMP(1);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         for (int j = sl; j < T; j += nsl * 8) {
             float v8[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v8[k] = (j + nsl * k < t_cap) ? vbase[(size_t)(j + nsl * k) * D] : 0.0f;
+            for (int k = 0; k < 8; k++) v8[k] = (j + nsl * k < t_cap) ? vbase[(size_t)(j + nsl * k) * DK] : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
                 if (j + nsl * k < T) a0 += (double)__fmul_rn(v8[k], __fmul_rn(S[j + nsl * k], inv));
