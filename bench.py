@@ -47,6 +47,10 @@ def ensure_model(pkg, workdir, ftype_name, n_layer):
             os.replace(f32 + ".tmp", f32)
         if ftype_name == "f32":
             return f32
+        if ftype_name == "f16":
+            pkg.write_synthetic(out + ".tmp", seed=SEED, n_layer=n_layer, ftype=1)
+            os.replace(out + ".tmp", out)
+            return out
         pkg.quantize_file(f32, out + ".tmp", ftype_name)
         os.replace(out + ".tmp", out)
         log("bench: wrote %s in %.1f s" % (out, time.time() - t0))
@@ -101,12 +105,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("BIOGPT_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path on one GPU (tests)
+    if world > 1 or force_dist:
         dist = replicas.init_process_group("nccl")
 
     # ---- model: rank 0 loads the file; the packed arena is broadcast (RCCL over xGMI) ----------------
     t_load0 = time.time()
-    if world == 1:
+    if world == 1 and not force_dist:
         path = ensure_model(pkg, args.workdir, args.ftype, args.n_layer)
         model = pkg.BiogptModel.load(path, device=local_rank)
         arena_t = None

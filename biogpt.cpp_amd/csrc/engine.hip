@@ -173,6 +173,9 @@ struct biogpt_hip_ctx {
 
     float *memory_k = nullptr, *memory_v = nullptr;
     float *x = nullptr, *x1 = nullptr, *q = nullptr, *att = nullptr, *h = nullptr;
+    int8_t *aq_q[2] = {nullptr, nullptr};     // producer-quantized activations: [0] attention out (d_model), [1] fc1 out (d_ff)
+    float *aq_d[2] = {nullptr, nullptr};
+    uint32_t *aq_s[2] = {nullptr, nullptr};
     float *logits = nullptr;      // [n_vocab]
     float *logits_all = nullptr;  // lazily [n][n_vocab]
     size_t logits_all_rows = 0;
@@ -269,7 +272,7 @@ hipError_t launch_fast_k(bgk::MatvecParams p, hipStream_t st) {
     p.rpw = RPS * steps;
     const int grid = (M + 4 * p.rpw - 1) / (4 * p.rpw);
     const size_t sm = bgk::matvec_fast_smem_bytes(K, p.rpw);
-    if (steps >= 4) hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, 4>), dim3(grid), dim3(256), sm, st, p);
+    if (steps > 1) hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, 4>), dim3(grid), dim3(256), sm, st, p);
     else hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, 1>), dim3(grid), dim3(256), sm, st, p);
     return hipGetLastError();
 }
@@ -294,6 +297,39 @@ bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err
         *grid_out = (p.W.M + 4 * RPS * steps - 1) / (4 * RPS * steps);
     }
     return true;
+}
+
+// fast-chain launches with producer-quantized activations (attention -> out_proj, fc1 -> fc2)
+template <int WT, int PRO, int EPI, int K, int PF>
+hipError_t launch_fast_explicit(bgk::MatvecParams p, int steps, hipStream_t st) {
+    constexpr int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
+    p.rpw = RPS * steps;
+    const int grid = (p.W.M + 4 * p.rpw - 1) / (4 * p.rpw);
+    hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, PF>), dim3(grid), dim3(256), bgk::matvec_fast_smem_bytes(K, p.rpw), st, p);
+    return hipGetLastError();
+}
+
+enum ChainOp { CHAIN_OPROJ, CHAIN_FC1, CHAIN_FC2 };
+template <int WT>
+hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
+    if constexpr (bgk::TypeInfo<WT>::quant) {
+        switch (op) {
+            case CHAIN_OPROJ: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 1024, 1>(p, 1, st);
+            case CHAIN_FC1: return launch_fast_explicit<WT, bgk::PRO_LN, bgk::EPI_GELU_Q8, 1024, 4>(p, 4, st);  // 32 rows / workgroup = one Q8 block
+            case CHAIN_FC2: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 4096, 1>(p, 1, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_chain(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
+    switch (p.W.type) {
+        case T_Q4_0: return launch_chain_typed<bgk::W_Q4_0>(op, p, st);
+        case T_Q4_1: return launch_chain_typed<bgk::W_Q4_1>(op, p, st);
+        case T_Q5_0: return launch_chain_typed<bgk::W_Q5_0>(op, p, st);
+        case T_Q5_1: return launch_chain_typed<bgk::W_Q5_1>(op, p, st);
+        case T_Q8_0: return launch_chain_typed<bgk::W_Q8_0>(op, p, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int WT, int PRO, int EPI>
@@ -327,6 +363,7 @@ bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvSha
     p.eps = 1e-5f;  // NORM_EPS biogpt.cpp:24
     p.D = c->hp.d_model;
     p.dk = c->hp.d_model / c->hp.n_head;
+    p.dk_log2 = ilog2(p.dk);
     p.P = c->hp.n_positions;
     p.st = c->state;
     p.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
@@ -353,6 +390,12 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
     if (attn_threads % dk != 0 || t_max > bgk::ATTN_MAXK * attn_threads)
         BG_FAIL(false, "context of %d tokens / head size %d not supported by the attention kernel", t_max, dk);
 
+    // single-token fast chain: BioGPT-base shapes, block-quantized weights -> producer-side Q8 hand-offs
+    const int32_t wt = ftype_to_type(hp.ftype);
+    const bool chain = N == 1 && is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
+                       !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
+    const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
+
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
                        sqrtf((float)D), c->x, D);
@@ -377,6 +420,8 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
             a.N = N; a.D = D; a.dk = dk; a.P = P;
             a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
+            a.q81 = q81;
+            if (chain) { a.oq_q = c->aq_q[0]; a.oq_d = c->aq_d[0]; a.oq_s = c->aq_s[0]; }
             if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
                 // loads are bounded by t_cap (multiple of 64); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);
@@ -397,7 +442,12 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.x = c->att; p.ldx = D; p.N = N;
             p.bias = dev_vec(c, L.o_b);
             p.resid = c->x; p.ldr = D; p.out = c->x1; p.ldo = D;
-            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+            if (chain) {
+                p.aq_q = c->aq_q[0]; p.aq_d = c->aq_d[0]; p.aq_s = c->aq_s[0];
+                HIP_TRY(false, launch_chain(CHAIN_OPROJ, p, st));
+            } else {
+                HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+            }
         }
         {  // LN1 + fc1 + bias + GELU
             const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw, N);
@@ -406,7 +456,12 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.ln_w = dev_vec(c, L.ln1_w); p.ln_b = dev_vec(c, L.ln1_b);
             p.bias = dev_vec(c, L.fc1_b);
             p.out = c->h; p.ldo = F;
-            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, st)));
+            if (chain) {
+                p.oq_q = c->aq_q[1]; p.oq_d = c->aq_d[1]; p.oq_s = c->aq_s[1];
+                HIP_TRY(false, launch_chain(CHAIN_FC1, p, st));
+            } else {
+                HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, st)));
+            }
         }
         {  // fc2 + bias + residual
             const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw, N);
@@ -414,7 +469,12 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.x = c->h; p.ldx = F; p.N = N;
             p.bias = dev_vec(c, L.fc2_b);
             p.resid = c->x1; p.ldr = D; p.out = c->x; p.ldo = D;
-            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+            if (chain) {
+                p.aq_q = c->aq_q[1]; p.aq_d = c->aq_d[1]; p.aq_s = c->aq_s[1];
+                HIP_TRY(false, launch_chain(CHAIN_FC2, p, st));
+            } else {
+                HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
+            }
         }
     }
     {  // final LayerNorm + lm_head; only the rows that are returned (F8)
@@ -489,6 +549,12 @@ bool alloc_runtime(biogpt_hip_ctx *c) {
     HIP_TRY(false, hipMalloc(&c->att, P * D * 4));
     HIP_TRY(false, hipMalloc(&c->h, P * F * 4));
     HIP_TRY(false, hipMalloc(&c->logits, V * 4));
+    for (int k = 0; k < 2; k++) {
+        const size_t n = k == 0 ? D : F;
+        HIP_TRY(false, hipMalloc(&c->aq_q[k], n));
+        HIP_TRY(false, hipMalloc(&c->aq_d[k], n / 32 * 4 + 16));
+        HIP_TRY(false, hipMalloc(&c->aq_s[k], n / 32 * 4 + 16));
+    }
     c->pmax_cap = 4096;
     HIP_TRY(false, hipMalloc(&c->pmax_val, (size_t)c->pmax_cap * 4));
     HIP_TRY(false, hipMalloc(&c->pmax_idx, (size_t)c->pmax_cap * 4));
@@ -606,7 +672,7 @@ void destroy(biogpt_hip_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->owns_arena && c->arena) (void)hipFree(c->arena);
     for (void *p : {(void *)c->memory_k, (void *)c->memory_v, (void *)c->x, (void *)c->x1, (void *)c->q, (void *)c->att,
-                    (void *)c->h, (void *)c->logits, (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
+                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     delete c;
@@ -869,7 +935,9 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     const int tw = target_wgs();
     // cycling through the layers defeats L2 residency of one matrix; the whole model still
     // fits the 256 MiB Infinity Cache -- stated in DESIGN.md
-    int last_grid = 0;
+    const int32_t wt0 = ftype_to_type(hp.ftype);
+    const bool chain = is_quantized(wt0) && D == 1024 && F == 4096 && D / hp.n_head == 64 && P <= 1024 &&
+                       !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
     auto launch = [&](int l) -> bool {
         g_launch_parity ^= 1;
         const LayerSlots &L = ctx->plan.layers[(size_t)(hp.n_layer ? l % hp.n_layer : 0)];
@@ -878,13 +946,15 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             bgk::MatvecParams p = mv_base(ctx, L.fc1, s);
             p.x = ctx->x1; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, L.ln1_w); p.ln_b = dev_vec(ctx, L.ln1_b);
             p.bias = dev_vec(ctx, L.fc1_b); p.out = ctx->h; p.ldo = F;
-            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, ctx->stream)));
+            if (chain) { p.oq_q = ctx->aq_q[1]; p.oq_d = ctx->aq_d[1]; p.oq_s = ctx->aq_s[1]; HIP_TRY(false, launch_chain(CHAIN_FC1, p, ctx->stream)); }
+            else HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, ctx->stream)));
         } else if (which == 1) {
             const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw);
             bgk::MatvecParams p = mv_base(ctx, L.fc2, s);
             p.x = ctx->h; p.ldx = F; p.N = 1; p.bias = dev_vec(ctx, L.fc2_b);
             p.resid = ctx->x1; p.ldr = D; p.out = ctx->x; p.ldo = D;
-            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
+            if (chain) { p.aq_q = ctx->aq_q[1]; p.aq_d = ctx->aq_d[1]; p.aq_s = ctx->aq_s[1]; HIP_TRY(false, launch_chain(CHAIN_FC2, p, ctx->stream)); }
+            else HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
         } else if (which == 2) {
             const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw);
             bgk::MatvecParams p = mv_base(ctx, L.qkv, s);
@@ -898,7 +968,8 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             bgk::MatvecParams p = mv_base(ctx, L.o, s);
             p.x = ctx->att; p.ldx = D; p.N = 1; p.bias = dev_vec(ctx, L.o_b);
             p.resid = ctx->x; p.ldr = D; p.out = ctx->x1; p.ldo = D;
-            HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
+            if (chain) { p.aq_q = ctx->aq_q[0]; p.aq_d = ctx->aq_d[0]; p.aq_s = ctx->aq_s[0]; HIP_TRY(false, launch_chain(CHAIN_OPROJ, p, ctx->stream)); }
+            else HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
         } else {
             const MatSlot &m = ctx->plan.lm_head;
             const MvShape s = mv_shape(m.type, m.M, m.K, tw);

@@ -41,8 +41,8 @@ namespace bgk {
 constexpr int QK = 32;
 
 enum WType : int { W_F32 = 0, W_F16 = 1, W_Q4_0 = 2, W_Q4_1 = 3, W_Q5_0 = 6, W_Q5_1 = 7, W_Q8_0 = 8 };
-enum Prologue : int { PRO_PLAIN = 0, PRO_LN = 1 };
-enum Epilogue : int { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
+enum Prologue : int { PRO_PLAIN = 0, PRO_LN = 1, PRO_Q8IN = 2 };  // Q8IN: activation already quantized by the producer kernel
+enum Epilogue : int { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_GELU_Q8 = 4 };  // GELU_Q8: fc1 writes its output as Q8 blocks
 
 // Per-context mutable device state: the decode position and the token ring the kernels read
 // their inputs from (so a captured graph can advance itself without host involvement).
@@ -198,7 +198,8 @@ struct MatvecParams {
     float *q_out;        // [N][D]
     float *kcache;       // layer slice of memory_k, head-major: [H][P][dk]
     float *vcache;
-    int32_t dk;          // head size
+    int32_t dk;          // head size (power of two)
+    int32_t dk_log2;
     int32_t P;           // n_positions
     int32_t D;
     float q_scale;
@@ -208,6 +209,9 @@ struct MatvecParams {
     // EPI_LOGITS: fused partial arg-max (N == 1 only); may be null
     float *pmax_val;
     int32_t *pmax_idx;
+    // producer-quantized activations (single-token fast chain): 32 int8 per block + scale + block sum
+    const int8_t *aq_q; const float *aq_d; const uint32_t *aq_s;   // PRO_Q8IN input
+    int8_t *oq_q; float *oq_d; uint32_t *oq_s;                     // EPI_GELU_Q8 output
     double inv_k;        // 1.0 / K
     int32_t k_pow2;      // K is a power of two: sum * inv_k == sum / K exactly (skips two f64 divisions)
     unsigned long long *tstamp;  // profiling: [2][grid][8] shader-clock stamps when dbg & 32
@@ -632,6 +636,8 @@ struct AttnParams {
     const uint16_t *exp_tab;
     int32_t N, D, dk, P;
     int32_t t_cap;                // launch-time upper bound of the context (fast kernel load bound)
+    int8_t *oq_q; float *oq_d; uint32_t *oq_s;  // optional Q8 copy of the output for the fast out_proj (null: off)
+    int32_t q81;                  // 1: Q8_1 activation form (Q4_1 / Q5_1 weights), 0: Q8_0
     unsigned long long *tstamp;  // profiling (dbg & 32): [16 waves][8] stamps of block (0,0)
     int32_t dbg;
 };

@@ -48,23 +48,39 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const int M = p.W.M;
     const int row_base = (blockIdx.x * 4 + wave) * rpw;
-    const int nsteps = rpw / RPS;
+    const int nsteps = (PF == 1) ? 1 : rpw / RPS;
 
     // ---- t = 0: independent loads ---------------------------------------------------------------
     const float4 *xcol = reinterpret_cast<const float4 *>(p.x);
     float4 xr[PRO == PRO_LN ? NJJ : 1];
     float4 xs4[NSHARE], lw4[NSHARE], lb4[NSHARE];
-    if (PRO == PRO_LN) {
+    uint32_t ax[NIT][8];   // this lane's activation blocks (constant over the row steps)
+    float axd[NIT];
+    uint32_t axs[NIT];
+    if (PRO == PRO_Q8IN) {
+        // the producer kernel (attention / fc1) already quantized the activation: fetch this lane's blocks
 #pragma unroll
-        for (int i = 0; i < NJJ; i++) xr[i] = xcol[i * 64 + lane];
-    }
-#pragma unroll
-    for (int i = 0; i < NSHARE; i++) {
-        const int ch = (wave + 4 * i) * 64 + lane;
-        xs4[i] = xcol[ch];
+        for (int it = 0; it < NIT; it++) {
+            const int u = sub + it * LPR;
+            const uint4 a = reinterpret_cast<const uint4 *>(p.aq_q)[u * 2], b = reinterpret_cast<const uint4 *>(p.aq_q)[u * 2 + 1];
+            ax[it][0] = a.x; ax[it][1] = a.y; ax[it][2] = a.z; ax[it][3] = a.w;
+            ax[it][4] = b.x; ax[it][5] = b.y; ax[it][6] = b.z; ax[it][7] = b.w;
+            axd[it] = p.aq_d[u];
+            axs[it] = p.aq_s[u];
+        }
+    } else {
         if (PRO == PRO_LN) {
-            lw4[i] = reinterpret_cast<const float4 *>(p.ln_w)[ch];
-            lb4[i] = reinterpret_cast<const float4 *>(p.ln_b)[ch];
+#pragma unroll
+            for (int i = 0; i < NJJ; i++) xr[i] = xcol[i * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < NSHARE; i++) {
+            const int ch = (wave + 4 * i) * 64 + lane;
+            xs4[i] = xcol[ch];
+            if (PRO == PRO_LN) {
+                lw4[i] = reinterpret_cast<const float4 *>(p.ln_w)[ch];
+                lb4[i] = reinterpret_cast<const float4 *>(p.ln_b)[ch];
+            }
         }
     }
     Unit<WT> wq[PF][NIT];
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
 
     // ---- convert the wave's share: [normalise] -> Q8_0 / Q8_1 -> LDS ----------------------------
 #pragma unroll
-    for (int i = 0; i < NSHARE; i++) {
+    for (int i = 0; i < (PRO == PRO_Q8IN ? 0 : NSHARE); i++) {
         const int ch = (wave + 4 * i) * 64 + lane;
         float4 v = xs4[i];
         if (PRO == PRO_LN) {
@@ -135,14 +151,11 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             }
         }
     }
-    __syncthreads();
+    if (PRO != PRO_Q8IN) __syncthreads();
 
-    // ---- this lane's activation blocks (constant over the row steps) ---------------------------
-    uint32_t ax[NIT][8];
-    float axd[NIT];
-    uint32_t axs[NIT];
+    // ---- this lane's activation blocks from LDS ---------------------------------------------------
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
+    for (int it = 0; it < (PRO == PRO_Q8IN ? 0 : NIT); it++) {
         const int u = sub + it * LPR;
         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + u * 8);
         const uint4 b = *reinterpret_cast<const uint4 *>(s_xq + u * 8 + 4);
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     }
 
     // ---- row steps: block terms -> the wave's LDS strip -----------------------------------------
-    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+    for (int s0 = 0; s0 < (PF == 1 ? 1 : nsteps); s0 += PF) {   // PF == 1: launched with exactly one row step per wave
 #pragma unroll
         for (int s = 0; s < PF; s++) {
             const int stp = s0 + s;
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             }
             const int nstp = stp + PF;  // refill this register slot with the row PF steps ahead
             const int nrow = row_base + nstp * RPS + rsub;
-            if (nstp < nsteps && nrow < M) {
+            if (PF > 1 && nstp < nsteps && nrow < M) {
 #pragma unroll
                 for (int it = 0; it < NIT; it++) load_unit<WT>(wq[s][it], p.W, (int64_t)nrow * BPR + sub + it * LPR);
             }
@@ -202,17 +215,44 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
                 p.q_out[rr] = __fmul_rn(v, p.q_scale);
             } else {
                 float *cache = (which == 1) ? p.kcache : p.vcache;
-                const int hh = rr / p.dk, dd = rr - hh * p.dk;  // head-major cache: [H][P][dk]
-                cache[((size_t)hh * p.P + e_npast) * p.dk + dd] = v;
+                const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);  // head-major cache: [H][P][dk], dk = 2^k
+                cache[(((size_t)hh * p.P + e_npast) << p.dk_log2) + dd] = v;
             }
         } else if (EPI == EPI_RESID) {
             p.out[r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
         } else if (EPI == EPI_GELU) {
             p.out[r] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);
+        } else if (EPI == EPI_GELU_Q8) {
+            s_tail[wave * 8 + lane] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);  // rpw == 8: 32 rows per workgroup
         } else {
             p.out[r] = v;
             best_val = v;
             best_idx = r;
+        }
+    }
+    if (EPI == EPI_GELU_Q8) {
+        // the workgroup's 32 outputs are one Q8 block of fc2's activation: quantize_row_q8_0 / q8_1 here,
+        // so the consumer starts from int8 (saves its whole quantize prologue)
+        __syncthreads();
+        if (wave == 0) {
+            const float v = s_tail[lane & 31];
+            float amax = fabsf(v);
+            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
+            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            const float d = amax / 127.0f;
+            const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+            const int q = (int)roundf(__fmul_rn(v, id));
+            int isum = q;
+            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
+            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
+            isum += __shfl_xor(isum, 16, 64);
+            const int blk = blockIdx.x;
+            if (lane < 32) p.oq_q[blk * 32 + lane] = (int8_t)q;
+            if (lane == 0) {
+                if (TI::q81) { p.oq_d[blk] = d; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
+                else { p.oq_d[blk] = h2f(f2h(d)); p.oq_s[blk] = (uint32_t)isum; }
+            }
         }
     }
     if (EPI == EPI_LOGITS && p.pmax_val != nullptr) {
@@ -382,7 +422,28 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         double t0 = 0.0, t1 = 0.0;
         for (int s2 = 0; s2 + 1 < nsl; s2 += 2) { t0 += pv[s2 * DK + tid]; t1 += pv[(s2 + 1) * DK + tid]; }
         if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
-        p.out[(size_t)i * D + (size_t)h * DK + tid] = (float)(t0 + t1);
+        const float o = (float)(t0 + t1);
+        p.out[(size_t)i * D + (size_t)h * DK + tid] = o;
+        if (p.oq_q != nullptr && i == 0) {
+            // wave 0 holds the head's 64 outputs = two Q8 blocks of out_proj's activation row
+            float amax = fabsf(o);
+            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
+            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            const float dq = amax / 127.0f;
+            const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
+            const int q = (int)roundf(__fmul_rn(o, id));
+            int isum = q;
+            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
+            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
+            isum += __shfl_xor(isum, 16, 64);
+            const int blk = h * 2 + (tid >> 5);
+            p.oq_q[blk * 32 + (tid & 31)] = (int8_t)q;
+            if ((tid & 31) == 0) {
+                if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
+                else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
+            }
+        }
     }
 #undef AT_STAMP
 }
