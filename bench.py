@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--n-predict", type=int, default=200)
     ap.add_argument("--n-layer", type=int, default=24, help="24 = BioGPT-base (anything else is NOT the headline config)")
     ap.add_argument("--workdir", default=os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"))
+    ap.add_argument("--workload", default="decode", choices=["decode", "prefill"],
+                    help="decode = headline (configs[1]); prefill = configs[2]: 512-token prompt in chunks of n_batch=8")
+    ap.add_argument("--n-prompt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded cpu_baseline sample")
     args = ap.parse_args()
@@ -142,8 +145,19 @@ def main():
     t_load = time.time() - t_load0
 
     n_predict = min(args.n_predict, hp.n_positions - 4)
+    prefill = args.workload == "prefill"
+    n_prompt = min(args.n_prompt, hp.n_positions)
 
     def run_step(unit):
+        if prefill:
+            # configs[2]: one 512-token prompt fed as consecutive evals of n_batch = 8 tokens (main.cpp:129-137),
+            # no intra-chunk mask (F1); logits stay on the device
+            rng = np.random.default_rng(7000 + unit)
+            toks = [2] + [int(v) for v in rng.integers(4, hp.n_vocab, n_prompt - 1)]
+            for n_past in range(0, n_prompt, 8):
+                model.eval_device(toks[n_past:n_past + 8], n_past)
+            model.synchronize()
+            return None, 0.0
         ids, secs = model.generate_greedy(make_prompt(hp.n_vocab, unit), n_predict, n_batch=8)
         return ids, secs
 
@@ -166,7 +180,7 @@ def main():
     if dist is not None:
         elapsed = replicas.max_over_ranks(elapsed)
 
-    total_tokens = world * args.steps * n_predict
+    total_tokens = world * args.steps * (n_prompt if prefill else n_predict)
     value = total_tokens / elapsed
 
     if rank != 0:
@@ -176,7 +190,8 @@ def main():
         return
 
     out = {
-        "metric": "decode tokens/sec BioGPT %s n_ctx=%d" % (args.ftype.upper(), hp.n_positions),
+        "metric": ("prefill tokens/sec BioGPT %s n_batch=8 prompt=%d" % (args.ftype.upper(), n_prompt)) if prefill else
+                  ("decode tokens/sec BioGPT %s n_ctx=%d" % (args.ftype.upper(), hp.n_positions)),
         "value": round(value, 2),
         "unit": "tokens/s",
         "n_gpus": world,
@@ -198,8 +213,19 @@ def main():
         "load_s": round(t_load, 2),
     }
 
+    if prefill:
+        out["config"]["workload"] = ("%d-token prompt ingested as %d evals of n_batch=8 tokens (no intra-chunk mask), BioGPT-base %s; "
+                                     "1 step = 1 prompt per rank; attention path: %s" % (
+                                         n_prompt, (n_prompt + 7) // 8, args.ftype.upper(),
+                                         "MFMA f32 16x16x4 (BIOGPT_HIP_PREFILL_MFMA=1)" if os.environ.get("BIOGPT_HIP_PREFILL_MFMA") == "1" else "VALU, double accumulation (bit-parity path)"))
+        # weights are re-streamed once per chunk: algorithmic bytes per chunk = W + KV read at that context
+        chunks = (n_prompt + 7) // 8
+        b = sum(pkg.decode_bytes_per_token(hp, min(n_prompt, 8 * (k + 1))) for k in range(chunks))
+        t_prompt = elapsed / args.steps
+        out["token_roofline"] = {"bytes_per_prompt": int(b), "GBps": round(b / t_prompt / 1e9, 1), "frac_of_peak": round(b / t_prompt / 1e9 / HBM_PEAK_GBS, 4)}
+
     # ---- roofline of the dominant kernel + whole-token figure (N = 1 only) ---------------------------
-    if world == 1:
+    if world == 1 and not prefill:
         try:
             reps = 24 * 20
             secs, nbytes = model.bench_matvec(0, layer=0, reps=reps)        # fc1: LN + Q4_0 mat-vec + GELU
@@ -243,7 +269,7 @@ def main():
             out["roofline_error"] = str(e)
 
     # ---- CPU baseline: the oracle (restatement of the reference's ggml CPU path), bounded sample -----
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not prefill:
         try:
             from oracle import oracle as O
             cores = usable_cores()

@@ -173,9 +173,10 @@ struct biogpt_hip_ctx {
 
     float *memory_k = nullptr, *memory_v = nullptr;
     float *x = nullptr, *x1 = nullptr, *q = nullptr, *att = nullptr, *h = nullptr;
-    int8_t *aq_q[2] = {nullptr, nullptr};     // producer-quantized activations: [0] attention out (d_model), [1] fc1 out (d_ff)
-    float *aq_d[2] = {nullptr, nullptr};
-    uint32_t *aq_s[2] = {nullptr, nullptr};
+    // producer-quantized activations [columns][K]: [0] attention out (d_model), [1] fc1 out (d_ff), [2] LayerNorm out (d_model)
+    int8_t *aq_q[3] = {nullptr, nullptr, nullptr};
+    float *aq_d[3] = {nullptr, nullptr, nullptr};
+    uint32_t *aq_s[3] = {nullptr, nullptr, nullptr};
     float *logits = nullptr;      // [n_vocab]
     float *logits_all = nullptr;  // lazily [n][n_vocab]
     size_t logits_all_rows = 0;
@@ -239,7 +240,7 @@ template <int WT, int PRO, int EPI, int NC>
 hipError_t launch_mv_kch(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
     // register chunks per lane the prologue needs: LN holds the whole column, plain only the wave's share
     const int njj = (p.W.K / 4 + 63) / 64;
-    const int need = (PRO == bgk::PRO_LN) ? njj : (njj + s.nwaves - 1) / s.nwaves;
+    const int need = (PRO == bgk::PRO_LN || NC > 1) ? njj : (njj + s.nwaves - 1) / s.nwaves;  // chunks a wave holds per column
     const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NC, s.upr, s.rpw, s.nwaves);
     const int gy = (p.N + NC - 1) / NC;
     const bool seq = env_int("BIOGPT_HIP_TREE_REDUCE", 0) == 0;  // default: the reference's block order (bit parity)
@@ -299,25 +300,38 @@ bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err
     return true;
 }
 
-// fast-chain launches with producer-quantized activations (attention -> out_proj, fc1 -> fc2)
-template <int WT, int PRO, int EPI, int K, int PF>
+// fast-chain launches with producer-quantized activations (attention -> out_proj, fc1 -> fc2; for
+// prefill chunks also lnq_kernel -> q/k/v and -> fc1), NC = 1 (decode) or 8 columns per workgroup
+template <int WT, int PRO, int EPI, int K, int PF, int NC>
 hipError_t launch_fast_explicit(bgk::MatvecParams p, int steps, hipStream_t st) {
     constexpr int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
     p.rpw = RPS * steps;
     const int grid = (p.W.M + 4 * p.rpw - 1) / (4 * p.rpw);
-    hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, PF>), dim3(grid), dim3(256), bgk::matvec_fast_smem_bytes(K, p.rpw), st, p);
+    const int gy = (p.N + NC - 1) / NC;
+    hipLaunchKernelGGL((bgk::matvec_fast_kernel<WT, PRO, EPI, K, PF, NC>), dim3(grid, gy), dim3(256),
+                       bgk::matvec_fast_smem_bytes(K, p.rpw, NC, EPI == bgk::EPI_GELU_Q8), st, p);
     return hipGetLastError();
 }
 
-enum ChainOp { CHAIN_OPROJ, CHAIN_FC1, CHAIN_FC2 };
+enum ChainOp { CHAIN_QKV_Q8, CHAIN_OPROJ, CHAIN_FC1, CHAIN_FC1_Q8, CHAIN_FC2 };
+template <int WT, int NC>
+hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
+    switch (op) {
+        case CHAIN_QKV_Q8: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_QKV, 1024, 1, NC>(p, 1, st);
+        case CHAIN_OPROJ: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 1024, 1, NC>(p, 1, st);
+        case CHAIN_FC1:   // decode: LayerNorm fused; 32 rows / workgroup = one Q8 block of fc2's input
+            if constexpr (NC == 1) return launch_fast_explicit<WT, bgk::PRO_LN, bgk::EPI_GELU_Q8, 1024, 4, 1>(p, 4, st);
+            else return hipErrorInvalidValue;
+        case CHAIN_FC1_Q8: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_GELU_Q8, 1024, 4, NC>(p, 4, st);
+        case CHAIN_FC2: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 4096, 1, NC>(p, 1, st);
+    }
+    return hipErrorInvalidValue;
+}
 template <int WT>
 hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
     if constexpr (bgk::TypeInfo<WT>::quant) {
-        switch (op) {
-            case CHAIN_OPROJ: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 1024, 1>(p, 1, st);
-            case CHAIN_FC1: return launch_fast_explicit<WT, bgk::PRO_LN, bgk::EPI_GELU_Q8, 1024, 4>(p, 4, st);  // 32 rows / workgroup = one Q8 block
-            case CHAIN_FC2: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 4096, 1>(p, 1, st);
-        }
+        if (p.N == 1) return launch_chain_nc<WT, 1>(op, p, st);
+        return launch_chain_nc<WT, 8>(op, p, st);
     }
     return hipErrorInvalidValue;
 }
@@ -331,6 +345,7 @@ hipError_t launch_chain(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) 
         default: return hipErrorInvalidValue;
     }
 }
+hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_w, size_t ln_b, int q81, hipStream_t st);
 
 template <int WT, int PRO, int EPI>
 hipError_t launch_mv_typed(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st, int *grid_out) {
@@ -376,6 +391,13 @@ bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvSha
 
 int target_wgs() { return env_int("BIOGPT_HIP_TARGET_WGS", 256); }
 
+hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_w, size_t ln_b, int q81, hipStream_t st) {
+    const double inv_k = 1.0 / 1024.0;
+    if (q81) hipLaunchKernelGGL((bgk::lnq_kernel<1024, true>), dim3(N), dim3(256), 0, st, x, 1024, dev_vec(c, ln_w), dev_vec(c, ln_b), 1e-5f, inv_k, c->aq_q[2], c->aq_d[2], c->aq_s[2]);
+    else hipLaunchKernelGGL((bgk::lnq_kernel<1024, false>), dim3(N), dim3(256), 0, st, x, 1024, dev_vec(c, ln_w), dev_vec(c, ln_b), 1e-5f, inv_k, c->aq_q[2], c->aq_d[2], c->aq_s[2]);
+    return hipGetLastError();
+}
+
 // The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
 // lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
 bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
@@ -392,8 +414,9 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
 
     // single-token fast chain: BioGPT-base shapes, block-quantized weights -> producer-side Q8 hand-offs
     const int32_t wt = ftype_to_type(hp.ftype);
-    const bool chain = N == 1 && is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
+    const bool chain = is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
+    const bool pchain = chain && N > 1;   // prefill chunk: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
     const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
 
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
@@ -411,7 +434,13 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.kcache = c->memory_k + (size_t)l * P * D;
             p.vcache = c->memory_v + (size_t)l * P * D;
             p.q_scale = 1.0f / sqrtf((float)dk);
-            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, st)));
+            if (pchain) {
+                HIP_TRY(false, launch_lnq(c, c->x, N, L.ln0_w, L.ln0_b, q81, st));
+                p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
+                HIP_TRY(false, launch_chain(CHAIN_QKV_Q8, p, st));
+            } else {
+                HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, st)));
+            }
         }
         {  // attention
             bgk::AttnParams a{};
@@ -422,7 +451,16 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
             a.q81 = q81;
             if (chain) { a.oq_q = c->aq_q[0]; a.oq_d = c->aq_d[0]; a.oq_s = c->aq_s[0]; }
-            if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+            if (dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && env_int("BIOGPT_HIP_PREFILL_MFMA", 0)) {
+                // opt-in: QK^T / PV of the prefill chunk on the matrix cores (f32 MFMA; tolerance parity, not bit parity)
+                const size_t smb = bgk::attn_mfma_smem_bytes(P);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIP_TRY(false, hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smb));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(256), smb, st, a);
+            } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
                 // loads are bounded by t_cap (multiple of 64); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);
                 if (a.t_cap <= 256) {
@@ -456,7 +494,12 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.ln_w = dev_vec(c, L.ln1_w); p.ln_b = dev_vec(c, L.ln1_b);
             p.bias = dev_vec(c, L.fc1_b);
             p.out = c->h; p.ldo = F;
-            if (chain) {
+            if (pchain) {
+                HIP_TRY(false, launch_lnq(c, c->x1, N, L.ln1_w, L.ln1_b, q81, st));
+                p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
+                p.oq_q = c->aq_q[1]; p.oq_d = c->aq_d[1]; p.oq_s = c->aq_s[1];
+                HIP_TRY(false, launch_chain(CHAIN_FC1_Q8, p, st));
+            } else if (chain) {
                 p.oq_q = c->aq_q[1]; p.oq_d = c->aq_d[1]; p.oq_s = c->aq_s[1];
                 HIP_TRY(false, launch_chain(CHAIN_FC1, p, st));
             } else {
@@ -549,8 +592,8 @@ bool alloc_runtime(biogpt_hip_ctx *c) {
     HIP_TRY(false, hipMalloc(&c->att, P * D * 4));
     HIP_TRY(false, hipMalloc(&c->h, P * F * 4));
     HIP_TRY(false, hipMalloc(&c->logits, V * 4));
-    for (int k = 0; k < 2; k++) {
-        const size_t n = k == 0 ? D : F;
+    for (int k = 0; k < 3; k++) {
+        const size_t n = (k == 1 ? F : D) * P;
         HIP_TRY(false, hipMalloc(&c->aq_q[k], n));
         HIP_TRY(false, hipMalloc(&c->aq_d[k], n / 32 * 4 + 16));
         HIP_TRY(false, hipMalloc(&c->aq_s[k], n / 32 * 4 + 16));
@@ -672,7 +715,7 @@ void destroy(biogpt_hip_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->owns_arena && c->arena) (void)hipFree(c->arena);
     for (void *p : {(void *)c->memory_k, (void *)c->memory_v, (void *)c->x, (void *)c->x1, (void *)c->q, (void *)c->att,
-                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
+                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     delete c;

@@ -401,13 +401,16 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
     // ---- prologue: [LayerNorm] + activation conversion into LDS -------------------------------
     const int nchunks = K >> 2;
     const int njj = (nchunks + 63) >> 6;            // chunks per lane over the whole column
-    for (int c = 0; c < ncols; c++) {
+    // N = 1: the 4 waves share the column (each converts a quarter).  N > 1: a wave owns whole columns
+    // (c = wave, wave + nwaves, ...) so the columns' load latencies and LayerNorms run side by side.
+    constexpr bool COLWISE = NC > 1;
+    for (int c = COLWISE ? wave : 0; c < ncols; c += COLWISE ? nwaves : 1) {
         const float4 *xcol = reinterpret_cast<const float4 *>(p.x + (size_t)(col0 + c) * p.ldx);
         float4 xr[KCH];
-        // register slot i holds chunk jj(i): LN -> jj = i (whole column); plain -> jj = wave + i*nwaves (own share)
+        // register slot i holds chunk jj(i): whole column (jj = i) for LN / column-wise; else the wave's share
 #pragma unroll
         for (int i = 0; i < KCH; i++) {
-            const int jj = (PRO == PRO_LN) ? i : wave + i * nwaves;
+            const int jj = (PRO == PRO_LN || COLWISE) ? i : wave + i * nwaves;
             const int ch = jj * 64 + lane;
             xr[i] = (jj < njj && ch < nchunks && !(p.dbg & 1)) ? xcol[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
 #pragma unroll
             for (int i = 0; i < KCH; i++) {
                 const int ch = i * 64 + lane;
-                if (i < njj && ch < nchunks && (i % nwaves) == wave) {  // only the share this wave converts
+                if (i < njj && ch < nchunks && (COLWISE || (i % nwaves) == wave)) {  // only what this wave converts
                     const float4 w = reinterpret_cast<const float4 *>(p.ln_w)[ch];
                     const float4 b = reinterpret_cast<const float4 *>(p.ln_b)[ch];
                     float4 v = xr[i];
@@ -452,9 +455,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
         // convert this wave's share and publish it in LDS
 #pragma unroll
         for (int i = 0; i < KCH; i++) {
-            const int jj = (PRO == PRO_LN) ? i : wave + i * nwaves;
+            const int jj = (PRO == PRO_LN || COLWISE) ? i : wave + i * nwaves;
             const int ch = jj * 64 + lane;
-            const bool mine = jj < njj && ((PRO == PRO_LN) ? (i % nwaves) == wave : true);
+            const bool mine = jj < njj && (COLWISE || PRO != PRO_LN || (i % nwaves) == wave);
             if (!mine) continue;                       // wave-uniform
             const bool live = ch < nchunks;
             const float4 v = xr[i];

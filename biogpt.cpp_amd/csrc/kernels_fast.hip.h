@@ -22,10 +22,13 @@
 
 namespace bgk {
 
-template <int WT, int PRO, int EPI, int K, int PF>
+// NC = activation columns per workgroup: 1 for decode; 8 for prefill chunks (PRO_Q8IN only: the columns
+// were quantized once by lnq_kernel / the producer's epilogue, every workgroup just fetches them).
+template <int WT, int PRO, int EPI, int K, int PF, int NC = 1>
 __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "fast path is for the block-quantized types");
+    static_assert(NC == 1 || PRO == PRO_Q8IN, "multi-column fast path takes pre-quantized activations");
     constexpr int BPR = K / QK;                      // blocks per row
     constexpr int LPR = BPR < 64 ? BPR : 64;         // lanes per row
     constexpr int NIT = BPR / LPR;                   // blocks per lane per row
@@ -34,39 +37,48 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     constexpr int NJJ = NCHUNK / 64;                 // chunks per lane over the whole column
     constexpr int NSHARE = NJJ / 4;                  // chunks per lane of one wave's share (4 waves)
     constexpr int PSTRIDE = BPR + 4;                 // floats; keeps float4 alignment, skews banks
+    constexpr int TAIL = 64 + (EPI == EPI_GELU_Q8 ? 32 * NC : 0);   // floats
     static_assert(BPR % LPR == 0 && NCHUNK % 256 == 0, "K must be a multiple of 1024");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem_raw);            // [K/4] packed int8
     float *const s_xd = reinterpret_cast<float *>(smem_raw + K);              // [BPR]
     uint32_t *const s_xs = reinterpret_cast<uint32_t *>(s_xd + BPR);          // [BPR]
-    float *const s_tail = reinterpret_cast<float *>(s_xs + BPR);              // [64]
+    float *const s_tail = reinterpret_cast<float *>(s_xs + BPR);              // [TAIL]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rpw = p.rpw;                                                    // rows per wave (multiple of RPS)
-    float *const s_part = s_tail + 64 + wave * rpw * PSTRIDE;
+    float *const s_part = s_tail + TAIL + wave * rpw * NC * PSTRIDE;
 
     const int sub = lane & (LPR - 1), rsub = lane / LPR;
     const int M = p.W.M;
     const int row_base = (blockIdx.x * 4 + wave) * rpw;
     const int nsteps = (PF == 1) ? 1 : rpw / RPS;
+    const int col0 = blockIdx.y * NC;
+    const int ncols = (NC == 1) ? 1 : min(NC, p.N - col0);
 
     // ---- t = 0: independent loads ---------------------------------------------------------------
     const float4 *xcol = reinterpret_cast<const float4 *>(p.x);
     float4 xr[PRO == PRO_LN ? NJJ : 1];
     float4 xs4[NSHARE], lw4[NSHARE], lb4[NSHARE];
-    uint32_t ax[NIT][8];   // this lane's activation blocks (constant over the row steps)
-    float axd[NIT];
-    uint32_t axs[NIT];
+    uint32_t ax[NC][NIT][8];   // this lane's activation blocks (constant over the row steps)
+    float axd[NC][NIT];
+    uint32_t axs[NC][NIT];
     if (PRO == PRO_Q8IN) {
-        // the producer kernel (attention / fc1) already quantized the activation: fetch this lane's blocks
+        // the producer (lnq_kernel / attention / fc1) already quantized the activations: fetch this lane's blocks
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int u = sub + it * LPR;
-            const uint4 a = reinterpret_cast<const uint4 *>(p.aq_q)[u * 2], b = reinterpret_cast<const uint4 *>(p.aq_q)[u * 2 + 1];
-            ax[it][0] = a.x; ax[it][1] = a.y; ax[it][2] = a.z; ax[it][3] = a.w;
-            ax[it][4] = b.x; ax[it][5] = b.y; ax[it][6] = b.z; ax[it][7] = b.w;
-            axd[it] = p.aq_d[u];
-            axs[it] = p.aq_s[u];
+        for (int c = 0; c < NC; c++) {
+            if (c < ncols) {
+                const uint4 *aq = reinterpret_cast<const uint4 *>(p.aq_q + (size_t)(col0 + c) * K);
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int u = sub + it * LPR;
+                    const uint4 a = aq[u * 2], b = aq[u * 2 + 1];
+                    ax[c][it][0] = a.x; ax[c][it][1] = a.y; ax[c][it][2] = a.z; ax[c][it][3] = a.w;
+                    ax[c][it][4] = b.x; ax[c][it][5] = b.y; ax[c][it][6] = b.z; ax[c][it][7] = b.w;
+                    axd[c][it] = p.aq_d[(size_t)(col0 + c) * BPR + u];
+                    axs[c][it] = p.aq_s[(size_t)(col0 + c) * BPR + u];
+                }
+            }
         }
     } else {
         if (PRO == PRO_LN) {
@@ -92,13 +104,15 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             for (int it = 0; it < NIT; it++) load_unit<WT>(wq[s][it], p.W, (int64_t)row * BPR + sub + it * LPR);
         }
     }
-    const int f_row = row_base + lane;
-    const bool finisher = lane < rpw && f_row < M;
+    // finisher slot of this lane: output (row row_base + f % rpw, column col0 + f / rpw), f = lane
+    const int f_r = (NC == 1) ? lane : lane % rpw, f_c = (NC == 1) ? 0 : lane / rpw;
+    const int f_row = row_base + f_r;
+    const bool finisher = lane < rpw * ncols && f_row < M;
     float e_bias = 0.0f, e_res = 0.0f;
     int e_npast = 0;
     if (finisher) {
         if (EPI != EPI_LOGITS) e_bias = p.bias[f_row];
-        if (EPI == EPI_RESID) e_res = p.resid[f_row];
+        if (EPI == EPI_RESID) e_res = p.resid[(size_t)(col0 + f_c) * p.ldr + f_row];
         if (EPI == EPI_QKV) e_npast = p.st->n_past;
     }
 
@@ -159,10 +173,10 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
         const int u = sub + it * LPR;
         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + u * 8);
         const uint4 b = *reinterpret_cast<const uint4 *>(s_xq + u * 8 + 4);
-        ax[it][0] = a.x; ax[it][1] = a.y; ax[it][2] = a.z; ax[it][3] = a.w;
-        ax[it][4] = b.x; ax[it][5] = b.y; ax[it][6] = b.z; ax[it][7] = b.w;
-        axd[it] = s_xd[u];
-        axs[it] = s_xs[u];
+        ax[0][it][0] = a.x; ax[0][it][1] = a.y; ax[0][it][2] = a.z; ax[0][it][3] = a.w;
+        ax[0][it][4] = b.x; ax[0][it][5] = b.y; ax[0][it][6] = b.z; ax[0][it][7] = b.w;
+        axd[0][it] = s_xd[u];
+        axs[0][it] = s_xs[u];
     }
 
     // ---- row steps: block terms -> the wave's LDS strip -----------------------------------------
@@ -173,9 +187,14 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             const int row = row_base + stp * RPS + rsub;
             if (stp < nsteps && row < M) {
 #pragma unroll
-                for (int it = 0; it < NIT; it++)
-                    s_part[(stp * RPS + rsub) * PSTRIDE + sub + it * LPR] =
-                        unit_dot_quant<WT>(wq[s][it], ax[it], axd[it], __uint_as_float(axs[it]), (int)axs[it]);
+                for (int c = 0; c < NC; c++) {
+                    if (c < ncols) {
+#pragma unroll
+                        for (int it = 0; it < NIT; it++)
+                            s_part[((stp * RPS + rsub) * NC + c) * PSTRIDE + sub + it * LPR] =
+                                unit_dot_quant<WT>(wq[s][it], ax[c][it], axd[c][it], __uint_as_float(axs[c][it]), (int)axs[c][it]);
+                    }
+                }
             }
             const int nstp = stp + PF;  // refill this register slot with the row PF steps ahead
             const int nrow = row_base + nstp * RPS + rsub;
@@ -189,11 +208,11 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- finish: lane f adds row f's block terms in block order, then the epilogue --------------
+    // ---- finish: lane f adds its (row, column)'s block terms in block order, then the epilogue ----
     float best_val = -INFINITY;
     int best_idx = 0x7fffffff;
     if (finisher) {
-        const float4 *part = reinterpret_cast<const float4 *>(s_part + lane * PSTRIDE);
+        const float4 *part = reinterpret_cast<const float4 *>(s_part + (f_r * NC + f_c) * PSTRIDE);
         float sumf = 0.0f;
 #pragma unroll
         for (int b0 = 0; b0 < BPR / 4; b0 += 8) {  // 32 terms per batch: 8 LDS reads in flight
@@ -207,35 +226,35 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             }
         }
         float v = sumf;
-        const int r = f_row;
+        const int r = f_row, col = col0 + f_c;
         if (EPI == EPI_QKV) {
             v = __fadd_rn(e_bias, v);
             const int which = r / K, rr = r - which * K;  // d_model == K for the q/k/v projection
             if (which == 0) {
-                p.q_out[rr] = __fmul_rn(v, p.q_scale);
+                p.q_out[(size_t)col * K + rr] = __fmul_rn(v, p.q_scale);
             } else {
                 float *cache = (which == 1) ? p.kcache : p.vcache;
                 const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);  // head-major cache: [H][P][dk], dk = 2^k
-                cache[(((size_t)hh * p.P + e_npast) << p.dk_log2) + dd] = v;
+                cache[(((size_t)hh * p.P + e_npast + col) << p.dk_log2) + dd] = v;
             }
         } else if (EPI == EPI_RESID) {
-            p.out[r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
+            p.out[(size_t)col * p.ldo + r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
         } else if (EPI == EPI_GELU) {
-            p.out[r] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);
+            p.out[(size_t)col * p.ldo + r] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);
         } else if (EPI == EPI_GELU_Q8) {
-            s_tail[wave * 8 + lane] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);  // rpw == 8: 32 rows per workgroup
+            s_tail[64 + f_c * 32 + wave * 8 + f_r] = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias, v))]);  // rpw == 8: 32 rows / workgroup
         } else {
-            p.out[r] = v;
+            p.out[(size_t)col * p.ldo + r] = v;
             best_val = v;
             best_idx = r;
         }
     }
     if (EPI == EPI_GELU_Q8) {
-        // the workgroup's 32 outputs are one Q8 block of fc2's activation: quantize_row_q8_0 / q8_1 here,
-        // so the consumer starts from int8 (saves its whole quantize prologue)
+        // the workgroup's 32 outputs per column are one Q8 block of fc2's activation: quantize_row_q8_0 / q8_1
+        // here, so the consumer starts from int8 (saves its whole quantize prologue)
         __syncthreads();
-        if (wave == 0) {
-            const float v = s_tail[lane & 31];
+        for (int c = wave * 2 + (lane >> 5); c < ncols; c += 8) {   // a half-wave per column (NC == 1: wave 0, lanes 0-31)
+            const float v = s_tail[64 + c * 32 + (lane & 31)];
             float amax = fabsf(v);
             amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
             amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
@@ -247,9 +266,9 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
             isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
             isum += __shfl_xor(isum, 16, 64);
-            const int blk = blockIdx.x;
-            if (lane < 32) p.oq_q[blk * 32 + lane] = (int8_t)q;
-            if (lane == 0) {
+            const size_t blk = (size_t)(col0 + c) * (M / 32) + blockIdx.x;   // column-major [N][d_ff/32]
+            p.oq_q[blk * 32 + (lane & 31)] = (int8_t)q;
+            if ((lane & 31) == 0) {
                 if (TI::q81) { p.oq_d[blk] = d; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
                 else { p.oq_d[blk] = h2f(f2h(d)); p.oq_s[blk] = (uint32_t)isum; }
             }
@@ -277,8 +296,66 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     }
 }
 
-__host__ __device__ inline size_t matvec_fast_smem_bytes(int K, int rpw) {
-    return (size_t)K + 2 * (size_t)(K / QK) * 4 + 256 + 4 * (size_t)rpw * (K / QK + 4) * 4 + 64;
+// LayerNorm + Q8 quantization of N activation columns, once per LN site of a prefill chunk (the decode
+// path keeps this fused in the mat-vec prologue; with 8 columns it would be replicated in every workgroup).
+// One workgroup per column; same arithmetic as the prologue of matvec_fast_kernel<PRO_LN>.
+template <int K, bool Q81>
+__global__ __launch_bounds__(256) void lnq_kernel(const float *x, int ldx, const float *ln_w, const float *ln_b, float eps, double inv_k,
+                                                  int8_t *oq_q, float *oq_d, uint32_t *oq_s) {
+    constexpr int NJJ = K / 4 / 64, NSHARE = NJJ / 4, BPR = K / QK;
+    const int col = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 *xcol = reinterpret_cast<const float4 *>(x + (size_t)col * ldx);
+    float4 xr[NJJ], xs4[NSHARE], lw4[NSHARE], lb4[NSHARE];
+#pragma unroll
+    for (int i = 0; i < NJJ; i++) xr[i] = xcol[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < NSHARE; i++) {
+        const int ch = (wave + 4 * i) * 64 + lane;
+        xs4[i] = xcol[ch];
+        lw4[i] = reinterpret_cast<const float4 *>(ln_w)[ch];
+        lb4[i] = reinterpret_cast<const float4 *>(ln_b)[ch];
+    }
+    double s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NJJ; i++) s1 += ((double)xr[i].x + (double)xr[i].y) + ((double)xr[i].z + (double)xr[i].w);
+    s1 = wave_sum_f64(s1);
+    const float mean = (float)(s1 * inv_k);
+    double s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NJJ; i++) {
+        const float a = __fsub_rn(xr[i].x, mean), b = __fsub_rn(xr[i].y, mean);
+        const float c = __fsub_rn(xr[i].z, mean), d = __fsub_rn(xr[i].w, mean);
+        s2 += ((double)__fmul_rn(a, a) + (double)__fmul_rn(b, b)) + ((double)__fmul_rn(c, c) + (double)__fmul_rn(d, d));
+    }
+    s2 = wave_sum_f64(s2);
+    const float var = (float)(s2 * inv_k);
+    const float scale = 1.0f / sqrtf(__fadd_rn(var, eps));
+#pragma unroll
+    for (int i = 0; i < NSHARE; i++) {
+        const int ch = (wave + 4 * i) * 64 + lane;
+        float4 v = xs4[i];
+        v.x = __fadd_rn(__fmul_rn(lw4[i].x, __fmul_rn(__fsub_rn(v.x, mean), scale)), lb4[i].x);
+        v.y = __fadd_rn(__fmul_rn(lw4[i].y, __fmul_rn(__fsub_rn(v.y, mean), scale)), lb4[i].y);
+        v.z = __fadd_rn(__fmul_rn(lw4[i].z, __fmul_rn(__fsub_rn(v.z, mean), scale)), lb4[i].z);
+        v.w = __fadd_rn(__fmul_rn(lw4[i].w, __fmul_rn(__fsub_rn(v.w, mean), scale)), lb4[i].w);
+        const float amax = group8_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        const float d = amax / 127.0f;
+        const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+        const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
+        const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
+        const int isum = group8_sum(q0 + q1 + q2 + q3);
+        reinterpret_cast<uint32_t *>(oq_q + (size_t)col * K)[ch] =
+            (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        if ((lane & 7) == 0) {
+            const size_t b = (size_t)col * BPR + (ch >> 3);
+            if (Q81) { oq_d[b] = d; oq_s[b] = __float_as_uint(__fmul_rn((float)isum, d)); }
+            else { oq_d[b] = h2f(f2h(d)); oq_s[b] = (uint32_t)isum; }
+        }
+    }
+}
+
+__host__ __device__ inline size_t matvec_fast_smem_bytes(int K, int rpw, int nc = 1, bool gelu_q8 = false) {
+    return (size_t)K + 2 * (size_t)(K / QK) * 4 + (64 + (gelu_q8 ? 32 * nc : 0)) * 4 + 4 * (size_t)rpw * nc * (K / QK + 4) * 4 + 64;
 }
 
 }  // namespace bgk
@@ -424,7 +501,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
         const float o = (float)(t0 + t1);
         p.out[(size_t)i * D + (size_t)h * DK + tid] = o;
-        if (p.oq_q != nullptr && i == 0) {
+        if (p.oq_q != nullptr) {
             // wave 0 holds the head's 64 outputs = two Q8 blocks of out_proj's activation row
             float amax = fabsf(o);
             amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
@@ -437,7 +514,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
             isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
             isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
             isum += __shfl_xor(isum, 16, 64);
-            const int blk = h * 2 + (tid >> 5);
+            const size_t blk = (size_t)i * (D / 32) + h * 2 + (tid >> 5);   // [N][d_model/32]
             p.oq_q[blk * 32 + (tid & 31)] = (int8_t)q;
             if ((tid & 31) == 0) {
                 if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
@@ -447,5 +524,161 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
     }
 #undef AT_STAMP
 }
+
+// ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
+// QK^T/PV contraction") ---------------------------------------------------------------------------------
+// One 256-thread workgroup per head, up to 16 query tokens of one chunk (n_batch = 8 pads the 16-wide tile),
+// head size 64, no intra-chunk mask (F1) unless the opt-in causal flag is set.
+//   QK^T : per 16-key tile  C[key][query] += A[key][d] * B[d][query]  with v_mfma_f32_16x16x4_f32, 16 steps
+//          over the 64 dims (the dims are visited in the order 16m + 4k + c so that every lane's operands are
+//          four consecutive floats = one 16-byte load); tiles round-robin over the 4 waves
+//   soft : 16 lanes per query row (one DPP row), fp16-table exp and double row sums as ggml_soft_max
+//   PV   : C[query][d] += A[query][key] * B[key][d], 4 keys per step, 4 MFMAs (d = 4n + c) per step;
+//          key steps round-robin over the waves, partial tiles summed through LDS
+// f32 MFMA is a k-ordered f32 fmaf chain (MI355X guide): results agree with the reference's double-sum dots
+// to f32 round-off (~1e-6 relative), i.e. inside the 1e-3 logit contract but NOT bit-identical -- this path
+// is opt-in (BIOGPT_HIP_PREFILL_MFMA=1), the default prefill attention stays the bit-parity VALU kernel.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, N = p.N;
+    const int n_past = p.st->n_past;
+    const int causal = p.st->causal;
+    const int T = n_past + N;
+    const int T16 = (T + 15) & ~15;
+    const int TP = p.P + 2;                       // LDS row pitch (floats): pitch % 32 == 2 -> conflict-free A reads in PV
+    float *S = reinterpret_cast<float *>(smem_raw);                       // [16][TP] scores, then probabilities
+    float *R = S + 16 * TP;                                               // [4 waves][16][64] partial outputs
+
+    const float *kbase = p.kcache + (size_t)h * p.P * DK;                 // head-major cache [H][P][dk]
+    const float *vbase = p.vcache + (size_t)h * p.P * DK;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // B operand of QK^T: this lane's query row (li), dims 16m + 4lk + c
+    float4 qv[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        qv[m] = (li < N) ? *reinterpret_cast<const float4 *>(p.q + (size_t)li * D + (size_t)h * DK + 16 * m + 4 * lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- QK^T ----
+    for (int j0 = wave * 16; j0 < T16; j0 += 128) {      // 2 key tiles per trip: all loads first
+        float4 kv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int jt = j0 + 64 * u;
+            const float *krow = kbase + (size_t)min(jt + li, p.P - 1) * DK + 4 * lk;
+#pragma unroll
+            for (int m = 0; m < 4; m++) kv[u][m] = *reinterpret_cast<const float4 *>(krow + 16 * m);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int jt = j0 + 64 * u;
+            if (jt >= T16) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].x, qv[m].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].y, qv[m].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].z, qv[m].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].w, qv[m].w, acc, 0, 0, 0);
+            }
+            // C layout: column (query) = lane & 15, rows (keys) = 4*(lane >> 4) + r
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = jt + 4 * lk + r;
+                const int tlim = causal ? n_past + li + 1 : T;
+                S[li * TP + j] = (j < tlim) ? acc[r] : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax: 16 lanes per query row ----
+    {
+        const int row = tid >> 4, c16 = tid & 15;
+        float *Sr = S + row * TP;
+        float mx = -INFINITY;
+        for (int j = c16; j < T16; j += 16) mx = fmaxf(mx, Sr[j]);
+        mx = fmaxf(mx, dpp_f<DPP_QUAD_XOR1>(mx)); mx = fmaxf(mx, dpp_f<DPP_QUAD_XOR2>(mx));
+        mx = fmaxf(mx, dpp_f<DPP_ROW_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_f<DPP_ROW_MIRROR>(mx));
+        double sum = 0.0;
+        for (int j = c16; j < T16; j += 16) {
+            const float val = h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]);   // exp(-inf) = 0 for masked / padded keys
+            Sr[j] = val;
+            sum += (double)val;
+        }
+        sum += dpp_d<DPP_QUAD_XOR1>(sum); sum += dpp_d<DPP_QUAD_XOR2>(sum);
+        sum += dpp_d<DPP_ROW_HALF_MIRROR>(sum); sum += dpp_d<DPP_ROW_MIRROR>(sum);
+        const float inv = inv_sum_f32(sum);
+        for (int j = c16; j < T16; j += 16) Sr[j] = __fmul_rn(Sr[j], inv);
+    }
+    __syncthreads();
+
+    // ---- PV ----
+    f32x4 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j0 = wave * 4; j0 < T16; j0 += 64) {        // 4 key steps per trip: all loads first
+        float a[4];
+        float4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 16 * u;
+            const bool ok = j < T16;
+            a[u] = ok ? S[li * TP + j + lk] : 0.0f;                                                    // A[query li][key j + lk]
+            b[u] = ok ? *reinterpret_cast<const float4 *>(vbase + (size_t)(j + lk) * DK + 4 * li)      // B[key][d = 4*li + c]
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, o[1], 0, 0, 0);
+            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, o[2], 0, 0, 0);
+            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, o[3], 0, 0, 0);
+        }
+    }
+    // C layout: column n = lane & 15 -> d = 4n + c ; rows (queries) = 4*(lane >> 4) + r
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) R[(wave * 16 + 4 * lk + r) * DK + 4 * li + c] = o[c][r];
+    __syncthreads();
+
+    // ---- combine the 4 waves, write f32 + (optionally) the Q8 copy for the fast out_proj ----
+    {
+        const int qi = tid >> 4, d0 = (tid & 15) * 4;     // thread -> (query, 4 consecutive dims)
+        float4 v;
+        float *vv = reinterpret_cast<float *>(&v);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            vv[c] = (R[(0 * 16 + qi) * DK + d0 + c] + R[(1 * 16 + qi) * DK + d0 + c]) + (R[(2 * 16 + qi) * DK + d0 + c] + R[(3 * 16 + qi) * DK + d0 + c]);
+        const bool live = qi < N;
+        if (live) *reinterpret_cast<float4 *>(p.out + (size_t)qi * D + (size_t)h * DK + d0) = v;
+        if (p.oq_q != nullptr) {
+            // a Q8 block = 32 dims = 8 consecutive threads (quantize_row_q8_0 / q8_1)
+            const float amax = group8_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            const float dq = amax / 127.0f;
+            const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
+            const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
+            const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
+            const int isum = group8_sum(q0 + q1 + q2 + q3);
+            if (live) {
+                const size_t blk = (size_t)qi * (D / 32) + h * 2 + (d0 >> 5);
+                reinterpret_cast<uint32_t *>(p.oq_q)[((size_t)qi * D + (size_t)h * DK + d0) >> 2] =
+                    (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+                if ((tid & 7) == 0) {
+                    if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
+                    else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
+                }
+            }
+        }
+    }
+}
+
+__host__ __device__ inline size_t attn_mfma_smem_bytes(int P) { return ((size_t)16 * (P + 2) + 4 * 16 * 64) * 4 + 64; }
 
 }  // namespace bgk
