@@ -780,7 +780,7 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
 
 // The single-token decode step is captured once per context bucket (the attention workgroup size is a
 // launch parameter, everything else reads n_past / the token from HBM) and replayed per token.
-constexpr int N_BUCKETS = 6;
+constexpr int N_BUCKETS = 6;   // 64 / 128 / 192 / 256 / 512 / n_positions keys
 int graph_bucket(int T) { return T <= 256 ? (T - 1) / 64 : (T <= 512 ? 4 : 5); }
 int bucket_tmax(const biogpt_hip_ctx *c, int b) {
     const int t = b < 4 ? 64 * (b + 1) : (b == 4 ? 512 : c->hp.n_positions);
@@ -971,7 +971,7 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || (which != 4 && (layer < 0 || layer >= ctx->hp.n_layer))) BG_FAIL(-1, "bad argument");
+    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer))) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     const auto &hp = ctx->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, P = hp.n_positions;
@@ -983,6 +983,22 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
     auto launch = [&](int l) -> bool {
         g_launch_parity ^= 1;
+        if (which == 5) {  // attention of layer (l mod L) with `layer` keys in the cache
+            bgk::AttnParams a{};
+            const int ll = l % hp.n_layer, dk = D / hp.n_head;
+            a.q = ctx->q; a.kcache = ctx->memory_k + (size_t)ll * P * D; a.vcache = ctx->memory_v + (size_t)ll * P * D;
+            a.out = ctx->att; a.st = ctx->state;
+            a.exp_tab = reinterpret_cast<const uint16_t *>(ctx->arena + ctx->plan.exp_tab);
+            a.N = 1; a.D = D; a.dk = dk; a.P = P;
+            a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
+            a.oq_q = ctx->aq_q[0]; a.oq_d = ctx->aq_d[0]; a.oq_s = ctx->aq_s[0];
+            a.t_cap = std::min(P, (layer + 1 + 63) & ~63);
+            if (a.t_cap <= 256) hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(hp.n_head, 1), dim3(4 * a.t_cap), 0, ctx->stream, a);
+            else if (a.t_cap <= 512) hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((bgk::attn_fast_kernel<4, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
+            HIP_TRY(false, hipGetLastError());
+            return true;
+        }
         const LayerSlots &L = ctx->plan.layers[(size_t)(hp.n_layer ? l % hp.n_layer : 0)];
         if (which == 0) {
             const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
@@ -1024,8 +1040,8 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
         return true;
     };
     const int32_t tok0 = 0;
-    if (!upload_state(ctx, &tok0, 1, 0)) return -2;
-    const bool stamps = (env_int("BIOGPT_HIP_DBG", 0) & 32) != 0;
+    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : 0)) return -2;
+    const bool stamps = (env_int("BIOGPT_HIP_DBG", 0) & 32) != 0 && which < 5;
     if (stamps) {
         if (!g_tstamp) HIP_TRY(-2, hipMalloc(&g_tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
         HIP_TRY(-2, hipMemset(g_tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
@@ -1062,6 +1078,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
         }
     }
     if (bytes_out) {
+        if (which == 5) { *bytes_out = 2.0 * (layer + 1) * D * 4; return 0; }  // K and V rows of one layer
         const MatSlot *m = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
                          : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
         // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)

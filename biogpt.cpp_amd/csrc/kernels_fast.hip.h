@@ -369,6 +369,11 @@ namespace bgk {
 // of the context (the captured decode graphs are bucketed by it), NOT by the device-side position:
 // rows in [T, t_cap) are allocated cache whose values are loaded and ignored (masked by T).
 //   KP   = key passes of NT/4 keys;  VPRE = V values prefetched at entry (16 per lane; t_cap <= NT/4)
+// Layouts that were measured and rejected (tools/sweep_attn.py): 256 threads with several key passes per
+// lane (one wave per SIMD) and a thread-per-key layout (t_cap threads) are both 15-40 % SLOWER -- with every
+// load and all arithmetic ablated this kernel still takes 4.4 us, i.e. its cost is the serial chain of
+// dependent steps (entry, position load, two block reductions, table lookup, PV, final reduce), and more
+// lanes shorten each step.
 // exact (float)(1.0/sum): v_rcp_f64 + two Newton steps is within 1 ulp(double) of the quotient, which
 // rounds to the same float as the IEEE double division except on ~1e-9 of inputs
 __device__ __forceinline__ float inv_sum_f32(double s) {
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
     constexpr int DK = 64;
     __shared__ float S[KP * 256];
     __shared__ double red[16];
+    __shared__ float redf[16];
     __shared__ double pv[1024];
     const int h = blockIdx.x, i = blockIdx.y;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < KP; ps++) {
         const int j = ps * kpp + kidx;
-        if (j < t_cap) {
+        if (j < t_cap && !(p.dbg & 1)) {
 #pragma unroll
             for (int m = 0; m < 4; m++) kr[ps][m] = kbase[(size_t)j * (DK / 4) + 4 * m];
         }
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = sl + nsl * k;
-            if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
+            if (j < t_cap && !(p.dbg & 2)) vr[k] = vbase[(size_t)j * DK];
         }
     }
     AT_STAMP(1);
@@ -447,32 +453,40 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         sc[ps] = (ps * kpp + kidx < T) ? (float)acc : -INFINITY;
     }
     AT_STAMP(2);
-
     // ---- softmax (ggml_soft_max: fp16-table exp, double sum, scale by (float)(1/sum)) ----
+    // one barrier for the max, one for the sum (which also publishes S): separate exchange arrays
+    const int nw = nt >> 6, lane = tid & 63, wv = tid >> 6;
     float mx = sc[0];
 #pragma unroll
     for (int ps = 1; ps < KP; ps++) mx = fmaxf(mx, sc[ps]);
-    mx = block_max_f32(mx, reinterpret_cast<float *>(red));
+    mx = wave_max_f32(mx);
+    if (lane == 0) redf[wv] = mx;
+    __syncthreads();
+    mx = redf[0];
+    for (int w = 1; w < nw; w++) mx = fmaxf(mx, redf[w]);
     AT_STAMP(3);
     double sum = 0.0;
 #pragma unroll
     for (int ps = 0; ps < KP; ps++) {
         const int j = ps * kpp + kidx;
         if (j < T && ksub == 0) {
-            const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc[ps], mx))]);
+            const float val = (p.dbg & 4) ? __fsub_rn(sc[ps], mx) : h2f(p.exp_tab[f2h(__fsub_rn(sc[ps], mx))]);
             S[j] = val;
             sum += (double)val;
         }
     }
     AT_STAMP(4);
-    sum = block_sum_f64(sum, red);
-    const float inv = inv_sum_f32(sum);
+    sum = wave_sum_f64(sum);
+    if (lane == 0) red[wv] = sum;
     __syncthreads();
+    sum = 0.0;
+    for (int w = 0; w < nw; w++) sum += red[w];
+    const float inv = inv_sum_f32(sum);
     AT_STAMP(5);
 
     // ---- PV: nsl slices x 64 dims, double accumulation ----
     double a0 = 0.0, a1 = 0.0;
-    if (VPRE) {
+    if (VPRE && !(p.dbg & 8)) {
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
             const int j0 = sl + nsl * k, j1 = j0 + nsl;
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
         const float o = (float)(t0 + t1);
         p.out[(size_t)i * D + (size_t)h * DK + tid] = o;
-        if (p.oq_q != nullptr) {
+        if (p.oq_q != nullptr && !(p.dbg & 16)) {
             // wave 0 holds the head's 64 outputs = two Q8 blocks of out_proj's activation row
             float amax = fabsf(o);
             amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
