@@ -237,7 +237,7 @@ def main():
                 traffic = json.load(open(tpath)).get("fc1_matvec_hbm_bytes_per_launch")
             ach = nbytes / secs / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "matvec_kernel<%s,LN,GELU> (fc1 %dx%d, 24 launches/token)" % (args.ftype.upper(), hp.d_ff, hp.d_model),
+                "bound": "hbm", "kernel": "matvec_fast_kernel<%s,LN,GELU_Q8,%d> (fc1 %dx%d: LayerNorm + W*A8 mat-vec + GELU + Q8 output, 24 launches/token)" % (args.ftype.upper(), hp.d_model, hp.d_ff, hp.d_model),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
                 "method": "HIP events around %d back-to-back launches on the engine stream, cycling the 24 layers' weights" % reps,

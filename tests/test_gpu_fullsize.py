@@ -93,3 +93,18 @@ def test_prefill_mfma_attention_opt_in(pkg, oracle, files, name, monkeypatch):
     print("%s MFMA prefill: worst |diff| %.2e" % (name, worst))
     assert worst <= 5e-2
     g.close()
+
+
+def test_full_context_generation_all_graph_buckets(pkg, oracle, files):
+    """Greedy generation up to the last position (main.cpp:82 clamp): walks every captured decode graph
+    (context buckets 64 ... n_positions) and the long-context attention path; ids must equal the oracle's."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    o = oracle.OracleModel(files["q4_0"], n_threads=8)
+    prompt = [2, 901, 17000, 33, 4100]
+    ids, secs = g.generate_greedy(prompt, 5000, n_batch=8)           # clamped to 1024 - 5 = 1019
+    assert len(ids) == KW["n_positions"] - len(prompt)
+    ref, _ = o.generate_greedy(prompt, 5000, n_batch=8)
+    same = int((np.asarray(ids) == np.asarray(ref)).sum())
+    print("full-context generation: %d/%d ids identical, %.0f tok/s" % (same, len(ids), len(ids) / secs))
+    assert same == len(ids)
+    g.close()
