@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 
 namespace {
@@ -103,4 +104,75 @@ biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const floa
     }
     std::discrete_distribution<> pick(prob.begin(), prob.end());
     return cand[(size_t)pick(rng)].second;
+}
+
+// ---- CLI flags of the reference's `biogpt` tool (biogpt.cpp:982-1040), table-driven -------------------
+namespace {
+enum FlagKind { F_I32, F_F32, F_U8, F_STR };
+struct Flag {
+    const char *short_name, *long_name, *meta, *help;
+    FlagKind kind;
+    size_t offset;
+};
+#define FLAG(sn, ln, meta, help, kind, member) {sn, ln, meta, help, kind, offsetof(biogpt_params, member)}
+const Flag kFlags[] = {
+    FLAG("-s", "--seed", "SEED", "RNG seed", F_I32, seed),
+    FLAG("-t", "--threads", "N", "number of threads (ignored by the MI355X engine)", F_I32, n_threads),
+    FLAG("-p", "--prompt", "PROMPT", "prompt to start generation with", F_STR, prompt),
+    FLAG("-l", "--lang", "LANG", "language of the prompt; like the reference this overwrites the PROMPT (F9)", F_STR, prompt),
+    FLAG("-n", "--n_predict", "N", "number of tokens to predict", F_I32, n_predict),
+    FLAG("-v", "--verbosity", "V", "verbosity level", F_U8, verbosity),
+    FLAG(nullptr, "--top_k", "N", "top-k sampling", F_I32, top_k),
+    FLAG(nullptr, "--top_p", "N", "top-p sampling", F_F32, top_p),
+    FLAG(nullptr, "--temp", "N", "temperature", F_F32, temp),
+    FLAG("-b", "--batch_size", "N", "batch size for prompt processing", F_I32, n_batch),
+    FLAG("-m", "--model", "FNAME", "model path", F_STR, model),
+};
+#undef FLAG
+}  // namespace
+
+bool biogpt_params_parse(int argc, char **argv, biogpt_params &params) {
+    for (int i = 1; i < argc; i++) {
+        const std::string arg = argv[i];
+        if (arg == "-h" || arg == "--help") { biogpt_print_usage(argv, params); exit(0); }
+        const Flag *hit = nullptr;
+        for (const Flag &f : kFlags)
+            if ((f.short_name && arg == f.short_name) || arg == f.long_name) { hit = &f; break; }
+        if (!hit) {  // biogpt.cpp:1011-1015
+            fprintf(stderr, "error: unknown argument: %s\n", arg.c_str());
+            biogpt_print_usage(argv, params);
+            exit(0);
+        }
+        if (i + 1 >= argc) {  // the reference reads argv[++i] unchecked; fail cleanly instead
+            fprintf(stderr, "error: missing value for %s\n", arg.c_str());
+            return false;
+        }
+        char *base = reinterpret_cast<char *>(&params) + hit->offset;
+        const char *val = argv[++i];
+        switch (hit->kind) {
+            case F_I32: *reinterpret_cast<int32_t *>(base) = std::stoi(val); break;
+            case F_F32: *reinterpret_cast<float *>(base) = std::stof(val); break;
+            case F_U8: *reinterpret_cast<uint8_t *>(base) = (uint8_t)std::stoi(val); break;
+            case F_STR: *reinterpret_cast<std::string *>(base) = val; break;
+        }
+    }
+    return true;
+}
+
+void biogpt_print_usage(char **argv, const biogpt_params &params) {
+    fprintf(stderr, "usage: %s [options]\n\noptions:\n  -h, --help            show this help message and exit\n", argv[0]);
+    for (const Flag &f : kFlags) {
+        std::string names = f.short_name ? std::string(f.short_name) + " " + f.meta + ", " : std::string();
+        names += std::string(f.long_name) + " " + f.meta;
+        const char *base = reinterpret_cast<const char *>(&params) + f.offset;
+        std::string dflt;
+        switch (f.kind) {
+            case F_I32: dflt = std::to_string(*reinterpret_cast<const int32_t *>(base)); break;
+            case F_F32: { char b[32]; snprintf(b, sizeof b, "%.1f", *reinterpret_cast<const float *>(base)); dflt = b; } break;
+            case F_U8: dflt = std::to_string((int)*reinterpret_cast<const uint8_t *>(base)); break;
+            case F_STR: dflt = *reinterpret_cast<const std::string *>(base); break;
+        }
+        fprintf(stderr, "  %-28s %s (default: %s)\n", names.c_str(), f.help, dflt.c_str());
+    }
+    fprintf(stderr, "\n");
 }

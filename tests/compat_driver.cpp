@@ -10,14 +10,26 @@
 #include "ggml-alloc.h"
 
 int main(int argc, char **argv) {
-    if (argc < 5) return 2;
     ggml_time_init();
     biogpt_params params;
-    params.model = argv[1];
-    params.n_predict = std::atoi(argv[2]);
-    params.top_k = std::atoi(argv[3]);
     token_sequence embed_inp;
-    for (int i = 4; i < argc; i++) embed_inp.push_back(std::atoi(argv[i]));
+    if (argc >= 2 && std::string(argv[1]) == "--flags") {
+        // reference-style flags (biogpt_params_parse); the prompt is a list of ids "2 17 45"
+        if (!biogpt_params_parse(argc - 1, argv + 1, params)) return 2;
+        size_t pos = 0;
+        while (pos < params.prompt.size()) {
+            size_t used = 0;
+            embed_inp.push_back(std::stoi(params.prompt.substr(pos), &used));
+            pos += used;
+            while (pos < params.prompt.size() && params.prompt[pos] == ' ') pos++;
+        }
+    } else {
+        if (argc < 5) return 2;
+        params.model = argv[1];
+        params.n_predict = std::atoi(argv[2]);
+        params.top_k = std::atoi(argv[3]);
+        for (int i = 4; i < argc; i++) embed_inp.push_back(std::atoi(argv[i]));
+    }
     std::mt19937 rng(7);
 
     biogpt_vocab vocab;

@@ -45,6 +45,26 @@ def test_driver_greedy_ids_match_oracle(pkg, oracle, tiny_models, tmp_path, name
     assert "vocab 320 tokens, 7 merges, n_loaded 37" in r.stderr
 
 
+def test_params_parse_flags(pkg, tmp_path):
+    exe = _build_driver(pkg, tmp_path)
+    r = subprocess.run([exe, "--flags", "--bogus", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "unknown argument: --bogus" in r.stderr and "--top_k N" in r.stderr   # biogpt.cpp:1011-1015
+    r = subprocess.run([exe, "--flags", "-m"], capture_output=True, text=True)
+    assert r.returncode == 2 and "missing value" in r.stderr
+    r = subprocess.run([exe, "--flags", "-m", str(tmp_path / "nope.bin"), "-n", "3", "--top_k", "1", "-p", "2 5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_flags_drive_generation(pkg, oracle, tiny_models, tmp_path):
+    exe = _build_driver(pkg, tmp_path)
+    r = subprocess.run([exe, "--flags", "-m", tiny_models["q4_1"], "-n", "12", "--top_k", "1", "-b", "4", "-p", "2 17 45 300 9 128"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref, _ = oracle.OracleModel(tiny_models["q4_1"]).generate_greedy([2, 17, 45, 300, 9, 128], 12, n_batch=4)
+    assert [int(t) for t in r.stdout.split()] == list(ref)
+
+
 @pytest.mark.gpu
 def test_sampler_top_k_top_p_is_seeded_and_bounded(pkg, tiny_models, tmp_path):
     exe = _build_driver(pkg, tmp_path)
