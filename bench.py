@@ -246,6 +246,14 @@ def main():
                     "lm_head": {"GBps": round(nbytes_lm / secs_lm / 1e9, 1), "us": round(secs_lm * 1e6, 3), "bytes": nbytes_lm},
                 },
             }
+            # the SAME kernel body on a weight stream larger than L2 + Infinity Cache (2^19 rows x 1024 Q4_0 = 302 MB):
+            # what it sustains per byte once the 1.6 us launch floor is amortised (north_star: >= 70 % of roofline)
+            if args.ftype == "q4_0":
+                ss, sb = model.bench_stream(1 << 19, 20, 8)
+                out["roofline"]["kernel_at_scale"] = {
+                    "what": "matvec_fast_kernel<Q4_0,LN,LOGITS,1024> (LayerNorm + W4A8 mat-vec, in-order block sums) on 524288 x 1024 synthetic Q4_0 rows",
+                    "bytes_per_launch": sb, "us_per_launch": round(ss * 1e6, 2), "achieved": round(sb / ss / 1e9, 1),
+                    "frac": round(sb / ss / 1e9 / HBM_PEAK_GBS, 4)}
             # whole-token: graph replay at fixed context, HIP-event timed
             tok = {}
             for T in (104, 1024):

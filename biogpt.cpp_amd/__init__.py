@@ -80,6 +80,7 @@ SYMBOLS = [
     ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
     ("biogpt_hip_bench_matvec", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_decode", C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(C.c_double)]),
+    ("biogpt_hip_bench_stream", C.c_int, [_P, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_quantize_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
     ("biogpt_hip_write_synthetic", C.c_int, [C.c_char_p, C.POINTER(HParams), C.c_uint64]),
 ]
@@ -190,6 +191,12 @@ class BiogptModel:
     def bench_matvec(self, which, layer=0, reps=200):
         secs, nbytes = C.c_double(0.0), C.c_double(0.0)
         if lib().biogpt_hip_bench_matvec(self._h, int(which), int(layer), int(reps), C.byref(secs), C.byref(nbytes)) != 0:
+            raise BiogptError(_err())
+        return secs.value, nbytes.value
+
+    def bench_stream(self, rows=1 << 19, reps=20, steps=8):
+        secs, nbytes = C.c_double(0.0), C.c_double(0.0)
+        if lib().biogpt_hip_bench_stream(self._h, int(rows), int(reps), int(steps), C.byref(secs), C.byref(nbytes)) != 0:
             raise BiogptError(_err())
         return secs.value, nbytes.value
 

@@ -1087,6 +1087,49 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     return 0;
 }
 
+int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int steps, double *seconds_out, double *bytes_out) {
+    // The decode mat-vec kernel body on a weight stream far larger than the caches: rows x 1024 synthetic
+    // Q4_0 blocks (random bytes), the model's final LayerNorm as prologue, logits epilogue without arg-max.
+    clear_error();
+    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
+    if (ctx->hp.d_model != 1024 || rows < 1024 || rows % 1024 || reps < 1 || steps < 2) BG_FAIL(-1, "bad argument");
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    const size_t nblk = (size_t)rows * 32;
+    uint8_t *qs = nullptr, *sc = nullptr;
+    float *out = nullptr;
+    HIP_TRY(-2, hipMalloc(&qs, nblk * 16));
+    HIP_TRY(-2, hipMalloc(&sc, nblk * 2));
+    HIP_TRY(-2, hipMalloc(&out, (size_t)rows * 4));
+    {
+        std::vector<uint32_t> h(nblk * 4);
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (auto &v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (uint32_t)(s >> 32); }
+        HIP_TRY(-2, hipMemcpy(qs, h.data(), nblk * 16, hipMemcpyHostToDevice));
+        std::vector<uint16_t> d(nblk, 0x2000);  // fp16 2^-7: finite, no NaN/inf scales
+        HIP_TRY(-2, hipMemcpy(sc, d.data(), nblk * 2, hipMemcpyHostToDevice));
+    }
+    bgk::MatvecParams p{};
+    p.W.qs = qs; p.W.sc = sc; p.W.qh = nullptr; p.W.type = T_Q4_0; p.W.M = rows; p.W.K = 1024;
+    p.x = ctx->x; p.ldx = 1024; p.N = 1; p.eps = 1e-5f;
+    p.ln_w = dev_vec(ctx, ctx->plan.ln_w); p.ln_b = dev_vec(ctx, ctx->plan.ln_b);
+    p.out = out; p.ldo = rows; p.st = ctx->state; p.inv_k = 1.0 / 1024.0; p.k_pow2 = 1;
+    p.rpw = 2 * steps;
+    const int grid = (rows + 4 * p.rpw - 1) / (4 * p.rpw);
+    const size_t sm = bgk::matvec_fast_smem_bytes(1024, p.rpw);
+    auto launch = [&] { hipLaunchKernelGGL((bgk::matvec_fast_kernel<bgk::W_Q4_0, bgk::PRO_LN, bgk::EPI_LOGITS, 1024, 4, 1>), dim3(grid), dim3(256), sm, ctx->stream, p); };
+    for (int i = 0; i < 2; i++) launch();
+    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; i++) launch();
+    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
+    if (bytes_out) *bytes_out = 18.0 * (double)nblk + 4.0 * 1024 + 4.0 * rows;   // file-density bytes (18 B / block) + x + out
+    (void)hipFree(qs); (void)hipFree(sc); (void)hipFree(out);
+    return 0;
+}
+
 int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out) {
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");

@@ -138,6 +138,12 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
                             double *seconds_out, double *bytes_out);
 
+/* The decode mat-vec kernel (LayerNorm + Q4_0 W*A8 mat-vec, d_model = 1024 columns) on a synthetic weight
+ * stream of `rows` rows -- far larger than the caches when rows >= 2^19 (302 MB): measures what the kernel
+ * body sustains per byte when launch latency is amortised (SURVEY 8d roofline check).  `steps` = row steps per
+ * wave.  HIP-event timed; *bytes_out = algorithmic bytes of one launch. */
+int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int steps, double *seconds_out, double *bytes_out);
+
 /* Timed replay of the captured single-token decode graph at a fixed n_past (no token feedback
  * side effects beyond the KV row at n_past): average seconds per token over `reps` replays,
  * HIP-event timed on the context's stream. */
