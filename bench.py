@@ -263,6 +263,17 @@ def main():
                                    "GBps": round(b / s / 1e9, 1), "frac_of_peak": round(b / s / 1e9 / HBM_PEAK_GBS, 4),
                                    "bytes_per_token": int(b)}
             out["token_roofline"] = tok
+            # batched multi-sequence decode on this one GPU (biogpt_hip_generate_greedy_batch): S independent
+            # 200-token continuations decoded together, weights read once per step for all S -- NOT the headline
+            # (configs[1] is single-stream), reported because it is what the HBM-bound regime of this chip looks like
+            if args.ftype.startswith("q"):
+                ms = {}
+                for S in (8, 32):
+                    prompts = [make_prompt(hp.n_vocab, 9000 + i) for i in range(S)]
+                    model.generate_greedy_batch(prompts, 8, n_batch=8)            # warm-up: allocations + graph capture
+                    ids_b, secs_b = model.generate_greedy_batch(prompts, n_predict, n_batch=8)
+                    ms["S=%d" % S] = {"tokens_per_s": round(S * n_predict / secs_b, 1), "ms_per_step_all_seqs": round(secs_b / n_predict * 1e3, 4)}
+                out["multi_stream"] = ms
             # the drop-in API loop: logits cross PCIe every token, host arg-max (never `value`)
             pr = make_prompt(hp.n_vocab, 7)
             t1 = time.perf_counter()

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("biogpt_hip_synchronize", C.c_int, [_P]),
     ("biogpt_hip_eval_all", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_generate_greedy", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
+    ("biogpt_hip_generate_greedy_batch", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
     ("biogpt_hip_bench_matvec", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_decode", C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(C.c_double)]),
@@ -181,6 +182,18 @@ class BiogptModel:
         if n < 0:
             raise BiogptError(_err())
         return out[:n].copy(), secs.value
+
+    def generate_greedy_batch(self, prompts, n_predict, n_batch=8):
+        """Batched decode of several independent prompts (list of id lists) on this device."""
+        lens = np.asarray([len(p) for p in prompts], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int32) for p in prompts]))
+        out = np.zeros((len(prompts), max(int(n_predict), 1)), dtype=np.int32)
+        secs = C.c_double(0.0)
+        n = lib().biogpt_hip_generate_greedy_batch(self._h, flat.ctypes.data, lens.ctypes.data, len(prompts), int(n_batch),
+                                                   int(n_predict), out.ctypes.data, C.byref(secs))
+        if n < 0:
+            raise BiogptError(_err())
+        return out.reshape(-1)[:len(prompts) * n].reshape(len(prompts), n).copy(), secs.value
 
     def read_kv(self, which, offset, count):
         out = np.empty(int(count), dtype=np.float32)

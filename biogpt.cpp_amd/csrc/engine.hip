@@ -189,6 +189,14 @@ struct biogpt_hip_ctx {
     size_t slot_bytes = 0;
     int slot_idx = 0;
 
+    // batched multi-sequence decode (biogpt_hip_generate_greedy_batch): per-sequence caches + state
+    float *bk = nullptr, *bv = nullptr;   // [cap][n_layer][n_head][n_positions][dk]
+    bgk::SeqState *seq = nullptr;         // [cap]
+    int32_t *seq_gen = nullptr;           // [cap][n_positions]
+    int batch_cap = 0;
+    hipGraphExec_t graph_batch[6] = {};   // [context bucket], captured for graph_batch_n sequences
+    int graph_batch_n = 0;
+
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
@@ -313,7 +321,7 @@ hipError_t launch_fast_explicit(bgk::MatvecParams p, int steps, hipStream_t st) 
     return hipGetLastError();
 }
 
-enum ChainOp { CHAIN_QKV_Q8, CHAIN_OPROJ, CHAIN_FC1, CHAIN_FC1_Q8, CHAIN_FC2 };
+enum ChainOp { CHAIN_QKV_Q8, CHAIN_OPROJ, CHAIN_FC1, CHAIN_FC1_Q8, CHAIN_FC2, CHAIN_LMHEAD_Q8 };
 template <int WT, int NC>
 hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
     switch (op) {
@@ -324,13 +332,16 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
             else return hipErrorInvalidValue;
         case CHAIN_FC1_Q8: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_GELU_Q8, 1024, 4, NC>(p, 4, st);
         case CHAIN_FC2: return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_RESID, 4096, 1, NC>(p, 1, st);
+        case CHAIN_LMHEAD_Q8:  // rows_per_wave * columns <= 64 finisher lanes: 4 row steps with 8 columns
+            if constexpr (NC == 8) return launch_fast_explicit<WT, bgk::PRO_Q8IN, bgk::EPI_LOGITS, 1024, 4, 8>(p, 4, st);
+            else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
 template <int WT>
 hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
     if constexpr (bgk::TypeInfo<WT>::quant) {
-        if (p.N == 1) return launch_chain_nc<WT, 1>(op, p, st);
+        if (p.N == 1 && p.seq == nullptr && op != CHAIN_LMHEAD_Q8 && op != CHAIN_QKV_Q8 && op != CHAIN_FC1_Q8) return launch_chain_nc<WT, 1>(op, p, st);
         return launch_chain_nc<WT, 8>(op, p, st);
     }
     return hipErrorInvalidValue;
@@ -400,7 +411,7 @@ hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_
 
 // The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
 // lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
-bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
+bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false) {
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
     const int dk = D / H;
@@ -416,12 +427,16 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
     const int32_t wt = ftype_to_type(hp.ftype);
     const bool chain = is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
-    const bool pchain = chain && N > 1;   // prefill chunk: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
+    const bool pchain = chain && (N > 1 || batch);   // several columns: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
+    if (batch && !chain) BG_FAIL(false, "batched decode needs the BioGPT-base fast chain (block-quantized weights, d_model 1024, d_ff 4096, head size 64)");
+    const int64_t seq_stride = (int64_t)hp.n_layer * P * D;
+    float *const kroot = batch ? c->bk : c->memory_k;
+    float *const vroot = batch ? c->bv : c->memory_v;
     const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
 
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
-                       sqrtf((float)D), c->x, D);
+                       sqrtf((float)D), c->x, D, batch ? c->seq : nullptr);
     for (int l = 0; l < hp.n_layer; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
@@ -431,8 +446,9 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
             p.ln_w = dev_vec(c, L.ln0_w); p.ln_b = dev_vec(c, L.ln0_b);
             p.bias = dev_vec(c, L.qkv_b);
             p.q_out = c->q;
-            p.kcache = c->memory_k + (size_t)l * P * D;
-            p.vcache = c->memory_v + (size_t)l * P * D;
+            p.kcache = kroot + (size_t)l * P * D;
+            p.vcache = vroot + (size_t)l * P * D;
+            if (batch) { p.seq = c->seq; p.kv_seq_stride = seq_stride; }
             p.q_scale = 1.0f / sqrtf((float)dk);
             if (pchain) {
                 HIP_TRY(false, launch_lnq(c, c->x, N, L.ln0_w, L.ln0_b, q81, st));
@@ -444,14 +460,15 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
         }
         {  // attention
             bgk::AttnParams a{};
-            a.q = c->q; a.kcache = c->memory_k + (size_t)l * P * D; a.vcache = c->memory_v + (size_t)l * P * D;
+            a.q = c->q; a.kcache = kroot + (size_t)l * P * D; a.vcache = vroot + (size_t)l * P * D;
+            if (batch) { a.seq = c->seq; a.kv_seq_stride = seq_stride; }
             a.out = c->att; a.st = c->state;
             a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
             a.N = N; a.D = D; a.dk = dk; a.P = P;
             a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
             a.q81 = q81;
             if (chain) { a.oq_q = c->aq_q[0]; a.oq_d = c->aq_d[0]; a.oq_s = c->aq_s[0]; }
-            if (dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && env_int("BIOGPT_HIP_PREFILL_MFMA", 0)) {
+            if (!batch && dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && env_int("BIOGPT_HIP_PREFILL_MFMA", 0)) {
                 // opt-in: QK^T / PV of the prefill chunk on the matrix cores (f32 MFMA; tolerance parity, not bit parity)
                 const size_t smb = bgk::attn_mfma_smem_bytes(P);
                 static bool attr_set = false;
@@ -519,6 +536,16 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max) {
                 HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
             }
         }
+    }
+    if (batch) {  // every sequence needs its logits row: LayerNorm+Q8 once, then the 8-column mat-vec
+        const MatSlot &m = c->plan.lm_head;
+        const MvShape s = mv_shape(m.type, m.M, m.K, tw, N);
+        bgk::MatvecParams p = mv_base(c, m, s);
+        HIP_TRY(false, launch_lnq(c, c->x, N, c->plan.ln_w, c->plan.ln_b, q81, st));
+        p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
+        p.N = N; p.out = c->logits_all; p.ldo = V;
+        HIP_TRY(false, launch_chain(CHAIN_LMHEAD_Q8, p, st));
+        return true;
     }
     {  // final LayerNorm + lm_head; only the rows that are returned (F8)
         const MatSlot &m = c->plan.lm_head;
@@ -710,6 +737,8 @@ void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
+    for (void *p : {(void *)c->bk, (void *)c->bv, (void *)c->seq, (void *)c->seq_gen}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -947,6 +976,112 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
     if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
     HIP_TRY(-2, hipMemcpy(out_ids, reinterpret_cast<uint8_t *>(ctx->state) + sizeof(bgk::DevState) + (size_t)ctx->hp.n_positions * 4,
                           (size_t)n_predict * 4, hipMemcpyDeviceToHost));
+    return n_predict;
+}
+
+int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_seqs,
+                                     int32_t n_batch, int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+    clear_error();
+    if (!ctx || !prompts || !prompt_lens || !out_ids) BG_FAIL(-1, "null argument");
+    if (!ctx->ready) BG_FAIL(-1, "model has no tensors loaded (empty model): cannot evaluate");
+    if (n_seqs < 1 || n_seqs > 64) BG_FAIL(-1, "n_seqs must be in [1, 64]");
+    if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
+    const auto &hp = ctx->hp;
+    const int P = hp.n_positions, D = hp.d_model, V = hp.n_vocab;
+    int max_len = 0;
+    {
+        size_t off = 0;
+        for (int s = 0; s < n_seqs; s++) {
+            if (prompt_lens[s] < 1) BG_FAIL(-1, "empty prompt (sequence %d)", s);
+            if (!check_eval_args(ctx, prompts + off, prompt_lens[s], 0)) return -1;
+            max_len = std::max(max_len, prompt_lens[s]);
+            off += (size_t)prompt_lens[s];
+        }
+    }
+    n_predict = std::min(n_predict, P - max_len);  // main.cpp:82, for the longest prompt
+    if (n_predict <= 0) return 0;
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    const size_t seq_stride = (size_t)hp.n_layer * P * D;
+    if (n_seqs > ctx->batch_cap) {  // per-sequence F32 KV caches + state (192 MiB per BioGPT-base sequence)
+        for (void *p : {(void *)ctx->bk, (void *)ctx->bv, (void *)ctx->seq, (void *)ctx->seq_gen}) if (p) (void)hipFree(p);
+        ctx->bk = ctx->bv = nullptr; ctx->seq = nullptr; ctx->seq_gen = nullptr; ctx->batch_cap = 0;
+        HIP_TRY(-2, hipMalloc(&ctx->bk, seq_stride * 4 * n_seqs));
+        HIP_TRY(-2, hipMalloc(&ctx->bv, seq_stride * 4 * n_seqs));
+        HIP_TRY(-2, hipMalloc(&ctx->seq, sizeof(bgk::SeqState) * n_seqs));
+        HIP_TRY(-2, hipMalloc(&ctx->seq_gen, (size_t)n_seqs * P * 4));
+        ctx->batch_cap = n_seqs;
+        for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    }
+    if ((size_t)n_seqs > ctx->logits_all_rows) {
+        if (ctx->logits_all) (void)hipFree(ctx->logits_all);
+        ctx->logits_all = nullptr;
+        HIP_TRY(-2, hipMalloc(&ctx->logits_all, (size_t)n_seqs * V * 4));
+        ctx->logits_all_rows = (size_t)n_seqs;
+        for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    }
+    if (ctx->graph_batch_n != n_seqs) {
+        for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        ctx->graph_batch_n = n_seqs;
+    }
+    std::vector<bgk::SeqState> hs((size_t)n_seqs);
+    for (int s = 0; s < n_seqs; s++) hs[(size_t)s] = bgk::SeqState{prompt_lens[s], 0, 0, 0};
+    HIP_TRY(-2, hipMemcpy(ctx->seq, hs.data(), sizeof(bgk::SeqState) * n_seqs, hipMemcpyHostToDevice));
+
+    auto batch_step = [&](int t_max) -> bool {
+        if (!enqueue_forward(ctx, n_seqs, false, t_max, true)) return false;
+        hipLaunchKernelGGL(bgk::argmax_rows_kernel, dim3(n_seqs), dim3(1024), 0, ctx->stream, ctx->logits_all, V, V, ctx->seq, 0, ctx->seq_gen, P, 1);
+        HIP_TRY(false, hipGetLastError());
+        return true;
+    };
+    const bool use_graph = env_int("BIOGPT_HIP_NO_GRAPH", 0) == 0;
+    if (use_graph) {
+        for (int b = graph_bucket(max_len + 1); b <= graph_bucket(std::max(1, max_len + n_predict - 1)); b++) {
+            if (ctx->graph_batch[b]) continue;
+            hipGraph_t g = nullptr;
+            HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const bool ok = batch_step(bucket_tmax(ctx, b));
+            hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+            if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
+            HIP_TRY(-2, e);
+            HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_batch[b], g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+    }
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+
+    const auto t0 = std::chrono::steady_clock::now();
+    // prompt ingestion, one sequence after the other, each into its own cache (main.cpp:129-137 per sequence)
+    float *const k0 = ctx->memory_k, *const v0 = ctx->memory_v;
+    size_t off = 0;
+    bool ok = true;
+    for (int s = 0; s < n_seqs && ok; s++) {
+        ctx->memory_k = ctx->bk + (size_t)s * seq_stride;
+        ctx->memory_v = ctx->bv + (size_t)s * seq_stride;
+        const int len = prompt_lens[s];
+        for (int n_past = 0; n_past < len && ok; n_past += n_batch) {
+            const int n = std::min(n_batch, len - n_past);
+            ok = upload_state(ctx, prompts + off + n_past, n, n_past) && enqueue_forward(ctx, n, false, n_past + n);
+        }
+        if (ok) {  // first sampled token of this sequence
+            hipLaunchKernelGGL(bgk::argmax_rows_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, V, V, ctx->seq, s, ctx->seq_gen, P, 0);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        off += (size_t)len;
+    }
+    ctx->memory_k = k0;
+    ctx->memory_v = v0;
+    if (!ok) return -2;
+    for (int k = 1; k < n_predict; k++) {  // batched decode: one column per sequence
+        const int t_max = max_len + k;
+        if (use_graph) HIP_TRY(-2, hipGraphLaunch(ctx->graph_batch[graph_bucket(t_max)], ctx->stream));
+        else if (!batch_step(t_max)) return -2;
+    }
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+    std::vector<int32_t> gen((size_t)n_seqs * P);
+    HIP_TRY(-2, hipMemcpy(gen.data(), ctx->seq_gen, gen.size() * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < n_seqs; s++) std::memcpy(out_ids + (size_t)s * n_predict, gen.data() + (size_t)s * P, (size_t)n_predict * 4);
     return n_predict;
 }
 

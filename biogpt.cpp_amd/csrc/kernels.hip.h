@@ -56,6 +56,15 @@ struct DevState {
 __device__ __forceinline__ const int32_t *state_tokens(const DevState *st) { return reinterpret_cast<const int32_t *>(st + 1); }
 __device__ __forceinline__ int32_t *state_tokens(DevState *st) { return reinterpret_cast<int32_t *>(st + 1); }
 
+// Per-sequence decode state for batched multi-sequence decode (one activation column per sequence):
+// its own position, current token and output count; kernels index it by column.
+struct SeqState {
+    int32_t n_past;
+    int32_t token;
+    int32_t n_gen;
+    int32_t pad;
+};
+
 struct DevMatrix {
     const uint8_t *qs;   // quants / float values
     const uint8_t *sc;   // per-block scales (see header comment); unused for float types
@@ -164,12 +173,13 @@ __device__ __forceinline__ float dequant_elem(const DevMatrix &m, int64_t row, i
 // x[n][d] = dequant(embed_tokens[tok[n]])[d] * sqrt(D) + dequant(embed_pos[n_past + n + 2])[d]
 // (biogpt.cpp:664-686; position offset +2 at :672; embedding scale F7)
 __global__ void embed_kernel(DevMatrix tok_emb, DevMatrix pos_emb, const DevState *st, float embed_scale,
-                             float *x, int D) {
+                             float *x, int D, const SeqState *seq) {
     const int n = blockIdx.y;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
-    const int32_t tok = state_tokens(st)[n];
-    const int32_t pos = st->n_past + n + 2;
+    // seq != null: column n is an independent sequence with its own token / position
+    const int32_t tok = seq ? seq[n].token : state_tokens(st)[n];
+    const int32_t pos = (seq ? seq[n].n_past : st->n_past + n) + 2;
     const float te = __fmul_rn(dequant_elem(tok_emb, tok, d), embed_scale);
     const float pe = dequant_elem(pos_emb, pos, d);
     x[(size_t)n * D + d] = __fadd_rn(te, pe);
@@ -204,6 +214,8 @@ struct MatvecParams {
     int32_t D;
     float q_scale;
     const DevState *st;
+    const SeqState *seq;       // batched decode: per-column position (null: columns are consecutive positions of one sequence)
+    int64_t kv_seq_stride;     // floats between two sequences' caches
     // EPI_GELU
     const uint16_t *gelu_tab;
     // EPI_LOGITS: fused partial arg-max (N == 1 only); may be null
@@ -641,6 +653,8 @@ struct AttnParams {
     int32_t t_cap;                // launch-time upper bound of the context (fast kernel load bound)
     int8_t *oq_q; float *oq_d; uint32_t *oq_s;  // optional Q8 copy of the output for the fast out_proj (null: off)
     int32_t q81;                  // 1: Q8_1 activation form (Q4_1 / Q5_1 weights), 0: Q8_0
+    const SeqState *seq;          // batched decode: query row i belongs to sequence i (own cache + position)
+    int64_t kv_seq_stride;
     unsigned long long *tstamp;  // profiling (dbg & 32): [16 waves][8] stamps of block (0,0)
     int32_t dbg;
 };
@@ -769,6 +783,39 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float *pmax_val, cons
         st->n_gen = g + 1;
         tokens[0] = si[0];
         st->n_past = st->n_past + n_eval;
+    }
+}
+
+
+// Batched decode sampler: one workgroup per sequence row of logits[rows][ld]; arg-max (lowest id wins ties),
+// appended to the sequence's id list, becomes its next input token; advance = 1 moves its position on.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float *logits, int ld, int n_vocab, SeqState *seq, int seq0,
+                                                           int32_t *gen_ids, int gen_stride, int advance) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const float *lg = logits + (size_t)row * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < n_vocab; k += blockDim.x) {
+        const float v = lg[k];
+        if (v > bv) { bv = v; bi = k; }   // ascending k: the first maximum is kept
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nw; w++)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        SeqState *s = seq + seq0 + row;
+        gen_ids[(size_t)(seq0 + row) * gen_stride + s->n_gen] = bi;
+        s->n_gen += 1;
+        s->token = bi;
+        s->n_past += advance;
     }
 }
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     if (finisher) {
         if (EPI != EPI_LOGITS) e_bias = p.bias[f_row];
         if (EPI == EPI_RESID) e_res = p.resid[(size_t)(col0 + f_c) * p.ldr + f_row];
-        if (EPI == EPI_QKV) e_npast = p.st->n_past;
+        if (EPI == EPI_QKV) e_npast = p.seq ? p.seq[col0 + f_c].n_past : p.st->n_past + col0 + f_c;   // cache row of this column
     }
 
     // ---- LayerNorm statistics (ggml_norm: double sums; per wave over the whole column) ----------
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             if (which == 0) {
                 p.q_out[(size_t)col * K + rr] = __fmul_rn(v, p.q_scale);
             } else {
-                float *cache = (which == 1) ? p.kcache : p.vcache;
+                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)col * p.kv_seq_stride : 0);
                 const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);  // head-major cache: [H][P][dk], dk = 2^k
-                cache[(((size_t)hh * p.P + e_npast + col) << p.dk_log2) + dd] = v;
+                cache[(((size_t)hh * p.P + e_npast) << p.dk_log2) + dd] = v;
             }
         } else if (EPI == EPI_RESID) {
             p.out[(size_t)col * p.ldo + r] = __fadd_rn(__fadd_rn(v, e_bias), e_res);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             }
         }
     }
-    if (EPI == EPI_LOGITS && p.pmax_val != nullptr) {
+    if (EPI == EPI_LOGITS && NC == 1 && p.pmax_val != nullptr) {
         // per-block partial arg-max (lowest index wins ties), finished by argmax_kernel
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -407,13 +407,14 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
     // lane ksub of a quad owns float4 #(4m + ksub) of the 16 float4 of a key row: each load instruction
     // of a quad covers 64 contiguous bytes
-    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + ksub;   // [H][P][dk]
-    const float *__restrict__ vbase = p.vcache + (size_t)h * p.P * DK + d;
+    const size_t seq_off = p.seq ? (size_t)i * p.kv_seq_stride : 0;   // batched decode: query row i = sequence i
+    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + seq_off + (size_t)h * p.P * DK) + ksub;   // [H][P][dk]
+    const float *__restrict__ vbase = p.vcache + seq_off + (size_t)h * p.P * DK + d;
     const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)i * D + (size_t)h * DK) + ksub;
 
     // ---- entry: all loads ----
-    const int n_past = p.st->n_past;
-    const int causal = p.st->causal;
+    const int n_past = p.seq ? p.seq[i].n_past : p.st->n_past;
+    const int causal = p.seq ? 0 : p.st->causal;
     float4 kr[KP][4];
 #pragma unroll
     for (int ps = 0; ps < KP; ps++) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         }
     }
     AT_STAMP(1);
-    const int T = causal ? n_past + i + 1 : n_past + p.N;
+    const int T = p.seq ? n_past + 1 : (causal ? n_past + i + 1 : n_past + p.N);
 
     // ---- scores: 16 dims per lane, quad reduce ----
     float sc[KP];

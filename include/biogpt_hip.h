@@ -125,6 +125,17 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
                                int32_t n_batch, int32_t n_predict, int32_t *out_ids,
                                double *seconds_out);
 
+/* Batched greedy generation: n_seqs independent sequences decoded together on ONE device, one activation
+ * column per sequence (own F32 KV cache, own position), so every weight byte is read once per step for all
+ * sequences.  Each sequence's ids are identical to what biogpt_hip_generate_greedy() returns for it alone
+ * (per-column arithmetic is unchanged).  No counterpart in the reference (it decodes one sequence); this is
+ * the single-GPU form of "independent prompts" sharding.  prompts = the prompts concatenated,
+ * prompt_lens[n_seqs] their lengths; n_predict is clamped to n_positions - max(prompt_lens); out_ids is
+ * [n_seqs][returned n_predict].  Needs the BioGPT-base fast chain (block-quantized weights). */
+int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens,
+                                     int32_t n_seqs, int32_t n_batch, int32_t n_predict, int32_t *out_ids,
+                                     double *seconds_out);
+
 /* ---- introspection for tests / profiling ---------------------------------------------------
  * Copy `count` floats of the F32 KV cache (which: 0 = K, 1 = V) starting at element `offset` of
  * the flat [n_layer][n_positions][d_model] array (biogpt.cpp:331-335) to host memory. */
