@@ -476,7 +476,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     HIP_TRY(false, hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smb));
                     attr_set = true;
                 }
-                hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(256), smb, st, a);
+                hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
             } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
                 // loads are bounded by t_cap (multiple of 64); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);

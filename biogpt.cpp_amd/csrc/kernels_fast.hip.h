@@ -542,7 +542,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
 // ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
 // QK^T/PV contraction") ---------------------------------------------------------------------------------
-// One 256-thread workgroup per head, up to 16 query tokens of one chunk (n_batch = 8 pads the 16-wide tile),
+// One 1024-thread workgroup per head, up to 16 query tokens of one chunk (n_batch = 8 pads the 16-wide tile),
 // head size 64, no intra-chunk mask (F1) unless the opt-in causal flag is set.
 //   QK^T : per 16-key tile  C[key][query] += A[key][d] * B[d][query]  with v_mfma_f32_16x16x4_f32, 16 steps
 //          over the 64 dims (the dims are visited in the order 16m + 4k + c so that every lane's operands are
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 // is opt-in (BIOGPT_HIP_PREFILL_MFMA=1), the default prefill attention stays the bit-parity VALU kernel.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
-    constexpr int DK = 64;
+__global__ __launch_bounds__(1024) void attn_mfma_kernel(const AttnParams p) {
+    constexpr int DK = 64, NW = 16;               // 16 waves: one per query row in the softmax phase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     const int T16 = (T + 15) & ~15;
     const int TP = p.P + 2;                       // LDS row pitch (floats): pitch % 32 == 2 -> conflict-free A reads in PV
     float *S = reinterpret_cast<float *>(smem_raw);                       // [16][TP] scores, then probabilities
-    float *R = S + 16 * TP;                                               // [4 waves][16][64] partial outputs
+    float *R = S + 16 * TP;                                               // [16 waves][16][64] partial outputs
 
     const float *kbase = p.kcache + (size_t)h * p.P * DK;                 // head-major cache [H][P][dk]
     const float *vbase = p.vcache + (size_t)h * p.P * DK;
@@ -579,19 +579,19 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     for (int m = 0; m < 4; m++)
         qv[m] = (li < N) ? *reinterpret_cast<const float4 *>(p.q + (size_t)li * D + (size_t)h * DK + 16 * m + 4 * lk) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- QK^T ----
-    for (int j0 = wave * 16; j0 < T16; j0 += 128) {      // 2 key tiles per trip: all loads first
+    // ---- QK^T: 16-key tiles round-robin over the 16 waves, 2 tiles per trip (all loads first) ----
+    for (int j0 = wave * 16; j0 < T16; j0 += 2 * NW * 16) {
         float4 kv[2][4];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int jt = j0 + 64 * u;
+            const int jt = j0 + NW * 16 * u;
             const float *krow = kbase + (size_t)min(jt + li, p.P - 1) * DK + 4 * lk;
 #pragma unroll
             for (int m = 0; m < 4; m++) kv[u][m] = *reinterpret_cast<const float4 *>(krow + 16 * m);
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int jt = j0 + 64 * u;
+            const int jt = j0 + NW * 16 * u;
             if (jt >= T16) break;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -612,37 +612,42 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     }
     __syncthreads();
 
-    // ---- softmax: 16 lanes per query row ----
+    // ---- softmax: wave w owns query row w (ggml_soft_max: fp16-table exp, double row sum) ----
     {
-        const int row = tid >> 4, c16 = tid & 15;
-        float *Sr = S + row * TP;
+        float *Sr = S + wave * TP;
         float mx = -INFINITY;
-        for (int j = c16; j < T16; j += 16) mx = fmaxf(mx, Sr[j]);
-        mx = fmaxf(mx, dpp_f<DPP_QUAD_XOR1>(mx)); mx = fmaxf(mx, dpp_f<DPP_QUAD_XOR2>(mx));
-        mx = fmaxf(mx, dpp_f<DPP_ROW_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_f<DPP_ROW_MIRROR>(mx));
+        for (int j = lane; j < T16; j += 64) mx = fmaxf(mx, Sr[j]);
+        mx = wave_max_f32(mx);
         double sum = 0.0;
-        for (int j = c16; j < T16; j += 16) {
-            const float val = h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]);   // exp(-inf) = 0 for masked / padded keys
-            Sr[j] = val;
-            sum += (double)val;
+        for (int j0 = lane; j0 < T16; j0 += 256) {      // 4 table lookups in flight per lane
+            float val[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                val[u] = (j < T16) ? h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]) : 0.0f;   // exp(-inf) = 0 for masked / padded keys
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                if (j < T16) { Sr[j] = val[u]; sum += (double)val[u]; }
+            }
         }
-        sum += dpp_d<DPP_QUAD_XOR1>(sum); sum += dpp_d<DPP_QUAD_XOR2>(sum);
-        sum += dpp_d<DPP_ROW_HALF_MIRROR>(sum); sum += dpp_d<DPP_ROW_MIRROR>(sum);
+        sum = wave_sum_f64(sum);
         const float inv = inv_sum_f32(sum);
-        for (int j = c16; j < T16; j += 16) Sr[j] = __fmul_rn(Sr[j], inv);
+        for (int j = lane; j < T16; j += 64) Sr[j] = __fmul_rn(Sr[j], inv);
     }
     __syncthreads();
 
-    // ---- PV ----
+    // ---- PV: 4-key steps round-robin over the 16 waves, 4 steps per trip (all loads first) ----
     f32x4 o[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave * 4; j0 < T16; j0 += 64) {        // 4 key steps per trip: all loads first
+    for (int j0 = wave * 4; j0 < T16; j0 += 4 * NW * 4) {
         float a[4];
         float4 b[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + 16 * u;
+            const int j = j0 + NW * 4 * u;
             const bool ok = j < T16;
             a[u] = ok ? S[li * TP + j + lk] : 0.0f;                                                    // A[query li][key j + lk]
             b[u] = ok ? *reinterpret_cast<const float4 *>(vbase + (size_t)(j + lk) * DK + 4 * li)      // B[key][d = 4*li + c]
@@ -663,29 +668,31 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
         for (int r = 0; r < 4; r++) R[(wave * 16 + 4 * lk + r) * DK + 4 * li + c] = o[c][r];
     __syncthreads();
 
-    // ---- combine the 4 waves, write f32 + (optionally) the Q8 copy for the fast out_proj ----
+    // ---- combine the 16 waves: thread -> one output (query qi, dim dd); waves summed in order ----
     {
-        const int qi = tid >> 4, d0 = (tid & 15) * 4;     // thread -> (query, 4 consecutive dims)
-        float4 v;
-        float *vv = reinterpret_cast<float *>(&v);
+        const int qi = tid >> 6, dd = tid & 63;
+        float v = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-            vv[c] = (R[(0 * 16 + qi) * DK + d0 + c] + R[(1 * 16 + qi) * DK + d0 + c]) + (R[(2 * 16 + qi) * DK + d0 + c] + R[(3 * 16 + qi) * DK + d0 + c]);
+        for (int w = 0; w < NW; w++) v += R[(w * 16 + qi) * DK + dd];
         const bool live = qi < N;
-        if (live) *reinterpret_cast<float4 *>(p.out + (size_t)qi * D + (size_t)h * DK + d0) = v;
+        if (live) p.out[(size_t)qi * D + (size_t)h * DK + dd] = v;
         if (p.oq_q != nullptr) {
-            // a Q8 block = 32 dims = 8 consecutive threads (quantize_row_q8_0 / q8_1)
-            const float amax = group8_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            // wave qi holds the query's 64 outputs of this head = two Q8 blocks (quantize_row_q8_0 / q8_1)
+            float amax = fabsf(v);
+            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
+            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
             const float dq = amax / 127.0f;
             const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
-            const int q0 = (int)roundf(__fmul_rn(v.x, id)), q1 = (int)roundf(__fmul_rn(v.y, id));
-            const int q2 = (int)roundf(__fmul_rn(v.z, id)), q3 = (int)roundf(__fmul_rn(v.w, id));
-            const int isum = group8_sum(q0 + q1 + q2 + q3);
+            const int q = (int)roundf(__fmul_rn(v, id));
+            int isum = q;
+            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
+            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
+            isum += __shfl_xor(isum, 16, 64);
             if (live) {
-                const size_t blk = (size_t)qi * (D / 32) + h * 2 + (d0 >> 5);
-                reinterpret_cast<uint32_t *>(p.oq_q)[((size_t)qi * D + (size_t)h * DK + d0) >> 2] =
-                    (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-                if ((tid & 7) == 0) {
+                const size_t blk = (size_t)qi * (D / 32) + h * 2 + (dd >> 5);
+                p.oq_q[blk * 32 + (dd & 31)] = (int8_t)q;
+                if ((dd & 31) == 0) {
                     if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
                     else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
                 }
@@ -694,6 +701,6 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     }
 }
 
-__host__ __device__ inline size_t attn_mfma_smem_bytes(int P) { return ((size_t)16 * (P + 2) + 4 * 16 * 64) * 4 + 64; }
+__host__ __device__ inline size_t attn_mfma_smem_bytes(int P) { return ((size_t)16 * (P + 2) + 16 * 16 * 64) * 4 + 64; }
 
 }  // namespace bgk
