@@ -194,6 +194,7 @@ struct biogpt_hip_ctx {
     bgk::SeqState *seq = nullptr;         // [cap]
     int32_t *seq_gen = nullptr;           // [cap][n_positions]
     int batch_cap = 0;
+    bool mfma_attr_set = false;
     hipGraphExec_t graph_batch[6] = {};   // [context bucket], captured for graph_batch_n sequences
     int graph_batch_n = 0;
 
@@ -471,10 +472,9 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             if (!batch && dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && env_int("BIOGPT_HIP_PREFILL_MFMA", 0)) {
                 // opt-in: QK^T / PV of the prefill chunk on the matrix cores (f32 MFMA; tolerance parity, not bit parity)
                 const size_t smb = bgk::attn_mfma_smem_bytes(P);
-                static bool attr_set = false;
-                if (!attr_set) {
+                if (!c->mfma_attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
                     HIP_TRY(false, hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smb));
-                    attr_set = true;
+                    c->mfma_attr_set = true;
                 }
                 hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
             } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
