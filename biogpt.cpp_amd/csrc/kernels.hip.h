@@ -345,11 +345,15 @@ __host__ __device__ inline size_t matvec_smem_bytes(int wtype, int K, int NC, in
 // LayerNorm prologue every wave loads the WHOLE column (statistics are computed redundantly per wave
 // with DPP reductions -- no block barrier), but converts/quantizes only its share (jj % nwaves == wave).
 // For the plain prologue a wave loads only its share.  KCH = register chunks per lane (4 or 16).
+#ifdef BIOGPT_HIP_PROFILE_HOOKS   // make EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS: in-kernel timestamps (tools/sweep_matvec.py)
 #define BG_STAMP(k)                                                                                  \
     do {                                                                                            \
         if ((p.dbg & 32) && threadIdx.x == 0)                                                       \
             p.tstamp[(((size_t)((p.dbg >> 8) & 1) * gridDim.x + blockIdx.x) * 8) + (k)] = __builtin_readcyclecounter(); \
     } while (0)
+#else
+#define BG_STAMP(k) do {} while (0)
+#endif
 
 template <int WT, int PRO, int EPI, int NC, int KCH, bool SEQ = true>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {

@@ -392,11 +392,17 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
     __shared__ double pv[1024];
     const int h = blockIdx.x, i = blockIdx.y;
     const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef BIOGPT_HIP_PROFILE_HOOKS   // make EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS: timestamps + ablation bits (tools/sweep_attn.py)
 #define AT_STAMP(k)                                                                                   \
     do {                                                                                              \
         if ((p.dbg & 32) && (tid & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0)                    \
             p.tstamp[(tid >> 6) * 8 + (k)] = __builtin_readcyclecounter();                            \
     } while (0)
+#define AT_DBG(bit) (p.dbg & (bit))
+#else
+#define AT_STAMP(k) do {} while (0)
+#define AT_DBG(bit) 0
+#endif
     AT_STAMP(0);
     const int D = p.D;
     const int kpp = nt >> 2;                       // keys per pass
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < KP; ps++) {
         const int j = ps * kpp + kidx;
-        if (j < t_cap && !(p.dbg & 1)) {
+        if (j < t_cap && !AT_DBG(1)) {
 #pragma unroll
             for (int m = 0; m < 4; m++) kr[ps][m] = kbase[(size_t)j * (DK / 4) + 4 * m];
         }
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = sl + nsl * k;
-            if (j < t_cap && !(p.dbg & 2)) vr[k] = vbase[(size_t)j * DK];
+            if (j < t_cap && !AT_DBG(2)) vr[k] = vbase[(size_t)j * DK];
         }
     }
     AT_STAMP(1);
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
     for (int ps = 0; ps < KP; ps++) {
         const int j = ps * kpp + kidx;
         if (j < T && ksub == 0) {
-            const float val = (p.dbg & 4) ? __fsub_rn(sc[ps], mx) : h2f(p.exp_tab[f2h(__fsub_rn(sc[ps], mx))]);
+            const float val = AT_DBG(4) ? __fsub_rn(sc[ps], mx) : h2f(p.exp_tab[f2h(__fsub_rn(sc[ps], mx))]);
             S[j] = val;
             sum += (double)val;
         }
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
     // ---- PV: nsl slices x 64 dims, double accumulation ----
     double a0 = 0.0, a1 = 0.0;
-    if (VPRE && !(p.dbg & 8)) {
+    if (VPRE && !AT_DBG(8)) {
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
             const int j0 = sl + nsl * k, j1 = j0 + nsl;
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
         const float o = (float)(t0 + t1);
         p.out[(size_t)i * D + (size_t)h * DK + tid] = o;
-        if (p.oq_q != nullptr && !(p.dbg & 16)) {
+        if (p.oq_q != nullptr && !AT_DBG(16)) {
             // wave 0 holds the head's 64 outputs = two Q8 blocks of out_proj's activation row
             float amax = fabsf(o);
             amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
@@ -538,6 +544,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         }
     }
 #undef AT_STAMP
+#undef AT_DBG
 }
 
 // ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
