@@ -1,81 +1,102 @@
-// Test driver for include/biogpt_compat.h: the generation loop of the reference's CLI
-// (examples/main/main.cpp:36-151) written against the reference's C++ API names, with token ids as
-// input/output instead of text (the tokenizer is out of scope).
-//   usage: compat_driver MODEL N_PREDICT TOP_K ID [ID...]   -> prints the sampled ids, one line
+// Test driver for include/biogpt_compat.h.  It exercises every model-library symbol the reference's CLI
+// uses (biogpt.h:128-169 + the ggml handles of examples/main/main.cpp:47-70,164-169) but with token ids
+// in and out instead of text (the tokenizer is out of scope), and with the prompt phase
+// and the sampling phase as two separate loops.
+//
+//   compat_driver MODEL N_PREDICT TOP_K ID [ID...]          positional form
+//   compat_driver --flags <reference-style flags>           -p "2 17 45" is a list of ids
+// prints the sampled ids on one line.
 #include <cstdio>
 #include <cstdlib>
+#include <sstream>
 
 #include "biogpt.h"
 #include "ggml.h"
 #include "ggml-alloc.h"
 
+namespace {
+
+struct Session {
+    biogpt_model model;
+    biogpt_vocab vocab;
+    ggml_allocr *allocr = nullptr;
+    ggml_backend_buffer_t scratch = nullptr;
+    std::vector<float> logits;
+    int n_past = 0;
+
+    bool open(const biogpt_params &prm) {
+        if (!biogpt_model_load(prm.model, model, vocab, prm.verbosity)) return false;
+        // what main.cpp does to size its compute buffer; every call is a shim here
+        ggml_allocr *probe = ggml_allocr_new_measure(ggml_backend_get_alignment(model.backend));
+        const int worst = std::min(model.hparams.n_positions, prm.n_batch);
+        ggml_cgraph *g = biogpt_graph(model, probe, token_sequence((size_t)worst, 0), model.hparams.n_positions - worst);
+        const size_t bytes = ggml_allocr_alloc_graph(probe, g);
+        ggml_allocr_free(probe);
+        scratch = ggml_backend_alloc_buffer(model.backend, bytes);
+        allocr = ggml_allocr_new_from_buffer(scratch);
+        return true;
+    }
+    bool feed(const token_sequence &chunk, int n_threads) {
+        if (!biogpt_eval(model, chunk, logits, allocr, n_past, n_threads)) return false;
+        n_past += (int)chunk.size();
+        return true;
+    }
+    void close() {
+        ggml_free(model.ctx);
+        ggml_backend_buffer_free(model.buffer_w);
+        ggml_backend_buffer_free(model.buffer_kv);
+        ggml_backend_buffer_free(scratch);
+        ggml_backend_free(model.backend);
+    }
+};
+
+token_sequence parse_ids(const std::string &text) {
+    token_sequence ids;
+    std::istringstream in(text);
+    int v;
+    while (in >> v) ids.push_back(v);
+    return ids;
+}
+
+}  // namespace
+
 int main(int argc, char **argv) {
     ggml_time_init();
-    biogpt_params params;
-    token_sequence embed_inp;
+    biogpt_params prm;
+    token_sequence prompt;
     if (argc >= 2 && std::string(argv[1]) == "--flags") {
-        // reference-style flags (biogpt_params_parse); the prompt is a list of ids "2 17 45"
-        if (!biogpt_params_parse(argc - 1, argv + 1, params)) return 2;
-        size_t pos = 0;
-        while (pos < params.prompt.size()) {
-            size_t used = 0;
-            embed_inp.push_back(std::stoi(params.prompt.substr(pos), &used));
-            pos += used;
-            while (pos < params.prompt.size() && params.prompt[pos] == ' ') pos++;
-        }
+        if (!biogpt_params_parse(argc - 1, argv + 1, prm)) return 2;
+        prompt = parse_ids(prm.prompt);
     } else {
         if (argc < 5) return 2;
-        params.model = argv[1];
-        params.n_predict = std::atoi(argv[2]);
-        params.top_k = std::atoi(argv[3]);
-        for (int i = 4; i < argc; i++) embed_inp.push_back(std::atoi(argv[i]));
+        prm.model = argv[1];
+        prm.n_predict = std::atoi(argv[2]);
+        prm.top_k = std::atoi(argv[3]);
+        for (int a = 4; a < argc; a++) prompt.push_back(std::atoi(argv[a]));
     }
-    std::mt19937 rng(7);
 
-    biogpt_vocab vocab;
-    biogpt_model model;
-    if (!biogpt_model_load(params.model, model, vocab, params.verbosity)) {
-        fprintf(stderr, "failed to load model from '%s'\n", params.model.c_str());
+    Session s;
+    if (!s.open(prm)) {
+        fprintf(stderr, "failed to load model from '%s'\n", prm.model.c_str());
         return 1;
     }
-    // compute-buffer measurement dance of main.cpp:47-70 (all no-ops on this engine)
-    struct ggml_allocr *allocr = ggml_allocr_new_measure(ggml_backend_get_alignment(model.backend));
-    int n_tokens = std::min(model.hparams.n_positions, params.n_batch);
-    struct ggml_cgraph *gf = biogpt_graph(model, allocr, token_sequence(n_tokens, 0), model.hparams.n_positions - n_tokens);
-    size_t mem_size = ggml_allocr_alloc_graph(allocr, gf);
-    ggml_allocr_free(allocr);
-    ggml_backend_buffer_t buf_compute = ggml_backend_alloc_buffer(model.backend, mem_size);
-    allocr = ggml_allocr_new_from_buffer(buf_compute);
+    const int budget = std::min(prm.n_predict, s.model.hparams.n_positions - (int)prompt.size());
 
-    params.n_predict = std::min(params.n_predict, model.hparams.n_positions - (int)embed_inp.size());
-    int n_past = 0;
-    std::vector<float> logits;
-    token_sequence embed;
-    for (size_t i = embed.size(); i < embed_inp.size() + params.n_predict; i++) {
-        if (!embed.empty() && !biogpt_eval(model, embed, logits, allocr, n_past, params.n_threads)) return 1;
-        n_past += (int)embed.size();
-        embed.clear();
-        if (i >= embed_inp.size()) {
-            const int n_vocab = model.hparams.n_vocab;
-            biogpt_vocab::id id = biogpt_sample_top_k_top_p(vocab, logits.data() + (logits.size() - n_vocab), params.top_k,
-                                                            params.top_p, params.temp, rng);
-            embed.push_back(id);
-            printf("%d ", id);
-        } else {
-            for (size_t k = i; k < embed_inp.size(); k++) {
-                embed.push_back(embed_inp[k]);
-                if ((int32_t)embed.size() >= params.n_batch) break;
-            }
-            i += embed.size() - 1;
-        }
+    // phase 1: the prompt, n_batch ids per eval
+    for (size_t at = 0; at < prompt.size(); at += (size_t)prm.n_batch) {
+        const size_t n = std::min((size_t)prm.n_batch, prompt.size() - at);
+        if (!s.feed(token_sequence(prompt.begin() + at, prompt.begin() + at + n), prm.n_threads)) return 1;
+    }
+    // phase 2: sample, print, feed back (the last sampled id is not evaluated)
+    std::mt19937 rng(7);
+    for (int k = 0; k < budget; k++) {
+        const biogpt_vocab::id id = biogpt_sample_top_k_top_p(s.vocab, s.logits.data(), prm.top_k, prm.top_p, prm.temp, rng);
+        printf("%d ", id);
+        if (k + 1 < budget && !s.feed(token_sequence(1, id), prm.n_threads)) return 1;
     }
     printf("\n");
-    fprintf(stderr, "vocab %zu tokens, %zu merges, n_loaded %d, %lld us\n", vocab.id_to_token.size(), vocab.bpe_ranks.size(),
-            model.n_loaded, (long long)ggml_time_us());
-    ggml_free(model.ctx);
-    ggml_backend_buffer_free(model.buffer_w);
-    ggml_backend_buffer_free(model.buffer_kv);
-    ggml_backend_buffer_free(buf_compute);
-    ggml_backend_free(model.backend);
+    fprintf(stderr, "vocab %zu tokens, %zu merges, n_loaded %d, %lld us\n", s.vocab.id_to_token.size(), s.vocab.bpe_ranks.size(),
+            s.model.n_loaded, (long long)ggml_time_us());
+    s.close();
     return 0;
 }

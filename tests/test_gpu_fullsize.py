@@ -44,6 +44,9 @@ def test_fullshape_decode_and_prefill(pkg, oracle, files, name):
         worst = max(worst, float(np.abs(lg - lo).max()))
         exact += int((lg == lo).all())
         n_past += 1
+    big = [int(v) for v in rng.integers(4, KW["n_vocab"], 19)]       # one eval of 19 tokens: three column groups of the 8-wide kernels
+    lg, lo = g.eval(big, n_past), o.eval(big, n_past)
+    worst = max(worst, float(np.abs(lg - lo).max()))
     print("%s: worst |diff| %.2e, %d/6 decode steps bit-identical" % (name, worst, exact))
     assert worst <= ATOL
     g.close()
