@@ -268,7 +268,9 @@ hipError_t launch_mv_kch(const bgk::MatvecParams &p, const MvShape &s, hipStream
 template <int WT, int PRO, int EPI>
 hipError_t launch_mv_nc(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st) {
     constexpr int NCW = bgk::TypeInfo<WT>::quant ? 8 : 4;
-    if (p.N == 1) return launch_mv_kch<WT, PRO, EPI, 1>(p, s, st);
+    // a column tile keeps whole activation columns in registers (<= 16 float4 chunks per lane, K <= 4096); wider
+    // inputs (BioGPT-large fc2, K = 6400) go one column per workgroup row, where a wave only holds its share
+    if (p.N == 1 || (p.W.K / 4 + 63) / 64 > 16) return launch_mv_kch<WT, PRO, EPI, 1>(p, s, st);
     return launch_mv_kch<WT, PRO, EPI, NCW>(p, s, st);
 }
 

@@ -134,3 +134,38 @@ def test_batched_decode_equals_single_stream(pkg, oracle, files, name, n_seqs):
     again, _ = g.generate_greedy_batch(prompts[:2], 5)            # smaller batch on the same context: graphs re-captured
     assert list(again[1]) == list(ids[1][:5])
     g.close()
+
+
+@pytest.mark.parametrize("name", ["f32", "f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_biogpt_large_shapes_generic_path(pkg, oracle, tmp_path_factory, name):
+    """BioGPT-large widths (d_model 1600 = 50 blocks, d_ff 6400 = 200 blocks, 25 heads of 64): not powers of two,
+    so the shape-specialised kernels do not apply and the generic kernels run with masked lanes, 4 units per lane
+    and the non-power-of-two LayerNorm division.  Same bit-parity bar."""
+    d = tmp_path_factory.mktemp("large")
+    kw = dict(n_vocab=2048, n_layer=2, n_head=25, n_positions=96, d_ff=6400, d_model=1600, n_merges=3)
+    f32 = str(d / "f32.bin")
+    if name in ("f32", "f16"):
+        path = str(d / (name + ".bin"))
+        pkg.write_synthetic(path, ftype=int(name == "f16"), **kw)
+    else:
+        pkg.write_synthetic(f32, **kw)
+        path = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, path, name)
+    g = pkg.BiogptModel.load(path)
+    o = oracle.OracleModel(path, n_threads=8)
+    rng = np.random.default_rng(9)
+    toks = [2] + [int(v) for v in rng.integers(4, kw["n_vocab"], 20)]
+    worst = 0.0
+    lg, lo = g.eval(toks[:8], 0), o.eval(toks[:8], 0)
+    worst = max(worst, float(np.abs(lg - lo).max()))
+    lg, lo = g.eval(toks[8:13], 8), o.eval(toks[8:13], 8)
+    worst = max(worst, float(np.abs(lg - lo).max()))
+    for j in range(13, 21):
+        lg, lo = g.eval([toks[j]], j), o.eval([toks[j]], j)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        assert int(lg.argmax()) == int(lo.argmax())
+    ids, _ = g.generate_greedy(toks[:5], 12)
+    ref, _ = oracle.OracleModel(path, n_threads=8).generate_greedy(toks[:5], 12)
+    print("%s large-shape: worst |diff| %.2e" % (name, worst))
+    assert worst <= ATOL and list(ids) == list(ref)
+    g.close()
