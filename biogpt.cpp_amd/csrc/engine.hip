@@ -480,10 +480,11 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                 }
                 hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
             } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
-                // loads are bounded by t_cap (multiple of 64); 4 lanes per key, 16 prefetched V rows per lane
+                // loads are bounded by t_cap (= P when the table is not a multiple of 64; the workgroup stays whole
+                // waves); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);
                 if (a.t_cap <= 256) {
-                    hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(H, N), dim3(4 * a.t_cap), 0, st, a);
+                    hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(H, N), dim3(4 * ((a.t_cap + 63) & ~63)), 0, st, a);
                 } else if (a.t_cap <= 512) {
                     hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(H, N), dim3(1024), 0, st, a);
                 } else {
@@ -1130,7 +1131,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
             a.oq_q = ctx->aq_q[0]; a.oq_d = ctx->aq_d[0]; a.oq_s = ctx->aq_s[0];
             a.t_cap = std::min(P, (layer + 1 + 63) & ~63);
-            if (a.t_cap <= 256) hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(hp.n_head, 1), dim3(4 * a.t_cap), 0, ctx->stream, a);
+            if (a.t_cap <= 256) hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(hp.n_head, 1), dim3(4 * ((a.t_cap + 63) & ~63)), 0, ctx->stream, a);
             else if (a.t_cap <= 512) hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
             else hipLaunchKernelGGL((bgk::attn_fast_kernel<4, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
             HIP_TRY(false, hipGetLastError());

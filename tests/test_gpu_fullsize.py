@@ -169,3 +169,59 @@ def test_biogpt_large_shapes_generic_path(pkg, oracle, tmp_path_factory, name):
     print("%s large-shape: worst |diff| %.2e" % (name, worst))
     assert worst <= ATOL and list(ids) == list(ref)
     g.close()
+
+
+SHAPES = [
+    # (n_vocab, n_layer, n_head, n_positions, d_ff, d_model)
+    (77, 1, 3, 40, 160, 96),        # 3 blocks per row, odd vocab, dk = 32
+    (130, 2, 2, 48, 1024, 256),     # dk = 128
+    (64, 1, 1, 34, 32, 32),         # one block per row, one head
+    (300, 1, 16, 36, 8192, 2048),   # dk = 128, fc2 rows of 256 blocks
+    (1000, 1, 5, 33, 96, 320),      # d_ff < d_model, dk = 64, position table shorter than one 64-key tile
+    (50, 1, 2, 200, 64, 128),       # dk = 64 with tables that are not multiples of 64 keys: every decode
+    (50, 1, 2, 300, 64, 128),       #   attention variant (<=256, <=512, <=1024 keys) meets a ragged last tile
+    (50, 1, 2, 600, 64, 128),
+    (50, 1, 2, 1000, 64, 128),
+    (50, 1, 2, 1500, 64, 128),      # beyond 1024 keys: generic attention
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "V%d_L%d_H%d_P%d_F%d_D%d" % s)
+@pytest.mark.parametrize("name", ["f32", "f16", "q4_0", "q5_0", "q8_0"])
+def test_odd_shapes(pkg, oracle, tmp_path_factory, shape, name):
+    """Shapes the loader accepts but BioGPT-base never exercises (odd block counts, dk of 32/128, one head,
+    d_ff < d_model): generic kernels, bit parity with the oracle for a prompt chunk, a ragged chunk, single
+    tokens up to the LAST position, and greedy ids."""
+    V, L, H, P, F, D = shape
+    d = tmp_path_factory.mktemp("odd")
+    kw = dict(n_vocab=V, n_layer=L, n_head=H, n_positions=P, d_ff=F, d_model=D, n_merges=2)
+    if name in ("f32", "f16"):
+        path = str(d / (name + ".bin"))
+        pkg.write_synthetic(path, ftype=int(name == "f16"), **kw)
+    else:
+        f32 = str(d / "f32.bin")
+        pkg.write_synthetic(f32, **kw)
+        path = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, path, name)
+    g = pkg.BiogptModel.load(path)
+    o = oracle.OracleModel(path, n_threads=8)
+    rng = np.random.default_rng(V + D)
+    toks = [2] + [int(v) for v in rng.integers(0, V, P - 1)]
+    worst, pos = 0.0, 0
+    for n in (8, 3, 1, 1, 9, 1):
+        lg, lo = g.eval(toks[pos:pos + n], pos), o.eval(toks[pos:pos + n], pos)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        pos += n
+    while pos < P - 70:                 # long tables: ragged prompt chunks up to the last 70 positions
+        lg, lo = g.eval(toks[pos:pos + 7], pos), o.eval(toks[pos:pos + 7], pos)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        pos += 7
+    while pos < P:                      # single tokens to the last position of the table
+        lg, lo = g.eval([toks[pos]], pos), o.eval([toks[pos]], pos)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        pos += 1
+    ids, _ = g.generate_greedy(toks[:4], P)          # clamped to P - 4
+    ref, _ = oracle.OracleModel(path, n_threads=8).generate_greedy(toks[:4], P)
+    assert len(ids) == P - 4
+    assert worst <= ATOL and list(ids) == list(ref), worst
+    g.close()
