@@ -183,6 +183,11 @@ SHAPES = [
     (50, 1, 2, 600, 64, 128),
     (50, 1, 2, 1000, 64, 128),
     (50, 1, 2, 1500, 64, 128),      # beyond 1024 keys: generic attention
+    (500, 1, 16, 70, 4096, 1024),   # BioGPT-base widths (specialised chain) on a ragged 70-position table
+    (500, 1, 8, 70, 2048, 1024),    # K = 1024 specialised mat-vecs mixed with generic fc2 and dk = 128 attention
+    (500, 1, 32, 70, 4096, 1024),   # base widths but dk = 32: specialised mat-vecs without the Q8 hand-off chain
+    (90, 1, 4, 70, 1024, 256),      # fc2 with K = 1024 writing a 256-wide residual
+    (90, 1, 4, 70, 4096, 256),      # fc2 with K = 4096 writing a 256-wide residual
 ]
 
 
