@@ -84,7 +84,21 @@ SYMBOLS = [
     ("biogpt_hip_bench_stream", C.c_int, [_P, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_quantize_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
     ("biogpt_hip_write_synthetic", C.c_int, [C.c_char_p, C.POINTER(HParams), C.c_uint64]),
+    # text <-> ids (host-only)
+    ("biogpt_hip_vocab_load", _P, [C.c_char_p]),
+    ("biogpt_hip_vocab_create", _P, [_P, _P, C.c_int32, _P, _P, C.c_int32]),
+    ("biogpt_hip_vocab_free", None, [_P]),
+    ("biogpt_hip_ctx_vocab", _P, [_P]),
+    ("biogpt_hip_tokenizer_set_data_dir", C.c_int, [C.c_char_p]),
+    ("biogpt_hip_tokenize", C.c_int, [_P, C.c_char_p, C.c_char_p, _P, C.c_int32]),
+    ("biogpt_hip_decode", C.c_int, [_P, _P, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_decode_strings", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_moses_tokenize", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_moses_detokenize", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_bpe", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_tokenizer_byte_class", C.c_int, [C.c_int, _P]),
 ]
+E_LENGTH = -7   # BIOGPT_HIP_E_LENGTH
 
 
 def lib():
@@ -119,6 +133,120 @@ def write_synthetic(path, seed=0x42494F47, **hparams):
     if lib().biogpt_hip_write_synthetic(os.fsencode(path), C.byref(hp), C.c_uint64(seed)) != 0:
         raise BiogptError(_err())
     return hp
+
+
+class TokenizerLengthError(BiogptError):
+    """The reference's moses_tokenize throws std::length_error for this text (mosestokenizer.cpp:264)."""
+
+
+def _bytes(s):
+    return s if isinstance(s, bytes) else s.encode("utf-8")
+
+
+def _string_result(fn, *args):
+    """C-ABI string protocol: the call returns the needed length; retry once with a buffer that fits."""
+    cap = 4096
+    for _ in range(2):
+        buf = C.create_string_buffer(cap)
+        n = fn(*args, buf, cap)
+        if n == E_LENGTH:
+            raise TokenizerLengthError(_err())
+        if n < 0:
+            raise BiogptError(_err())
+        if n + 1 <= cap:
+            return buf.raw[:n]
+        cap = n + 1
+    raise BiogptError("string result did not fit")
+
+
+def set_tokenizer_data_dir(path):
+    """Directory holding nonbreaking_prefixes/ (the reference's data/); default $BIOGPT_DATA_DIR or ../data."""
+    lib().biogpt_hip_tokenizer_set_data_dir(os.fsencode(path))
+
+
+def moses_tokenize(text, lang=""):
+    """moses_tokenize (mosestokenizer.cpp:290-358): list of byte strings."""
+    raw = _string_result(lib().biogpt_hip_moses_tokenize, _bytes(text), _bytes(lang))
+    return raw.split(b"\n") if raw else []
+
+
+def moses_detokenize(tokens, lang=""):
+    """moses_detokenize (mosestokenizer.cpp:360-466)."""
+    return _string_result(lib().biogpt_hip_moses_detokenize, b"\n".join(_bytes(t) for t in tokens), _bytes(lang))
+
+
+def decode_strings(tokens, lang=""):
+    """gpt_decode (biogpt.cpp:877-906) on vocabulary strings."""
+    return _string_result(lib().biogpt_hip_decode_strings, b"\n".join(_bytes(t) for t in tokens), _bytes(lang))
+
+
+def byte_class(which):
+    """256 flags of a perluniprops byte class: 0 IsAlnum, 1 IsAlpha, 2 IsLower, 3 IsN, 4 IsSc."""
+    out = (C.c_uint8 * 256)()
+    if lib().biogpt_hip_tokenizer_byte_class(which, out) != 0:
+        raise BiogptError("bad class index")
+    return bytes(out)
+
+
+class Vocab:
+    """biogpt_vocab (biogpt.h:37-48) for the tokenizer: gpt_tokenize / gpt_decode / bpe.  Host-only."""
+
+    def __init__(self, handle, owned):
+        self._h, self._owned = handle, owned
+
+    @classmethod
+    def load(cls, path):
+        h = lib().biogpt_hip_vocab_load(os.fsencode(path))
+        if not h:
+            raise BiogptError(_err())
+        return cls(h, True)
+
+    @classmethod
+    def create(cls, tokens, merges):
+        """tokens: id -> bytes; merges: rank -> b"left right" records (what the model file stores)."""
+        tokens = [_bytes(t) for t in tokens]
+        merges = [_bytes(m) for m in merges]
+        tp = (C.c_char_p * max(1, len(tokens)))(*tokens)
+        tl = (C.c_int32 * max(1, len(tokens)))(*[len(t) for t in tokens])
+        mp = (C.c_char_p * max(1, len(merges)))(*merges)
+        ml = (C.c_int32 * max(1, len(merges)))(*[len(m) for m in merges])
+        h = lib().biogpt_hip_vocab_create(tp, tl, len(tokens), mp, ml, len(merges))
+        if not h:
+            raise BiogptError(_err())
+        return cls(h, True)
+
+    def close(self):
+        if self._h and self._owned:
+            lib().biogpt_hip_vocab_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bpe(self, word):
+        return _string_result(lib().biogpt_hip_bpe, self._h, _bytes(word))
+
+    def tokenize(self, text, lang=""):
+        """gpt_tokenize (biogpt.cpp:850-875): ids, starting with 2."""
+        cap = 256
+        for _ in range(2):
+            out = (C.c_int32 * cap)()
+            n = lib().biogpt_hip_tokenize(self._h, _bytes(text), _bytes(lang), out, cap)
+            if n == E_LENGTH:
+                raise TokenizerLengthError(_err())
+            if n < 0:
+                raise BiogptError(_err())
+            if n <= cap:
+                return list(out[:n])
+            cap = n
+        raise BiogptError("id result did not fit")
+
+    def decode(self, ids, lang=""):
+        arr = (C.c_int32 * max(1, len(ids)))(*ids)
+        return _string_result(lib().biogpt_hip_decode, self._h, arr, len(ids), _bytes(lang))
 
 
 def arena_bytes_for(hp):
@@ -224,6 +352,12 @@ class BiogptModel:
         if lib().biogpt_hip_vocab_token(self._h, int(i), C.byref(p), C.byref(n)) != 0:
             raise IndexError(i)
         return C.string_at(p, n.value)
+
+    @property
+    def vocab(self):
+        """The context's vocabulary handle (borrowed: valid until close()); None for an attached context."""
+        h = lib().biogpt_hip_ctx_vocab(self._h)
+        return Vocab(h, False) if h else None
 
     @property
     def arena(self):

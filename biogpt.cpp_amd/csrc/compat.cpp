@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstddef>
 #include <cstdlib>
+#include <sstream>
+#include <stdexcept>
 
 namespace {
 // distinct non-null addresses for the opaque handles callers only pass around / free
@@ -53,15 +55,80 @@ bool biogpt_model_load(const std::string &fname, biogpt_model &model, biogpt_voc
         vocab.token_to_id[w] = i;
         vocab.id_to_token[i] = w;
     }
+    word_pair last_pair;
     for (int32_t r = 0; r < hp.n_merges; r++) {  // biogpt.cpp:131-155: "left right" -> rank
         const char *p = nullptr; int32_t n = 0;
         if (biogpt_hip_merge(ctx, r, &p, &n) != 0) break;
-        const std::string m(p, (size_t)n);
-        const size_t sp = m.find(' ');
-        if (sp == std::string::npos) continue;
-        vocab.bpe_ranks[word_pair(m.substr(0, sp), m.substr(sp + 1))] = r;
+        if (n > 0) {   // first two whitespace-separated words; an empty record re-ranks the previous pair (biogpt.cpp:138-152)
+            std::stringstream ss(std::string(p, (size_t)n));
+            std::string left, right;
+            ss >> left >> right;
+            last_pair = word_pair(left, right);
+        }
+        vocab.bpe_ranks[last_pair] = r;
     }
     return true;
+}
+
+// ---- tokenizer (biogpt.cpp:850-906) over the C-ABI ---------------------------------------------------
+// The maps in `vocab` are the caller's to edit, so the handle is rebuilt from them on every call (a prompt is
+// tokenized once per run): id_to_token in id order, bpe_ranks in rank order.
+namespace {
+struct VocabHandle {
+    biogpt_hip_vocab *h = nullptr;
+    explicit VocabHandle(biogpt_vocab &vocab) {
+        int32_t n_tok = 0;
+        for (const auto &kv : vocab.id_to_token) n_tok = std::max(n_tok, kv.first + 1);
+        std::vector<std::string> tokens((size_t)n_tok), merges;
+        for (const auto &kv : vocab.id_to_token) if (kv.first >= 0) tokens[(size_t)kv.first] = kv.second;
+        for (const auto &kv : vocab.bpe_ranks) {
+            if (kv.second < 0) continue;
+            if ((size_t)kv.second >= merges.size()) merges.resize((size_t)kv.second + 1);
+            merges[(size_t)kv.second] = kv.first.first + " " + kv.first.second;
+        }
+        std::vector<const char *> tp, mp;
+        std::vector<int32_t> tl, ml;
+        for (const std::string &t : tokens) { tp.push_back(t.data()); tl.push_back((int32_t)t.size()); }
+        for (const std::string &m : merges) { mp.push_back(m.data()); ml.push_back((int32_t)m.size()); }
+        h = biogpt_hip_vocab_create(tp.data(), tl.data(), n_tok, mp.data(), ml.data(), (int32_t)merges.size());
+    }
+    ~VocabHandle() { biogpt_hip_vocab_free(h); }
+};
+}  // namespace
+
+token_sequence gpt_tokenize(biogpt_vocab &vocab, const std::string &text, const std::string &lang) {
+    VocabHandle v(vocab);
+    if (!v.h) throw std::runtime_error(biogpt_hip_last_error());
+    token_sequence ids(64);
+    int n = biogpt_hip_tokenize(v.h, text.c_str(), lang.c_str(), ids.data(), (int32_t)ids.size());
+    if (n > (int)ids.size()) {
+        ids.resize((size_t)n);
+        n = biogpt_hip_tokenize(v.h, text.c_str(), lang.c_str(), ids.data(), (int32_t)ids.size());
+    }
+    if (n == BIOGPT_HIP_E_LENGTH) throw std::length_error("basic_string::_M_create");   // what the reference throws (mosestokenizer.cpp:264)
+    if (n < 0) throw std::runtime_error(biogpt_hip_last_error());
+    ids.resize((size_t)n);
+    return ids;
+}
+
+std::string gpt_decode(std::vector<std::string> &tokens, const std::string &lang) {
+    std::string joined;
+    for (size_t i = 0; i < tokens.size(); i++) { if (i) joined += '\n'; joined += tokens[i]; }
+    std::string out(joined.size() + 64, '\0');
+    int n = biogpt_hip_decode_strings(joined.c_str(), lang.c_str(), &out[0], (int32_t)out.size());
+    if (n + 1 > (int)out.size()) {
+        out.assign((size_t)n + 1, '\0');
+        n = biogpt_hip_decode_strings(joined.c_str(), lang.c_str(), &out[0], (int32_t)out.size());
+    }
+    if (n < 0) throw std::runtime_error(biogpt_hip_last_error());
+    out.resize((size_t)n);
+    // side effect of the reference: the caller's vector is rewritten in place (std::transform onto itself, biogpt.cpp:879-884)
+    for (std::string &t : tokens) {
+        t.erase(std::remove(t.begin(), t.end(), ' '), t.end());
+        for (const char *tag : {"</w>", "</s>"})
+            for (size_t at; (at = t.find(tag)) != std::string::npos;) t.replace(at, 4, " ");
+    }
+    return out;
 }
 
 struct ggml_cgraph *biogpt_graph(const biogpt_model &, struct ggml_allocr *, const token_sequence &, const int) {

@@ -165,6 +165,7 @@ struct biogpt_hip_ctx {
     int n_tensors = 0;
     int64_t pos_rows = 0;
     std::vector<std::string> vocab, merges;
+    biogpt_hip_vocab *tok_vocab = nullptr;   // token <-> id maps + merge ranks for the tokenizer entry points
 
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
@@ -767,6 +768,7 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
     c->n_tensors = (int)mf.tensors.size();
     c->vocab = mf.vocab;
     c->merges = mf.merges;
+    c->tok_vocab = bg::make_vocab(mf.vocab, mf.merges);
     const auto &hp = c->hp;
     if (verbosity > 0) {
         fprintf(stderr, "biogpt_hip_load: n_vocab = %d d_ff = %d d_model = %d n_positions = %d n_head = %d n_layer = %d ftype = %d n_merges = %d\n",
@@ -883,6 +885,7 @@ int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out) {
     return 0;
 }
 int biogpt_hip_n_tensors(const biogpt_hip_ctx *ctx) { return ctx ? ctx->n_tensors : -1; }
+const biogpt_hip_vocab *biogpt_hip_ctx_vocab(const biogpt_hip_ctx *ctx) { return ctx ? ctx->tok_vocab : nullptr; }
 
 int biogpt_hip_vocab_token(const biogpt_hip_ctx *ctx, int32_t id, const char **bytes, int32_t *len) {
     if (!ctx || id < 0 || (size_t)id >= ctx->vocab.size()) return -1;

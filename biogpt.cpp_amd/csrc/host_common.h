@@ -109,6 +109,10 @@ void set_error(const char *func, const char *fmt, ...) __attribute__((format(pri
 const char *last_error();
 void clear_error();
 
+// tokenizer_capi.cpp: the vocabulary handle a context carries for biogpt_hip_ctx_vocab()
+biogpt_hip_vocab *make_vocab(const std::vector<std::string> &tokens, const std::vector<std::string> &merges);
+void drop_vocab(biogpt_hip_vocab *v);
+
 #define BG_FAIL(ret, ...)                     \
     do {                                      \
         ::bg::set_error(__func__, __VA_ARGS__); \

@@ -15,6 +15,8 @@
  *   + top_k=1 sampler        biogpt.cpp:908-980        loop: argmax + token feedback stay in HBM)
  *   biogpt_model_quantize_internal + quantize CLI     biogpt_hip_quantize_file()
  *                            biogpt.cpp:459-621, quantize.cpp:8-135
+ *   gpt_tokenize             biogpt.cpp:850-875       biogpt_hip_tokenize()         (host-only: Moses word
+ *   gpt_decode               biogpt.cpp:877-906       biogpt_hip_decode()            splitting + byte BPE)
  *   teardown                 main.cpp:164-169         biogpt_hip_free()
  *
  * Plain pointers and sizes only: no C++/torch types cross this boundary.  The C++ wrappers with
@@ -39,6 +41,10 @@ extern "C" {
 #endif
 
 typedef struct biogpt_hip_ctx biogpt_hip_ctx;
+typedef struct biogpt_hip_vocab biogpt_hip_vocab;   /* vocabulary + merge ranks of one model file (host memory) */
+
+/* tokenizer status: the reference's moses_tokenize throws std::length_error for this input (see below) */
+#define BIOGPT_HIP_E_LENGTH (-7)
 
 /* header ints in file order (biogpt.cpp:54-60) + the merge count found in the file */
 typedef struct biogpt_hip_hparams {
@@ -159,6 +165,46 @@ int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int ste
  * side effects beyond the KV row at n_past): average seconds per token over `reps` replays,
  * HIP-event timed on the context's stream. */
 int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out);
+
+/* ---- text <-> ids (host-only, no GPU needed) -------------------------------------
+ * The reference's tokenizer stack -- moses_tokenize (mosestokenizer.cpp:290-358), bpe (bpe.cpp:20-91),
+ * gpt_tokenize / gpt_decode (biogpt.cpp:850-906), moses_detokenize (mosestokenizer.cpp:360-466) --
+ * re-implemented without std::regex, byte-for-byte equal in output including its quirks.
+ *
+ * Vocabulary handles: biogpt_hip_vocab_load() parses only the header, vocab and merges of a model file;
+ * biogpt_hip_ctx_vocab() borrows the one a loaded context already holds (NULL for an attached context).
+ * String results: the function returns the byte length of the result (without the terminating NUL) and
+ * writes it only when cap >= length + 1 -- call again with a larger buffer otherwise.  Lists of words
+ * travel as one '\n'-joined string.  Negative = error; BIOGPT_HIP_E_LENGTH where the reference throws
+ * std::length_error (a period-final word that is neither an abbreviation nor a listed prefix, followed by
+ * a word starting with a byte >= 0x80; mosestokenizer.cpp:264).
+ *
+ * Data files: nonbreaking_prefixes/nonbreaking_prefix.<lang> are read from the data directory
+ * ($BIOGPT_DATA_DIR, else "../data" like mosestokenizer.cpp:11-12; a missing file = empty list, as in
+ * the reference).  The five perluniprops byte classes are built in; <dir>/perluniprops/Is*.txt override
+ * them when present.  lang: "" (what the reference CLI effectively passes), "en", "fr", ... */
+biogpt_hip_vocab       *biogpt_hip_vocab_load(const char *fname);
+/* from arrays: tokens[id] / merges[rank] ("left right" records as stored in the file), explicit byte lengths */
+biogpt_hip_vocab       *biogpt_hip_vocab_create(const char *const *tokens, const int32_t *token_lens, int32_t n_tokens,
+                                                const char *const *merges, const int32_t *merge_lens, int32_t n_merges);
+void                    biogpt_hip_vocab_free(biogpt_hip_vocab *v);
+const biogpt_hip_vocab *biogpt_hip_ctx_vocab(const biogpt_hip_ctx *ctx);
+int biogpt_hip_tokenizer_set_data_dir(const char *dir);
+
+/* gpt_tokenize: ids of `text`, always starting with 2 ("</s>"); pieces missing from the vocabulary are
+ * dropped with a warning on stderr.  Returns the id count; writes min(count, cap) ids. */
+int biogpt_hip_tokenize(const biogpt_hip_vocab *v, const char *text, const char *lang, int32_t *out_ids, int32_t cap);
+/* gpt_decode of the vocabulary strings of `ids` (an id outside the table decodes as empty). */
+int biogpt_hip_decode(const biogpt_hip_vocab *v, const int32_t *ids, int32_t n, const char *lang, char *out, int32_t cap);
+/* gpt_decode on explicit token strings ('\n'-joined) */
+int biogpt_hip_decode_strings(const char *tokens_nl, const char *lang, char *out, int32_t cap);
+
+/* the stages, exposed for parity tests */
+int biogpt_hip_moses_tokenize(const char *text, const char *lang, char *out, int32_t cap);        /* words, '\n'-joined */
+int biogpt_hip_moses_detokenize(const char *tokens_nl, const char *lang, char *out, int32_t cap);
+int biogpt_hip_bpe(const biogpt_hip_vocab *v, const char *word, char *out, int32_t cap);          /* pieces joined by ' ' */
+/* membership table (256 x 0/1) of byte class `which`: 0 IsAlnum, 1 IsAlpha, 2 IsLower, 3 IsN, 4 IsSc */
+int biogpt_hip_tokenizer_byte_class(int which, uint8_t *out256);
 
 /* ---- host-side tools (no GPU needed) --------------------------------------------------------
  * File -> file quantizer, replaces examples/quantize (quantize.cpp:8-135 + biogpt.cpp:459-621):
