@@ -1,11 +1,11 @@
 // Test driver for include/biogpt_compat.h.  It exercises every model-library symbol the reference's CLI
-// uses (biogpt.h:128-169 + the ggml handles of examples/main/main.cpp:47-70,164-169) but with token ids
-// in and out instead of text (the tokenizer is out of scope), and with the prompt phase
+// uses (biogpt.h:128-169 + the ggml handles of examples/main/main.cpp:47-70,164-169), with the prompt phase
 // and the sampling phase as two separate loops.
 //
-//   compat_driver MODEL N_PREDICT TOP_K ID [ID...]          positional form
+//   compat_driver MODEL N_PREDICT TOP_K ID [ID...]          positional form, token ids in
 //   compat_driver --flags <reference-style flags>           -p "2 17 45" is a list of ids
-// prints the sampled ids on one line.
+//   compat_driver --text <reference-style flags>            -p "some text": gpt_tokenize in, gpt_decode out
+// prints the sampled ids on one line; --text also prints "prompt ids: ..." before and "text: ..." after.
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -64,9 +64,10 @@ int main(int argc, char **argv) {
     ggml_time_init();
     biogpt_params prm;
     token_sequence prompt;
-    if (argc >= 2 && std::string(argv[1]) == "--flags") {
+    const bool text_mode = argc >= 2 && std::string(argv[1]) == "--text";
+    if (argc >= 2 && (text_mode || std::string(argv[1]) == "--flags")) {
         if (!biogpt_params_parse(argc - 1, argv + 1, prm)) return 2;
-        prompt = parse_ids(prm.prompt);
+        if (!text_mode) prompt = parse_ids(prm.prompt);
     } else {
         if (argc < 5) return 2;
         prm.model = argv[1];
@@ -80,7 +81,14 @@ int main(int argc, char **argv) {
         fprintf(stderr, "failed to load model from '%s'\n", prm.model.c_str());
         return 1;
     }
+    if (text_mode) {
+        prompt = gpt_tokenize(s.vocab, prm.prompt, prm.lang);
+        printf("prompt ids:");
+        for (size_t i = 0; i < prompt.size(); i++) printf(" %d", prompt[i]);
+        printf("\n");
+    }
     const int budget = std::min(prm.n_predict, s.model.hparams.n_positions - (int)prompt.size());
+    token_sequence sampled;
 
     // phase 1: the prompt, n_batch ids per eval
     for (size_t at = 0; at < prompt.size(); at += (size_t)prm.n_batch) {
@@ -92,9 +100,16 @@ int main(int argc, char **argv) {
     for (int k = 0; k < budget; k++) {
         const biogpt_vocab::id id = biogpt_sample_top_k_top_p(s.vocab, s.logits.data(), prm.top_k, prm.top_p, prm.temp, rng);
         printf("%d ", id);
+        sampled.push_back(id);
         if (k + 1 < budget && !s.feed(token_sequence(1, id), prm.n_threads)) return 1;
     }
     printf("\n");
+    if (text_mode) {
+        std::vector<std::string> words;
+        for (size_t i = 0; i < prompt.size(); i++) words.push_back(s.vocab.id_to_token[prompt[i]]);
+        for (size_t i = 0; i < sampled.size(); i++) words.push_back(s.vocab.id_to_token[sampled[i]]);
+        printf("text: %s\n", gpt_decode(words, prm.lang).c_str());
+    }
     fprintf(stderr, "vocab %zu tokens, %zu merges, n_loaded %d, %lld us\n", s.vocab.id_to_token.size(), s.vocab.bpe_ranks.size(),
             s.model.n_loaded, (long long)ggml_time_us());
     s.close();

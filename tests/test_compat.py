@@ -73,3 +73,74 @@ def test_sampler_top_k_top_p_is_seeded_and_bounded(pkg, tiny_models, tmp_path):
     assert a.returncode == 0 and a.stdout == b.stdout          # mt19937(7): reproducible
     ids = [int(t) for t in a.stdout.split()]
     assert len(ids) == 16 and all(0 <= t < 320 for t in ids)
+
+
+# ---- text in, text out: tokenizer + engine + sampler through the reference-shaped API -------------------------
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOK_DATA = os.path.join(GOLD, "tokenizer_data")
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "biogpt_ref_cli")
+PROMPT = "The patient was treated with metformin. Dr. Hale reported no adverse events"
+
+
+def _text_model(pkg, tmp_path, ftype="q8_0"):
+    """A seeded tiny model carrying the tokenizer fixture's vocabulary and merge table."""
+    import modelfile_py
+    _, vocab, merges, _ = modelfile_py.read_model(os.path.join(GOLD, "tokenizer_vocab.bin"))
+    raw = str(tmp_path / "raw.bin")
+    pkg.write_synthetic(raw, n_vocab=len(vocab), n_layer=2, n_head=4, n_positions=96, d_ff=256, d_model=64, n_merges=3)
+    hp, _, _, tensors = modelfile_py.read_model(raw)
+    f32 = str(tmp_path / "text_f32.bin")
+    modelfile_py.write_model(f32, hp, vocab, merges, tensors)
+    out = str(tmp_path / ("text_%s.bin" % ftype))
+    pkg.quantize_file(f32, out, ftype)
+    return out, vocab
+
+
+def _expected_text_run(pkg, oracle, model, vocab_strings, n_predict, n_batch):
+    pkg.set_tokenizer_data_dir(TOK_DATA)
+    v = pkg.Vocab.load(model)
+    ids = v.tokenize(PROMPT, "")
+    gen, _ = oracle.OracleModel(model, n_threads=2).generate_greedy(ids, n_predict, n_batch=n_batch)
+    return v, ids, [int(t) for t in gen]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="reference sources only exist in the build container")
+def test_reference_cli_links_against_the_engine(pkg):
+    """examples/main/main.cpp, unmodified, + include/compat + libbiogpt_hip.so = a complete program (every symbol it
+    needs, tokenizer included, is exported); without a model it fails the way the reference does."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_cli"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([REF_CLI, "-m", "/nonexistent/model.bin", "-p", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to load model from '/nonexistent/model.bin'" in r.stderr
+
+
+@pytest.mark.gpu
+def test_driver_text_in_text_out(pkg, oracle, tmp_path):
+    exe = _build_driver(pkg, tmp_path)
+    model, vocab = _text_model(pkg, tmp_path)
+    v, ids, gen = _expected_text_run(pkg, oracle, model, vocab, 20, 8)
+    assert len(ids) > 12
+    r = subprocess.run([exe, "--text", "-m", model, "-n", "20", "--top_k", "1", "-b", "8", "-p", PROMPT], capture_output=True,
+                       env=dict(os.environ, BIOGPT_DATA_DIR=TOK_DATA))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split(b"\n")
+    assert lines[0] == b"prompt ids: " + " ".join(str(i) for i in ids).encode()
+    assert [int(t) for t in lines[1].split()] == gen
+    assert lines[2] == b"text: " + v.decode(ids + gen, "")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/biogpt_ref_cli is built from the reference's main.cpp in the build container")
+def test_reference_cli_end_to_end_on_the_engine(pkg, oracle, tmp_path):
+    """The reference's own CLI program (its main.cpp compiled against include/compat, oracle/Makefile ref_cli)
+    running on the MI355X engine: prompt text in, generated text out, equal to tokenizer + oracle + decode."""
+    model, vocab = _text_model(pkg, tmp_path, "q4_0")
+    v, ids, gen = _expected_text_run(pkg, oracle, model, vocab, 16, 8)
+    r = subprocess.run([REF_CLI, "-m", model, "-n", "16", "--top_k", "1", "-b", "8", "-s", "3", "-p", PROMPT], capture_output=True,
+                       env=dict(os.environ, BIOGPT_DATA_DIR=TOK_DATA))
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert ("number of tokens in prompt = %d, first 8 tokens: %s \n" % (len(ids), " ".join(str(i) for i in ids[:8]))).encode() in out
+    # main.cpp:139-145 prints one decoded chunk + ' ' per loop iteration: prompt chunks of n_batch ids, then one id at a time
+    chunks = [ids[i:i + 8] for i in range(0, len(ids), 8)] + [[g] for g in gen]
+    body = b"".join(v.decode(c, "") + b" " for c in chunks)
+    assert body in out, (body, out)
