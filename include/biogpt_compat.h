@@ -19,8 +19,8 @@
  * Types keep the reference's member names (biogpt.h:25-107) because callers read them
  * (main.cpp:57-58,82,115,142,148,164-169); tensor handles exist for source compatibility only and
  * stay null -- weights live in the engine's device arena.
- * Tokenizer entry points (gpt_tokenize / gpt_decode) are declared for source compatibility but are
- * outside this round's scope.
+ *   gpt_tokenize / gpt_decode  biogpt.h:153-161 -> biogpt_hip_tokenize() / biogpt_hip_decode_strings()
+ *                                              (csrc/tokenizer.cpp; same output bytes, same std::length_error)
  */
 #pragma once
 
@@ -136,6 +136,6 @@ biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const floa
 bool biogpt_params_parse(int argc, char **argv, biogpt_params &params);
 void biogpt_print_usage(char **argv, const biogpt_params &params);
 
-/* out of scope this round: declared so that callers compile */
+/* text <-> ids (biogpt.cpp:850-906); prefix lists come from $BIOGPT_DATA_DIR or ../data, like the reference */
 token_sequence gpt_tokenize(biogpt_vocab &vocab, const std::string &text, const std::string &lang);
 std::string gpt_decode(std::vector<std::string> &tokens, const std::string &lang);
