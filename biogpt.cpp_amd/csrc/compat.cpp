@@ -1,6 +1,8 @@
 // C++ wrappers with the reference's signatures (include/biogpt_compat.h) over the C-ABI, plus the
 // shims for the 11 ggml symbols examples/main/main.cpp calls directly.
 #include "../../include/biogpt_compat.h"
+#include "host_common.h"
+#include "quant_host.h"
 
 #include <algorithm>
 #include <chrono>
@@ -68,6 +70,70 @@ bool biogpt_model_load(const std::string &fname, biogpt_model &model, biogpt_voc
         vocab.bpe_ranks[last_pair] = r;
     }
     return true;
+}
+
+// ---- tensor-section quantizer on open streams (biogpt.cpp:459-621) -----------------------------------
+// examples/quantize/quantize.cpp copies the header, vocab and merges itself and hands the two streams over
+// for the tensors.  Same selection rule (name contains "weight" and ne[1] != 1), same records, same
+// progress lines; payload bytes come from the block encoders of quant_host.cpp (byte-identical to the oracle).
+void biogpt_model_quantize_internal(std::ifstream &fin, std::ofstream &fout, const ggml_ftype ftype) {
+    const bg::TensorType target = bg::ftype_to_type((int32_t)ftype);
+    if (target == bg::T_INVALID || target == bg::T_F32 || target == bg::T_F16) {
+        fprintf(stderr, "%s: invalid model type %d\n", __func__, (int)ftype);
+        throw std::runtime_error("invalid model type");
+    }
+    auto get32 = [&fin]() { int32_t v = 0; fin.read(reinterpret_cast<char *>(&v), 4); return v; };
+    auto put32 = [&fout](int32_t v) { fout.write(reinterpret_cast<const char *>(&v), 4); };
+    const double MB = 1024.0 * 1024.0;
+    size_t bytes_as_f32 = 0, bytes_out = 0;
+    std::vector<char> raw;
+    std::vector<float> values;
+    std::vector<uint8_t> blocks;
+    for (;;) {
+        const int32_t n_dims = get32(), name_len = get32();
+        int32_t ttype = get32();
+        if (fin.eof()) break;
+        int32_t ne[2] = {1, 1}, count = 1;
+        for (int d = 0; d < n_dims; d++) { ne[d] = get32(); count *= ne[d]; }
+        std::string name((size_t)name_len, '\0');
+        fin.read(&name[0], name_len);
+        printf("%64s - [%5d, %5d], type = %6s ", name.c_str(), ne[0], ne[1], bg::type_name(ttype));
+
+        const bool pick = name.find("weight") != std::string::npos && ne[1] != 1;
+        if (pick) {
+            if (ttype != bg::T_F32 && ttype != bg::T_F16) throw std::runtime_error("unsupported ttype for integer quantization");
+            values.resize((size_t)count);
+            if (ttype == bg::T_F16) {
+                raw.resize((size_t)count * 2);
+                fin.read(raw.data(), (std::streamsize)raw.size());
+                const uint16_t *h = reinterpret_cast<const uint16_t *>(raw.data());
+                for (int32_t i = 0; i < count; i++) values[(size_t)i] = bg::f16_to_f32(h[i]);
+            } else {
+                fin.read(reinterpret_cast<char *>(values.data()), (std::streamsize)count * 4);
+            }
+            ttype = target;
+        } else {
+            raw.resize((size_t)count * (ttype == bg::T_F32 ? 4 : 2));
+            fin.read(raw.data(), (std::streamsize)raw.size());
+        }
+        put32(n_dims); put32(name_len); put32(ttype);
+        for (int d = 0; d < n_dims; d++) put32(ne[d]);
+        fout.write(name.data(), name_len);
+        if (pick) {
+            blocks.resize(bg::file_row_bytes(target, ne[0]) * (size_t)ne[1]);
+            const size_t n = bg::quantize_rows(target, values.data(), ne[1], ne[0], blocks.data());
+            fout.write(reinterpret_cast<const char *>(blocks.data()), (std::streamsize)n);
+            bytes_out += n;
+            printf("size = %8.2f MB -> %8.2f MB\n", count * 4.0 / MB, n / MB);
+        } else {
+            fout.write(raw.data(), (std::streamsize)raw.size());
+            bytes_out += raw.size();
+            printf("size = %8.3f MB\n", raw.size() / MB);
+        }
+        bytes_as_f32 += (size_t)count * 4;
+    }
+    printf("%s: model size  = %8.2f MB\n", __func__, bytes_as_f32 / MB);
+    printf("%s: quant size  = %8.2f MB | ftype = %d (%s)\n", __func__, bytes_out / MB, (int)ftype, bg::type_name(target));
 }
 
 // ---- tokenizer (biogpt.cpp:850-906) over the C-ABI ---------------------------------------------------

@@ -63,6 +63,10 @@ void    ggml_backend_free(ggml_backend_t backend);
 
 #define BIOGPT_FILE_MAGIC 0x67676d6c /* 'ggml' */
 
+/* raw little-endian field I/O used by examples/quantize/quantize.cpp (biogpt.h:15-23) */
+template <typename T> static inline void read_safe(std::ifstream &in, T &field) { in.read(reinterpret_cast<char *>(&field), sizeof(T)); }
+template <typename T> static inline void write_safe(std::ofstream &out, T &field) { out.write(reinterpret_cast<const char *>(&field), sizeof(T)); }
+
 typedef std::pair<std::string, std::string> word_pair; /* bpe.h */
 
 struct biogpt_hparams { /* biogpt.h:25-35 */
@@ -128,7 +132,8 @@ struct ggml_cgraph *biogpt_graph(const biogpt_model &model, struct ggml_allocr *
 bool biogpt_eval(const biogpt_model &model, const token_sequence &embed_inp, std::vector<float> &logits,
                  struct ggml_allocr *allocr, const int n_past, const int n_threads);
 
-void biogpt_model_quantize_internal(std::ifstream &fin, std::ofstream &fout, const ggml_ftype ftype); /* use biogpt_hip_quantize_file */
+/* tensor section of a model file, stream to stream (biogpt.cpp:459-621); whole-file form: biogpt_hip_quantize_file() */
+void biogpt_model_quantize_internal(std::ifstream &fin, std::ofstream &fout, const ggml_ftype ftype);
 
 biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
                                            double temp, std::mt19937 &rng);

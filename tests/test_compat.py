@@ -144,3 +144,29 @@ def test_reference_cli_end_to_end_on_the_engine(pkg, oracle, tmp_path):
     chunks = [ids[i:i + 8] for i in range(0, len(ids), 8)] + [[g] for g in gen]
     body = b"".join(v.decode(c, "") + b" " for c in chunks)
     assert body in out, (body, out)
+
+
+REF_QUANTIZE = os.path.join(ROOT, "oracle", "_ref", "quantize_ref_cli")
+
+
+@pytest.mark.skipif(not (os.path.exists("/root/reference/examples/quantize/quantize.cpp") or os.path.exists(REF_QUANTIZE)),
+                    reason="needs the reference's quantize.cpp (build container) or the binary built from it")
+@pytest.mark.parametrize("name,ftype", [("q4_0", 2), ("q4_1", 3), ("q8_0", 7), ("q5_0", 8), ("q5_1", 9)])
+def test_reference_quantize_cli_on_our_library(pkg, oracle, tmp_path, name, ftype):
+    """examples/quantize/quantize.cpp, unmodified, against include/compat + our biogpt_model_quantize_internal:
+    output file byte-identical to the oracle's quantizer; F16 input too; progress lines as the reference prints."""
+    if os.path.exists("/root/reference/examples/quantize/quantize.cpp"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_quantize"], stdout=subprocess.DEVNULL)
+    for src_type in (0, 1):
+        src = str(tmp_path / ("src%d.bin" % src_type))
+        pkg.write_synthetic(src, ftype=src_type, n_vocab=96, n_layer=2, n_head=2, n_positions=32, d_ff=128, d_model=64)  # 40000 merges: the CLI insists (F6)
+        out, want = str(tmp_path / "cli.bin"), str(tmp_path / "oracle.bin")
+        r = subprocess.run([REF_QUANTIZE, "-f", src, "-o", out, "-t", str(ftype)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.rstrip().endswith("Done."), r.stderr
+        oracle.quantize_file(src, want, ftype)
+        with open(out, "rb") as a, open(want, "rb") as b:
+            assert a.read() == b.read()
+        assert "biogpt.embed_tokens.weight - [   64,    96], type =    %s size =     0.02 MB ->" % ("f32" if src_type == 0 else "f16") in r.stdout
+        assert "ftype = %d (%s)" % (ftype, name) in r.stdout
+    r = subprocess.run([REF_QUANTIZE, "-f", src, "-o", out, "-t", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid model type 1" in r.stderr        # uncaught std::runtime_error, like the reference
