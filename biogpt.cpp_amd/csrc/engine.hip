@@ -182,6 +182,8 @@ struct biogpt_hip_ctx {
     float *logits_all = nullptr;  // lazily [n][n_vocab]
     size_t logits_all_rows = 0;
     float *pmax_val = nullptr;
+    float *sp_scores = nullptr, *sp_max = nullptr;   // key-split decode attention scratch (kernels_fast.hip.h)
+    double *sp_pv = nullptr;
     int32_t *pmax_idx = nullptr;
     int pmax_cap = 0;
     bgk::DevState *state = nullptr;  // device
@@ -484,7 +486,15 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                 // loads are bounded by t_cap (= P when the table is not a multiple of 64; the workgroup stays whole
                 // waves); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);
-                if (a.t_cap <= 256) {
+                static const int split_min = env_int("BIOGPT_HIP_SPLIT_MIN", 256);
+                if (N == 1 && !batch && a.t_cap > split_min) {
+                    // long context, one query: spread the head's keys over the chip (three dependent launches)
+                    a.sp_scores = c->sp_scores; a.sp_max = c->sp_max; a.sp_pv = c->sp_pv;
+                    a.n_split = (a.t_cap + bgk::SPLIT_KEYS - 1) / bgk::SPLIT_KEYS;
+                    hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
+                    hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
+                    hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(H), dim3(64), 0, st, a);
+                } else if (a.t_cap <= 256) {
                     hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(H, N), dim3(4 * ((a.t_cap + 63) & ~63)), 0, st, a);
                 } else if (a.t_cap <= 512) {
                     hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(H, N), dim3(1024), 0, st, a);
@@ -631,6 +641,9 @@ bool alloc_runtime(biogpt_hip_ctx *c) {
     }
     c->pmax_cap = 4096;
     HIP_TRY(false, hipMalloc(&c->pmax_val, (size_t)c->pmax_cap * 4));
+    HIP_TRY(false, hipMalloc(&c->sp_scores, (size_t)hp.n_head * hp.n_positions * 4));
+    HIP_TRY(false, hipMalloc(&c->sp_max, (size_t)hp.n_head * bgk::SPLIT_MAX * 4));
+    HIP_TRY(false, hipMalloc(&c->sp_pv, (size_t)hp.n_head * bgk::SPLIT_MAX * 64 * 8));
     HIP_TRY(false, hipMalloc(&c->pmax_idx, (size_t)c->pmax_cap * 4));
     c->state_bytes = sizeof(bgk::DevState) + 2 * P * 4;
     HIP_TRY(false, hipMalloc(&c->state, c->state_bytes));
@@ -748,7 +761,7 @@ void destroy(biogpt_hip_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->owns_arena && c->arena) (void)hipFree(c->arena);
     for (void *p : {(void *)c->memory_k, (void *)c->memory_v, (void *)c->x, (void *)c->x1, (void *)c->q, (void *)c->att,
-                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->state})
+                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->sp_scores, (void *)c->sp_max, (void *)c->sp_pv, (void *)c->state})
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     delete c;

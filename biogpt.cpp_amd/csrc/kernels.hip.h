@@ -659,6 +659,7 @@ struct AttnParams {
     int32_t q81;                  // 1: Q8_1 activation form (Q4_1 / Q5_1 weights), 0: Q8_0
     const SeqState *seq;          // batched decode: query row i belongs to sequence i (own cache + position)
     int64_t kv_seq_stride;
+    float *sp_scores; float *sp_max; double *sp_pv; int32_t n_split;   // key-split decode attention scratch: [H][P], [H][16], [H][16][64]
     unsigned long long *tstamp;  // profiling (dbg & 32): [16 waves][8] stamps of block (0,0)
     int32_t dbg;
 };

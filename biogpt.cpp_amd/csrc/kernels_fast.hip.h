@@ -383,6 +383,31 @@ __device__ __forceinline__ float inv_sum_f32(double s) {
     return (float)r;
 }
 
+// One head's 64 outputs, held one per lane by wave 0: F32 row for the reference layout and, for the fast
+// out_proj, the two Q8 blocks of its activation row (amax / roundf / block sum as quantize_row_q8_0/_1).
+__device__ __forceinline__ void store_head_output(const AttnParams &p, int i, int h, int tid, float o, bool q8) {
+    constexpr int DK = 64;
+    p.out[(size_t)i * p.D + (size_t)h * DK + tid] = o;
+    if (!q8) return;
+    float amax = fabsf(o);
+    amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
+    amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
+    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+    const float dq = amax / 127.0f;
+    const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
+    const int q = (int)roundf(__fmul_rn(o, id));
+    int isum = q;
+    isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
+    isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
+    isum += __shfl_xor(isum, 16, 64);
+    const size_t blk = (size_t)i * (p.D / 32) + h * 2 + (tid >> 5);   // [N][d_model/32]
+    p.oq_q[blk * 32 + (tid & 31)] = (int8_t)q;
+    if ((tid & 31) == 0) {
+        if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
+        else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
+    }
+}
+
 template <int KP, bool VPRE>
 __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
     constexpr int DK = 64;
@@ -520,31 +545,128 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         double t0 = 0.0, t1 = 0.0;
         for (int s2 = 0; s2 + 1 < nsl; s2 += 2) { t0 += pv[s2 * DK + tid]; t1 += pv[(s2 + 1) * DK + tid]; }
         if (nsl & 1) t0 += pv[(nsl - 1) * DK + tid];
-        const float o = (float)(t0 + t1);
-        p.out[(size_t)i * D + (size_t)h * DK + tid] = o;
-        if (p.oq_q != nullptr && !AT_DBG(16)) {
-            // wave 0 holds the head's 64 outputs = two Q8 blocks of out_proj's activation row
-            float amax = fabsf(o);
-            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
-            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
-            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-            const float dq = amax / 127.0f;
-            const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
-            const int q = (int)roundf(__fmul_rn(o, id));
-            int isum = q;
-            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
-            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
-            isum += __shfl_xor(isum, 16, 64);
-            const size_t blk = (size_t)i * (D / 32) + h * 2 + (tid >> 5);   // [N][d_model/32]
-            p.oq_q[blk * 32 + (tid & 31)] = (int8_t)q;
-            if ((tid & 31) == 0) {
-                if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
-                else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
-            }
-        }
+        store_head_output(p, i, h, tid, (float)(t0 + t1), p.oq_q != nullptr && !AT_DBG(16));
     }
 #undef AT_STAMP
 #undef AT_DBG
+}
+
+// ---- single-token attention over a long context, split over the keys -----------------------------------
+// attn_fast_kernel puts a head on ONE compute unit: at 1024 keys that is 512 KB of K/V through one CU per
+// layer (21 us measured) while 240 CUs idle.  Here a head's keys are cut into ranges of 64 and spread over
+// the chip; the softmax of ggml_soft_max needs the global maximum before the table lookup and the global sum
+// before the PV products (p_j = fl(e_j * (float)(1/sum)) is rounded BEFORE it multiplies V), so the work
+// falls into three dependent launches:
+//   scores  (H x S workgroups)  S_j = K_j . q  -> scratch, per-range maximum
+//   pv      (H x S workgroups)  global max from the S maxima; e_j for ALL keys of the head (4 lookups per
+//                               lane, every workgroup computes the same double sum in the same order);
+//                               partial  sum_j V_jd * p_j  over its own 64 keys, in double
+//   combine (H workgroups)      partials added in range order, F32 store + Q8 hand-off for out_proj
+// Arithmetic per element is that of attn_fast_kernel; only the (double) association of the sums differs.
+constexpr int SPLIT_KEYS = 64;    // keys per workgroup
+constexpr int SPLIT_MAX = 16;     // ranges per head (contexts up to 1024 keys)
+
+__global__ __launch_bounds__(256) void attn_split_scores_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    __shared__ float redf[4];
+    const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const int ksub = tid & 3, j = s * SPLIT_KEYS + (tid >> 2);
+    const float4 *krow = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + (size_t)j * (DK / 4) + ksub;
+    const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)h * DK) + ksub;
+    const int n_past = p.st->n_past;
+    float4 kr[4], qv[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) kr[m] = (j < p.t_cap) ? krow[4 * m] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < 4; m++) qv[m] = qp[4 * m];
+    const int T = n_past + 1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        a0 += (double)__fmul_rn(kr[m].x, qv[m].x); a1 += (double)__fmul_rn(kr[m].y, qv[m].y);
+        a2 += (double)__fmul_rn(kr[m].z, qv[m].z); a3 += (double)__fmul_rn(kr[m].w, qv[m].w);
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    acc += dpp_d<DPP_QUAD_XOR1>(acc);
+    acc += dpp_d<DPP_QUAD_XOR2>(acc);
+    const float sc = (j < T) ? (float)acc : -INFINITY;
+    if (ksub == 0 && j < p.t_cap) p.sp_scores[(size_t)h * p.P + j] = sc;
+    const float mx = wave_max_f32(sc);
+    if ((tid & 63) == 0) redf[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) p.sp_max[h * SPLIT_MAX + s] = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+}
+
+__global__ __launch_bounds__(256) void attn_split_pv_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    __shared__ float e_own[SPLIT_KEYS];
+    __shared__ double red[4];
+    __shared__ double pv[256];
+    const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const int t0 = s * SPLIT_KEYS, d = tid & 63, sl = tid >> 6;
+    const float *__restrict__ vbase = p.vcache + (size_t)h * p.P * DK + d;
+    float vr[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int j = t0 + sl + 4 * k;
+        vr[k] = (j < p.t_cap) ? vbase[(size_t)j * DK] : 0.0f;
+    }
+    float scv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = tid + 256 * k;
+        scv[k] = (j < p.t_cap) ? p.sp_scores[(size_t)h * p.P + j] : -INFINITY;
+    }
+    // the S range maxima: one per lane of every wave (a loop of dependent scalar loads would serialise)
+    float mx = ((tid & 63) < p.n_split) ? p.sp_max[h * SPLIT_MAX + (tid & 63)] : -INFINITY;
+    const int T = p.st->n_past + 1;
+    if (t0 >= T) return;                      // a range past the context contributes nothing (combine skips it)
+    mx = wave_max_f32(mx);
+    float ev[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ev[k] = (tid + 256 * k < T) ? h2f(p.exp_tab[f2h(__fsub_rn(scv[k], mx))]) : 0.0f;
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = tid + 256 * k;
+        if (j < T) {
+            sum += (double)ev[k];
+            if (j >= t0 && j < t0 + SPLIT_KEYS) e_own[j - t0] = ev[k];
+        }
+    }
+    sum = wave_sum_f64(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = inv_sum_f32(sum);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const int j0 = sl + 4 * k, j1 = j0 + 4;
+        if (t0 + j0 < T) a0 += (double)__fmul_rn(vr[k], __fmul_rn(e_own[j0], inv));
+        if (t0 + j1 < T) a1 += (double)__fmul_rn(vr[k + 1], __fmul_rn(e_own[j1], inv));
+    }
+    pv[tid] = a0 + a1;
+    __syncthreads();
+    if (tid < DK) p.sp_pv[(size_t)(h * SPLIT_MAX + s) * DK + tid] = (pv[tid] + pv[64 + tid]) + (pv[128 + tid] + pv[192 + tid]);
+}
+
+__global__ __launch_bounds__(64) void attn_split_combine_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int T = p.st->n_past + 1;
+    const int ns = (T + SPLIT_KEYS - 1) / SPLIT_KEYS;
+    const double *part = p.sp_pv + (size_t)h * SPLIT_MAX * DK + tid;
+    double pr[SPLIT_MAX];                     // all loads in flight at once; ranges past the context hold stale values
+#pragma unroll
+    for (int s = 0; s < SPLIT_MAX; s++) pr[s] = part[s * DK];
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < SPLIT_MAX; s += 2) {
+        if (s < ns) t0 += pr[s];
+        if (s + 1 < ns) t1 += pr[s + 1];
+    }
+    store_head_output(p, 0, h, tid, (float)(t0 + t1), p.oq_q != nullptr);
 }
 
 // ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
