@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch ships its own HIP runtime: load it BEFORE libbiogpt_hip.so pulls in /opt/rocm's copy, otherwise a test
+    import torch  # noqa: F401  (that touches torch.cuda late in the process finds "No HIP GPUs")
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
