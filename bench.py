@@ -154,8 +154,11 @@ def main():
             # no intra-chunk mask (F1); logits stay on the device
             rng = np.random.default_rng(7000 + unit)
             toks = [2] + [int(v) for v in rng.integers(4, hp.n_vocab, n_prompt - 1)]
-            for n_past in range(0, n_prompt, 8):
-                model.eval_device(toks[n_past:n_past + 8], n_past)
+            if os.environ.get("BIOGPT_BENCH_CHUNK_CALLS"):      # one library call per reference chunk (the biogpt_eval loop)
+                for n_past in range(0, n_prompt, 8):
+                    model.eval_device(toks[n_past:n_past + 8], n_past)
+            else:                                                # same result, several chunks per pass (biogpt_hip_eval_prompt)
+                model.eval_prompt(toks, 0, 8, want_logits=False)
             model.synchronize()
             return None, 0.0
         ids, secs = model.generate_greedy(make_prompt(hp.n_vocab, unit), n_predict, n_batch=8)

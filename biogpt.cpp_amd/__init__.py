@@ -76,6 +76,7 @@ SYMBOLS = [
     ("biogpt_hip_logits_device", _P, [_P]),
     ("biogpt_hip_synchronize", C.c_int, [_P]),
     ("biogpt_hip_eval_all", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("biogpt_hip_eval_prompt", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_generate_greedy", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_generate_greedy_batch", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
@@ -288,6 +289,16 @@ class BiogptModel:
         toks = np.ascontiguousarray(tokens, dtype=np.int32)
         out = np.empty((toks.size, self.n_vocab), dtype=np.float32)
         if lib().biogpt_hip_eval_all(self._h, toks.ctypes.data, toks.size, int(n_past), out.ctypes.data) != 0:
+            raise BiogptError(_err())
+        return out
+
+    def eval_prompt(self, tokens, n_past=0, n_batch=8, want_logits=True):
+        """== eval() on consecutive chunks of n_batch tokens (main.cpp prompt loop), several chunks per pass.
+        Returns the last token's logits, or None (asynchronous) with want_logits=False."""
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.n_vocab, dtype=np.float32) if want_logits else None
+        if lib().biogpt_hip_eval_prompt(self._h, toks.ctypes.data, toks.size, int(n_past), int(n_batch),
+                                        out.ctypes.data if want_logits else None) != 0:
             raise BiogptError(_err())
         return out
 

@@ -50,9 +50,19 @@ struct DevState {
     int32_t n_past;   // tokens already in the KV cache
     int32_t n_gen;    // number of ids written to gen_ids by argmax_kernel
     int32_t causal;   // 0: reference behaviour (no intra-chunk mask, F1); 1: opt-in causal mask
-    int32_t pad;
+    int32_t chunk;    // > 0: the N columns are consecutive reference chunks of this many tokens evaluated in one
+                      // pass: column i sees the keys up to the end of ITS chunk (what n_batch-sized evals would show it)
     // followed in memory by: int32 tokens[n_positions]; int32 gen_ids[n_positions]
 };
+// keys visible to query column i of an N-column pass (biogpt.cpp:729-764 has no mask inside one eval, F1)
+__device__ __forceinline__ int visible_keys(const DevState *st, int i, int N) {
+    const int n_past = st->n_past;
+    if (st->causal) return n_past + i + 1;
+    const int nb = st->chunk;
+    if (nb <= 0) return n_past + N;
+    const int end = (i / nb + 1) * nb;
+    return n_past + (end < N ? end : N);
+}
 __device__ __forceinline__ const int32_t *state_tokens(const DevState *st) { return reinterpret_cast<const int32_t *>(st + 1); }
 __device__ __forceinline__ int32_t *state_tokens(DevState *st) { return reinterpret_cast<int32_t *>(st + 1); }
 
@@ -673,9 +683,7 @@ constexpr int ATTN_MAXK = 4;  // keys per thread held in registers: T <= ATTN_MA
 __global__ __launch_bounds__(1024) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int h = blockIdx.x, i = blockIdx.y;
-    const int n_past = p.st->n_past;
-    int T = n_past + p.N;
-    if (p.st->causal) T = n_past + i + 1;
+    const int T = visible_keys(p.st, i, p.N);
     const int dk = p.dk, D = p.D;
     const int tid = threadIdx.x, nt = blockDim.x;
 

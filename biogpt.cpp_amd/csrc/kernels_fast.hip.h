@@ -445,7 +445,6 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
     // ---- entry: all loads ----
     const int n_past = p.seq ? p.seq[i].n_past : p.st->n_past;
-    const int causal = p.seq ? 0 : p.st->causal;
     float4 kr[KP][4];
 #pragma unroll
     for (int ps = 0; ps < KP; ps++) {
@@ -467,7 +466,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         }
     }
     AT_STAMP(1);
-    const int T = p.seq ? n_past + 1 : (causal ? n_past + i + 1 : n_past + p.N);
+    const int T = p.seq ? n_past + 1 : visible_keys(p.st, i, p.N);
 
     // ---- scores: 16 dims per lane, quad reduce ----
     float sc[KP];
@@ -691,7 +690,6 @@ __global__ __launch_bounds__(1024) void attn_mfma_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = p.D, N = p.N;
     const int n_past = p.st->n_past;
-    const int causal = p.st->causal;
     const int T = n_past + N;
     const int T16 = (T + 15) & ~15;
     const int TP = p.P + 2;                       // LDS row pitch (floats): pitch % 32 == 2 -> conflict-free A reads in PV
@@ -734,7 +732,7 @@ __global__ __launch_bounds__(1024) void attn_mfma_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int j = jt + 4 * lk + r;
-                const int tlim = causal ? n_past + li + 1 : T;
+                const int tlim = visible_keys(p.st, li, N);
                 S[li * TP + j] = (j < tlim) ? acc[r] : -INFINITY;
             }
         }

@@ -121,6 +121,14 @@ int          biogpt_hip_synchronize(biogpt_hip_ctx *ctx);
 int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
                         float *logits_out);
 
+/* Prompt ingestion: the result of calling biogpt_hip_eval() on consecutive chunks of n_batch tokens
+ * (main.cpp:129-137 with -b n_batch) -- same KV rows, same logits for the last token, bit for bit -- but several
+ * chunks travel through the layers per pass (column i only attends to the keys its own chunk would have seen),
+ * so the weights are streamed once per pass of up to 128 tokens (BIOGPT_HIP_PROMPT_COLS) instead of once per n_batch.  logits_out may be NULL: the call
+ * is then asynchronous (biogpt_hip_logits_device() / biogpt_hip_synchronize()). */
+int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t n_batch,
+                           float *logits_out);
+
 /* Greedy generation harness = main.cpp:91-151 with --top_k 1: prompt fed in chunks of n_batch,
  * then n_predict (clamped to n_positions - n_prompt, main.cpp:82) tokens are sampled by arg-max
  * (lowest id wins ties) and fed back, all inside HBM (one captured hipGraph replay per token).

@@ -230,3 +230,28 @@ def test_odd_shapes(pkg, oracle, tmp_path_factory, shape, name):
     assert len(ids) == P - 4
     assert worst <= ATOL and list(ids) == list(ref), worst
     g.close()
+
+
+@pytest.mark.parametrize("cols", [32, 128, 512])
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0", "f32"])
+def test_prompt_pass_full_shape(pkg, oracle, files, monkeypatch, name, cols):
+    """BioGPT-base widths (specialised chain / generic float kernels): a 203-token prompt through
+    biogpt_hip_eval_prompt (-b 8: 26 reference chunks, `cols` columns per pass) against the oracle fed chunk by chunk."""
+    monkeypatch.setenv("BIOGPT_HIP_PROMPT_COLS", str(cols))     # 7 passes, 2 passes, the whole prompt in one pass
+    path = files[name]
+    g = pkg.BiogptModel.load(path)
+    o = oracle.OracleModel(path, n_threads=16)
+    rng = np.random.default_rng(5)
+    hp = g.hparams
+    toks = [2] + [int(v) for v in rng.integers(4, hp.n_vocab, 202)]
+    lo = None
+    for at in range(0, len(toks), 8):
+        lo = o.eval(toks[at:at + 8], at)
+    lg = g.eval_prompt(toks, 0, 8)
+    d = float(np.abs(lg - lo).max())
+    print("%s prompt pass: worst |diff| %.2e" % (name, d))
+    assert d <= ATOL and int(lg.argmax()) == int(lo.argmax())
+    ids, _ = g.generate_greedy(toks, 6, n_batch=8)          # the device loop ingests the prompt the same way
+    ref, _ = oracle.OracleModel(path, n_threads=16).generate_greedy(toks, 6, n_batch=8)
+    assert list(ids) == list(ref)
+    g.close()

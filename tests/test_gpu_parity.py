@@ -171,3 +171,43 @@ def test_external_arena_and_attach(pkg, oracle, tiny_models):
     for g in (g0, g1, g2):
         _check(g.eval(PROMPT[:6], 0), ref, "arena variant")
         g.close()
+
+
+LONG_PROMPT = [2] + [(37 * i + 11) % 316 + 4 for i in range(52)]     # 53 tokens (tiny n_positions = 64)
+
+
+@pytest.fixture(params=[16, 128])
+def prompt_cols(request, monkeypatch):
+    """columns per pass of the prompt path: several passes (16) and the whole 53-token prompt in one (128, the default)"""
+    monkeypatch.setenv("BIOGPT_HIP_PROMPT_COLS", str(request.param))
+    return request.param
+
+
+@pytest.mark.parametrize("name", ALL_TYPES)
+@pytest.mark.parametrize("n_batch", [8, 3, 13])
+def test_prompt_pass_equals_chunk_by_chunk_evals(loaded, pkg, tiny_models, prompt_cols, name, n_batch):
+    """biogpt_hip_eval_prompt: several reference chunks per pass through the layers, each column limited to the keys
+    its own n_batch-chunk would have seen -> the same logits, the same KV rows and the same continuation as
+    the reference's chunk-by-chunk prompt loop (oracle), for chunk sizes that do and do not divide the pass."""
+    g, o = loaded(name)
+    n_past, lo = 0, None
+    while n_past < len(LONG_PROMPT):
+        c = LONG_PROMPT[n_past:n_past + n_batch]
+        lo = o.eval(c, n_past)
+        n_past += len(c)
+    lg = g.eval_prompt(LONG_PROMPT, 0, n_batch)
+    d = _check(lg, lo, "%s prompt pass, n_batch %d" % (name, n_batch))
+    L, P, D = o.n_layer, o.n_positions, o.d_model
+    for which in (0, 1):
+        kv = g.read_kv(which, 0, L * P * D).reshape(L, P, D)
+        assert np.abs(kv[:, :len(LONG_PROMPT)] - o.kv(which)[:, :len(LONG_PROMPT)]).max() <= 1e-4
+    nxt = int(lg.argmax())
+    _check(g.eval([nxt], len(LONG_PROMPT)), o.eval([nxt], len(LONG_PROMPT)), "%s decode after the prompt pass" % name)
+    # continuing a prompt at n_past > 0 (second half as its own call) gives the same thing when the split is on a chunk boundary
+    h = pkg.BiogptModel.load(tiny_models[name])
+    cut = 2 * n_batch
+    h.eval_prompt(LONG_PROMPT[:cut], 0, n_batch, want_logits=False)
+    l2 = h.eval_prompt(LONG_PROMPT[cut:], cut, n_batch)
+    assert (l2 == lg).all()
+    h.close()
+    assert d == 0.0 or d <= ATOL
