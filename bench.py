@@ -217,15 +217,19 @@ def main():
     }
 
     if prefill:
-        out["config"]["workload"] = ("%d-token prompt ingested as %d evals of n_batch=8 tokens (no intra-chunk mask), BioGPT-base %s; "
-                                     "1 step = 1 prompt per rank; attention path: %s" % (
+        chunk_calls = bool(os.environ.get("BIOGPT_BENCH_CHUNK_CALLS"))
+        cols = 8 if chunk_calls else max(8, int(os.environ.get("BIOGPT_HIP_PROMPT_COLS", "128")) // 8 * 8)
+        out["config"]["workload"] = ("%d-token prompt = %d reference evals of n_batch=8 tokens (no mask inside an eval, F1), BioGPT-base %s; "
+                                     "%s; 1 step = 1 prompt per rank; attention path: %s" % (
                                          n_prompt, (n_prompt + 7) // 8, args.ftype.upper(),
+                                         "one library call per eval" if chunk_calls else
+                                         "biogpt_hip_eval_prompt: %d columns (%d evals) per pass, each column limited to its own eval's keys -- same logits and KV rows" % (cols, cols // 8),
                                          "MFMA f32 16x16x4 (BIOGPT_HIP_PREFILL_MFMA=1)" if os.environ.get("BIOGPT_HIP_PREFILL_MFMA") == "1" else "VALU, double accumulation (bit-parity path)"))
-        # weights are re-streamed once per chunk: algorithmic bytes per chunk = W + KV read at that context
-        chunks = (n_prompt + 7) // 8
-        b = sum(pkg.decode_bytes_per_token(hp, min(n_prompt, 8 * (k + 1))) for k in range(chunks))
+        # weights are streamed once per pass: algorithmic bytes per pass = W + KV read of its columns' contexts
+        passes = (n_prompt + cols - 1) // cols
+        b = sum(pkg.decode_bytes_per_token(hp, min(n_prompt, cols * (k + 1))) for k in range(passes))
         t_prompt = elapsed / args.steps
-        out["token_roofline"] = {"bytes_per_prompt": int(b), "GBps": round(b / t_prompt / 1e9, 1), "frac_of_peak": round(b / t_prompt / 1e9 / HBM_PEAK_GBS, 4)}
+        out["token_roofline"] = {"bytes_per_prompt": int(b), "passes": passes, "GBps": round(b / t_prompt / 1e9, 1), "frac_of_peak": round(b / t_prompt / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- roofline of the dominant kernel + whole-token figure (N = 1 only) ---------------------------
     if world == 1 and not prefill:
