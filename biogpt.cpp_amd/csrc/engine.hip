@@ -26,6 +26,7 @@
 #include "host_common.h"
 #include "kernels.hip.h"
 #include "kernels_fast.hip.h"
+#include "kernels_mfma.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
 
@@ -183,6 +184,7 @@ struct biogpt_hip_ctx {
     size_t logits_all_rows = 0;
     float *pmax_val = nullptr;
     float *sp_scores = nullptr, *sp_max = nullptr;   // key-split decode attention scratch (kernels_fast.hip.h)
+    uint8_t *tile_img = nullptr;   // row-tiled copy of the chain matrices for the MFMA kernels (same offsets as the arena), built on first use
     double *sp_pv = nullptr;
     int32_t *pmax_idx = nullptr;
     int pmax_cap = 0;
@@ -344,21 +346,48 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
     }
     return hipErrorInvalidValue;
 }
+// many columns (prompt passes, batched sequences): the same chain on the int8 matrix cores, reading the row-tiled
+// weight image (kernels_mfma.hip.h)
+template <int WT, int EPI, int K>
+hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    const size_t sm = bgk::matmul_mfma_smem_bytes(K, EPI == bgk::EPI_GELU_Q8);
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (one process drives one device)
+    if (sm > 64 * 1024 && !attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(256), sm, st, p, img);
+    return hipGetLastError();
+}
 template <int WT>
-hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
+hipError_t launch_chain_mfma(ChainOp op, const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    switch (op) {
+        case CHAIN_QKV_Q8: return launch_mfma<WT, bgk::EPI_QKV, 1024>(p, img, st);
+        case CHAIN_OPROJ: return launch_mfma<WT, bgk::EPI_RESID, 1024>(p, img, st);
+        case CHAIN_FC1_Q8: return launch_mfma<WT, bgk::EPI_GELU_Q8, 1024>(p, img, st);
+        case CHAIN_FC2: return launch_mfma<WT, bgk::EPI_RESID, 4096>(p, img, st);
+        case CHAIN_LMHEAD_Q8: return launch_mfma<WT, bgk::EPI_LOGITS, 1024>(p, img, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int WT>
+hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st, const bgk::DevMatrix *img) {
     if constexpr (bgk::TypeInfo<WT>::quant) {
+        if (img != nullptr && op != CHAIN_FC1) return launch_chain_mfma<WT>(op, p, *img, st);
         if (p.N == 1 && p.seq == nullptr && op != CHAIN_LMHEAD_Q8 && op != CHAIN_QKV_Q8 && op != CHAIN_FC1_Q8) return launch_chain_nc<WT, 1>(op, p, st);
         return launch_chain_nc<WT, 8>(op, p, st);
     }
     return hipErrorInvalidValue;
 }
-hipError_t launch_chain(ChainOp op, const bgk::MatvecParams &p, hipStream_t st) {
+hipError_t launch_chain(ChainOp op, const bgk::MatvecParams &p, hipStream_t st, const bgk::DevMatrix *img = nullptr) {
     switch (p.W.type) {
-        case T_Q4_0: return launch_chain_typed<bgk::W_Q4_0>(op, p, st);
-        case T_Q4_1: return launch_chain_typed<bgk::W_Q4_1>(op, p, st);
-        case T_Q5_0: return launch_chain_typed<bgk::W_Q5_0>(op, p, st);
-        case T_Q5_1: return launch_chain_typed<bgk::W_Q5_1>(op, p, st);
-        case T_Q8_0: return launch_chain_typed<bgk::W_Q8_0>(op, p, st);
+        case T_Q4_0: return launch_chain_typed<bgk::W_Q4_0>(op, p, st, img);
+        case T_Q4_1: return launch_chain_typed<bgk::W_Q4_1>(op, p, st, img);
+        case T_Q5_0: return launch_chain_typed<bgk::W_Q5_0>(op, p, st, img);
+        case T_Q5_1: return launch_chain_typed<bgk::W_Q5_1>(op, p, st, img);
+        case T_Q8_0: return launch_chain_typed<bgk::W_Q8_0>(op, p, st, img);
         default: return hipErrorInvalidValue;
     }
 }
@@ -417,6 +446,42 @@ hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_
 
 // The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
 // lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
+// ---- row-tiled weight image for the MFMA kernels (kernels_mfma.hip.h) -------------------------------------
+// Same offsets as the arena (an image of matrix m lives at tile_img + m.qs / m.sc / m.qh), so addressing needs no
+// second plan; built by retile_kernel from the SoA arena the first time a pass has enough columns.
+bgk::DevMatrix tile_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
+    bgk::DevMatrix d;
+    d.qs = c->tile_img + m.qs;
+    d.sc = c->tile_img + m.sc;
+    d.qh = reinterpret_cast<const uint32_t *>(c->tile_img + m.qh);
+    d.type = m.type; d.M = (int32_t)m.M; d.K = (int32_t)m.K;
+    return d;
+}
+template <int WT>
+void retile_one(biogpt_hip_ctx *c, const MatSlot &m) {
+    const int64_t n = m.M * (m.K / QK);
+    hipLaunchKernelGGL((bgk::retile_kernel<WT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_matrix(c, m),
+                       c->tile_img + m.qs, c->tile_img + m.sc, reinterpret_cast<uint32_t *>(c->tile_img + m.qh));
+}
+bool ensure_tile_images(biogpt_hip_ctx *c) {
+    if (c->tile_img) return true;
+    HIP_TRY(false, hipMalloc(&c->tile_img, c->plan.total));
+    auto one = [&](const MatSlot &m) {
+        switch (m.type) {
+            case T_Q4_0: retile_one<bgk::W_Q4_0>(c, m); break;
+            case T_Q4_1: retile_one<bgk::W_Q4_1>(c, m); break;
+            case T_Q5_0: retile_one<bgk::W_Q5_0>(c, m); break;
+            case T_Q5_1: retile_one<bgk::W_Q5_1>(c, m); break;
+            case T_Q8_0: retile_one<bgk::W_Q8_0>(c, m); break;
+            default: break;
+        }
+    };
+    for (const auto &L : c->plan.layers) { one(L.qkv); one(L.o); one(L.fc1); one(L.fc2); }
+    one(c->plan.lm_head);
+    HIP_TRY(false, hipGetLastError());
+    return true;
+}
+
 bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false) {
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
@@ -434,6 +499,10 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
     const bool chain = is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
     const bool pchain = chain && (N > 1 || batch);   // several columns: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
+    // enough columns to fill 16-wide MFMA tiles: the chain runs on the int8 matrix cores from the row-tiled weight image
+    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && c->tile_img != nullptr;
+    bgk::DevMatrix img;
+    auto tile = [&](const MatSlot &m) -> const bgk::DevMatrix * { if (!mfma) return nullptr; img = tile_matrix(c, m); return &img; };
     if (batch && !chain) BG_FAIL(false, "batched decode needs the BioGPT-base fast chain (block-quantized weights, d_model 1024, d_ff 4096, head size 64)");
     const int64_t seq_stride = (int64_t)hp.n_layer * P * D;
     float *const kroot = batch ? c->bk : c->memory_k;
@@ -459,7 +528,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             if (pchain) {
                 HIP_TRY(false, launch_lnq(c, c->x, N, L.ln0_w, L.ln0_b, q81, st));
                 p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
-                HIP_TRY(false, launch_chain(CHAIN_QKV_Q8, p, st));
+                HIP_TRY(false, launch_chain(CHAIN_QKV_Q8, p, st, tile(L.qkv)));
             } else {
                 HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, st)));
             }
@@ -513,7 +582,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             p.resid = c->x; p.ldr = D; p.out = c->x1; p.ldo = D;
             if (chain) {
                 p.aq_q = c->aq_q[0]; p.aq_d = c->aq_d[0]; p.aq_s = c->aq_s[0];
-                HIP_TRY(false, launch_chain(CHAIN_OPROJ, p, st));
+                HIP_TRY(false, launch_chain(CHAIN_OPROJ, p, st, tile(L.o)));
             } else {
                 HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
             }
@@ -529,7 +598,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                 HIP_TRY(false, launch_lnq(c, c->x1, N, L.ln1_w, L.ln1_b, q81, st));
                 p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
                 p.oq_q = c->aq_q[1]; p.oq_d = c->aq_d[1]; p.oq_s = c->aq_s[1];
-                HIP_TRY(false, launch_chain(CHAIN_FC1_Q8, p, st));
+                HIP_TRY(false, launch_chain(CHAIN_FC1_Q8, p, st, tile(L.fc1)));
             } else if (chain) {
                 p.oq_q = c->aq_q[1]; p.oq_d = c->aq_d[1]; p.oq_s = c->aq_s[1];
                 HIP_TRY(false, launch_chain(CHAIN_FC1, p, st));
@@ -545,7 +614,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             p.resid = c->x1; p.ldr = D; p.out = c->x; p.ldo = D;
             if (chain) {
                 p.aq_q = c->aq_q[1]; p.aq_d = c->aq_d[1]; p.aq_s = c->aq_s[1];
-                HIP_TRY(false, launch_chain(CHAIN_FC2, p, st));
+                HIP_TRY(false, launch_chain(CHAIN_FC2, p, st, tile(L.fc2)));
             } else {
                 HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, st)));
             }
@@ -558,7 +627,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
         HIP_TRY(false, launch_lnq(c, c->x, N, c->plan.ln_w, c->plan.ln_b, q81, st));
         p.aq_q = c->aq_q[2]; p.aq_d = c->aq_d[2]; p.aq_s = c->aq_s[2];
         p.N = N; p.out = c->logits_all; p.ldo = V;
-        HIP_TRY(false, launch_chain(CHAIN_LMHEAD_Q8, p, st));
+        HIP_TRY(false, launch_chain(CHAIN_LMHEAD_Q8, p, st, tile(c->plan.lm_head)));
         return true;
     }
     {  // final LayerNorm + lm_head; only the rows that are returned (F8)
@@ -761,7 +830,7 @@ void destroy(biogpt_hip_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->owns_arena && c->arena) (void)hipFree(c->arena);
     for (void *p : {(void *)c->memory_k, (void *)c->memory_v, (void *)c->x, (void *)c->x1, (void *)c->q, (void *)c->att,
-                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->sp_scores, (void *)c->sp_max, (void *)c->sp_pv, (void *)c->state})
+                    (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->sp_scores, (void *)c->sp_max, (void *)c->sp_pv, (void *)c->tile_img, (void *)c->state})
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     delete c;
@@ -966,6 +1035,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
 bool enqueue_prompt(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, int n_batch, int *last_cols = nullptr) {
     const int max_cols = std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 128));   // measured: 16 -> 17.9k, 32 -> 27.1k, 64 -> 36.0k, 128 -> 41.6k, 256 -> 43.1k prompt tok/s (Q4_0, -b 8)
     const int group = n_batch >= max_cols ? n_batch : (max_cols / n_batch) * n_batch;   // whole chunks per pass
+    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
     for (int at = 0; at < n;) {
         const int m = std::min(group, n - at);
         if (!upload_state(c, tokens + at, m, n_past + at, m > n_batch ? n_batch : 0)) return false;
@@ -1059,6 +1129,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
         ctx->batch_cap = n_seqs;
         for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     }
+    if (n_seqs >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && !ensure_tile_images(ctx)) return -2;   // before any graph capture
     if ((size_t)n_seqs > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
         ctx->logits_all = nullptr;

@@ -1,0 +1,257 @@
+// Block-quantized weights x many activation columns on the matrix cores (gfx950 v_mfma_i32_16x16x32_i8).
+//
+// With 32+ columns in flight (prompt passes of 128 tokens, dozens of sequences decoded together) the 8-column
+// mat-vec kernels of kernels_fast.hip.h are instruction-bound: ~12 VALU instructions per (row, column, block),
+// fc2 at 128 columns = 42 us.  One MFMA does the 32-element integer dot of a weight block against an activation
+// block for 16 rows x 16 columns at once -- exactly ggml's per-block "sumi" -- and everything after it is the
+// unchanged scalar arithmetic:
+//
+//   per wave = one 16 x 16 output tile, for block b = 0 .. K/32-1 IN ORDER:
+//     A = 16 rows x 32 weights of block b      (Q4: the nibbles as they are, Q5: + the fifth bit, Q8: the bytes)
+//     B = 32 activations x 16 columns          (the producer's Q8_0 / Q8_1 blocks)
+//     C = A x B (int32, zero-initialised)      -> sumi[row][col] of THIS block, 4 per lane
+//     acc[row][col] += ggml's per-type term    (sumi - 8*sum(x)) * d_w * d_x  etc. (unit_dot_quant)
+//
+// The accumulation runs over the blocks in block order inside one lane -- the association of the reference's
+// scalar vec_dot loop -- and the integer sums are exact: results are bit-identical to the VALU kernels and to
+// the oracle.
+//
+// What makes it fast is where the operands come from (a first version that loaded them straight from the SoA
+// weight arrays was bound by the texture addresser: every 8-byte operand load touched 16 cache lines):
+//   * weights: a second, ROW-TILED copy of the matrix (retile_kernel, built once on first use): the 16 rows of
+//     a tile are contiguous per block, so an A-operand load of a wave covers 256 contiguous bytes and the four
+//     scales a lane needs are 8 contiguous bytes;
+//   * activations: the 16 columns of the workgroup are staged once into LDS with coalesced 16-byte loads and
+//     shared by its 4 waves (= 4 row tiles); the row pitch K + 16 bytes makes the 8-byte operand reads
+//     conflict-free (4 lanes per bank pair, the minimum for 512 bytes).
+// Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)).  A loads are batched 8 blocks at a
+// time and double-buffered against the arithmetic.
+#pragma once
+
+#include "kernels_fast.hip.h"
+
+namespace bgk {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// ---- row-tiled weight image ---------------------------------------------------------------------------------
+// src (SoA arena): qs[(row*BPR + b) * QB], sc[(row*BPR + b)], qh[(row*BPR + b)]
+// dst (image)    : index (tile*BPR + b)*16 + r  with tile = row / 16, r = row % 16   (M is a multiple of 16)
+template <int WT>
+__global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq, uint8_t *ds, uint32_t *dh) {
+    using TI = TypeInfo<WT>;
+    constexpr int QB = TI::qbytes, SB = TI::q81 ? 4 : 2;
+    const int BPR = src.K / QK;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // source block index row*BPR + b
+    if (idx >= (int64_t)src.M * BPR) return;
+    const int row = (int)(idx / BPR), b = (int)(idx - (int64_t)row * BPR);
+    const int64_t dst = ((int64_t)(row >> 4) * BPR + b) * 16 + (row & 15);
+    const uint4 *q = reinterpret_cast<const uint4 *>(src.qs + idx * QB);
+    uint4 *o = reinterpret_cast<uint4 *>(dq + dst * QB);
+    o[0] = q[0];
+    if (QB == 32) o[1] = q[1];
+    if (SB == 4) reinterpret_cast<uint32_t *>(ds)[dst] = reinterpret_cast<const uint32_t *>(src.sc)[idx];
+    else reinterpret_cast<uint16_t *>(ds)[dst] = reinterpret_cast<const uint16_t *>(src.sc)[idx];
+    if (WT == W_Q5_0 || WT == W_Q5_1) dh[dst] = src.qh[idx];
+}
+
+// ggml's block term from the integer dot (same expressions as unit_dot_quant)
+template <int WT>
+__device__ __forceinline__ float mfma_block_term(int dot, uint32_t sc, float xd, uint32_t xs) {
+    if (WT == W_Q8_0) return __fmul_rn((float)dot, __fmul_rn(h2f((uint16_t)sc), xd));
+    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn((float)(dot - 8 * (int)xs), h2f((uint16_t)sc)), xd);
+    if (WT == W_Q5_0) return __fmul_rn(__fmul_rn(h2f((uint16_t)sc), xd), (float)(dot - 16 * (int)xs));
+    const float dw = h2f((uint16_t)(sc & 0xFFFFu)), mw = h2f((uint16_t)(sc >> 16));
+    return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), (float)dot), __fmul_rn(mw, __uint_as_float(xs)));
+}
+
+template <int WT>
+struct MfmaBatch {                       // one lane's weight-side operands for 8 consecutive blocks
+    static constexpr int SW = TypeInfo<WT>::q81 ? 4 : 2;   // dwords of the lane's 4 row scales per block
+    uint2 q[8];                          // raw operand bytes (nibbles / int8)
+    uint32_t sc[8][SW];                  // scales of rows 4g .. 4g+3 (fp16 d, or half2 {d, m})
+    uint32_t qh[8];                      // Q5: fifth bits of the lane's A row
+};
+
+// image addressing: `base` = (tile * BPR) * 16, block b adds b * 16
+template <int WT>
+__device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const DevMatrix &img, int64_t base, int b0, int li, int g) {
+    using TI = TypeInfo<WT>;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int64_t e = base + (int64_t)(b0 + j) * 16;                     // first of the tile's 16 entries of this block
+        if (WT == W_Q8_0) t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 32 + 8 * g);
+        else t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 16 + 8 * (g & 1));
+        if (TI::q81) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(img.sc + (e + 4 * g) * 4);
+            t.sc[j][0] = v.x; t.sc[j][1] = v.y; t.sc[j][2] = v.z; t.sc[j][3] = v.w;
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2 *>(img.sc + (e + 4 * g) * 2);
+            t.sc[j][0] = v.x; t.sc[j][1] = v.y;
+        }
+        if (WT == W_Q5_0 || WT == W_Q5_1) t.qh[j] = img.qh[e + li];
+    }
+}
+
+template <int WT>
+__device__ __forceinline__ long mfma_a_operand(const MfmaBatch<WT> &t, int j, int g) {
+    if (WT == W_Q8_0) return (long)(((unsigned long)t.q[j].y << 32) | t.q[j].x);
+    // 8 bytes of nibbles: low nibble of byte i = element i of the half, high nibble = element i + 16
+    const int sh = 4 * (g >> 1);
+    uint32_t lo = (t.q[j].x >> sh) & 0x0F0F0F0Fu, hi = (t.q[j].y >> sh) & 0x0F0F0F0Fu;
+    if (WT == W_Q5_0 || WT == W_Q5_1) {
+        const uint32_t bits = t.qh[j] >> (8 * g);   // fifth bits of elements 8g .. 8g+7
+        lo |= spread4(bits);
+        hi |= spread4(bits >> 4);
+    }
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+
+__host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool gelu_q8) {
+    const size_t act = (size_t)16 * (K + 16) + 2 * (size_t)16 * (K / QK + 1) * 4;
+    const size_t tail = gelu_q8 ? (size_t)16 * 64 * 4 : 0;
+    return (act > tail ? act : tail) + 64;    // the GELU_Q8 exchange reuses the activation area after the last block
+}
+
+template <int WT, int EPI, int K>
+__global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
+    using TI = TypeInfo<WT>;
+    static_assert(TI::quant, "block-quantized weights");
+    constexpr int BPR = K / QK, NB = BPR / 8, PITCH = K + 16, SP = BPR + 1;   // SP: per-column pitch of the scale arrays (bank skew)
+    static_assert(NB % 2 == 0, "K must be a multiple of 512");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint8_t *const s_q = smem_raw;                                              // [16 columns][PITCH] int8
+    float *const s_d = reinterpret_cast<float *>(smem_raw + 16 * PITCH);        // [16][SP] activation block scales
+    uint32_t *const s_s = reinterpret_cast<uint32_t *>(s_d + 16 * SP);          // [16][SP] block sums (Q8_0: int, Q8_1: d*sum)
+    float *const s_tail = reinterpret_cast<float *>(smem_raw);                  // GELU_Q8: [16 columns][64 rows], after the loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int M = p.W.M;
+    const int tile = blockIdx.x * 4 + wave;                                     // 16-row tile of this wave
+    const int row0 = tile * 16, col0 = blockIdx.y * 16;
+    const bool tile_ok = row0 < M;
+    const int tile_c = tile_ok ? tile : 0;                                      // waves past the last row keep the barriers company
+    const int64_t base = (int64_t)tile_c * BPR * 16;
+    const int col = col0 + li;
+    const bool col_ok = col < p.N;
+    const int colc = min(col, p.N - 1);
+    const int orow = row0 + 4 * g;                                              // outputs: rows 4g .. 4g+3, column lane & 15
+
+    MfmaBatch<WT> t0, t1;
+    mfma_load_batch<WT>(t0, img, base, 0, li, g);
+    // epilogue inputs (independent loads); M is a multiple of 4 everywhere
+    const int orc = min(orow, M - 4);
+    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res = e_bias;
+    if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc);
+    if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc * p.ldr + orc);
+    int e_npast = 0;
+    if (EPI == EPI_QKV) e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
+
+    // ---- stage the 16 activation columns of this workgroup in LDS (coalesced 16-byte pieces) -------------------
+    {
+        constexpr int PPC = K / 16;                                             // 16-byte pieces per column
+#pragma unroll
+        for (int i = 0; i < 16 * PPC / 256; i++) {
+            const int pc = tid + 256 * i, c = pc / PPC, o = (pc - c * PPC) * 16;
+            const int cc = min(col0 + c, p.N - 1);                              // idle columns re-read the last one
+            *reinterpret_cast<uint4 *>(s_q + c * PITCH + o) = *reinterpret_cast<const uint4 *>(p.aq_q + (size_t)cc * K + o);
+        }
+#pragma unroll
+        for (int i = 0; i < (16 * BPR + 255) / 256; i++) {
+            const int e = tid + 256 * i;
+            if (e < 16 * BPR) {
+                const int c = e / BPR, b = e - c * BPR;
+                const int cc = min(col0 + c, p.N - 1);
+                s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + b];
+                s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + b];
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15, k-group g
+    const float *bd = s_d + li * SP;
+    const uint32_t *bs = s_s + li * SP;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto consume = [&](const MfmaBatch<WT> &t, int b0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = b0 + j;
+            const long bop = *reinterpret_cast<const long *>(bq + b * QK);
+            const float xd = bd[b];
+            const uint32_t xs = bs[b];
+            const i32x4 zero = {0, 0, 0, 0};
+            const i32x4 c = __builtin_amdgcn_mfma_i32_16x16x32_i8(mfma_a_operand<WT>(t, j, g), bop, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t sc = TI::q81 ? t.sc[j][r] : ((t.sc[j][r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+                acc[r] = __fadd_rn(acc[r], mfma_block_term<WT>(c[r], sc, xd, xs));
+            }
+        }
+    };
+#pragma unroll 1
+    for (int nb = 0; nb < NB; nb += 2) {
+        mfma_load_batch<WT>(t1, img, base, (nb + 1) * 8, li, g);
+        consume(t0, nb * 8);
+        if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, (nb + 2) * 8, li, g);
+        consume(t1, (nb + 1) * 8);
+    }
+
+    const bool ok = col_ok && tile_ok;
+    if (EPI == EPI_GELU_Q8) {
+        __syncthreads();                                                        // everyone is done reading the activation area
+        float4 v;
+        v.x = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.x, acc[0]))]); v.y = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.y, acc[1]))]);
+        v.z = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.z, acc[2]))]); v.w = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.w, acc[3]))]);
+        *reinterpret_cast<float4 *>(s_tail + li * 64 + wave * 16 + 4 * g) = v;
+        __syncthreads();
+        // the workgroup's 64 rows are two Q8 blocks of fc2's activation row per column: quantize_row_q8_0 / _q8_1,
+        // a half-wave per (column, block)
+        for (int u = wave * 2 + (lane >> 5); u < 32; u += 8) {
+            const int c = u >> 1, half = u & 1;
+            if (col0 + c >= p.N) continue;
+            const float v1 = s_tail[c * 64 + half * 32 + (lane & 31)];
+            float amax = fabsf(v1);
+            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
+            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            const float d = amax / 127.0f;
+            const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+            const int q = (int)roundf(__fmul_rn(v1, id));
+            int isum = q;
+            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
+            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
+            isum += __shfl_xor(isum, 16, 64);
+            const size_t blk = (size_t)(col0 + c) * (M / 32) + blockIdx.x * 2 + half;   // column-major [N][d_ff/32]
+            p.oq_q[blk * 32 + (lane & 31)] = (int8_t)q;
+            if ((lane & 31) == 0) {
+                if (TI::q81) { p.oq_d[blk] = d; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
+                else { p.oq_d[blk] = h2f(f2h(d)); p.oq_s[blk] = (uint32_t)isum; }
+            }
+        }
+    } else if (ok) {
+        if (EPI == EPI_QKV) {
+            float4 v;
+            v.x = __fadd_rn(e_bias.x, acc[0]); v.y = __fadd_rn(e_bias.y, acc[1]); v.z = __fadd_rn(e_bias.z, acc[2]); v.w = __fadd_rn(e_bias.w, acc[3]);
+            const int which = orow / K, rr = orow - which * K;             // d_model == K for the q/k/v projection
+            if (which == 0) {
+                v.x = __fmul_rn(v.x, p.q_scale); v.y = __fmul_rn(v.y, p.q_scale); v.z = __fmul_rn(v.z, p.q_scale); v.w = __fmul_rn(v.w, p.q_scale);
+                *reinterpret_cast<float4 *>(p.q_out + (size_t)col * K + rr) = v;
+            } else {
+                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)col * p.kv_seq_stride : 0);
+                const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);       // head-major cache: [H][P][dk]; 4 | dk
+                *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast) << p.dk_log2) + dd) = v;
+            }
+        } else if (EPI == EPI_RESID) {
+            float4 v;
+            v.x = __fadd_rn(__fadd_rn(acc[0], e_bias.x), e_res.x); v.y = __fadd_rn(__fadd_rn(acc[1], e_bias.y), e_res.y);
+            v.z = __fadd_rn(__fadd_rn(acc[2], e_bias.z), e_res.z); v.w = __fadd_rn(__fadd_rn(acc[3], e_bias.w), e_res.w);
+            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = v;
+        } else {
+            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+}
+
+}  // namespace bgk
