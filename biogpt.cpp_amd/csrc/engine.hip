@@ -551,6 +551,10 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     c->mfma_attr_set = true;
                 }
                 hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
+            } else if (!batch && dk == 64 && t_max <= 1024 && N >= env_int("BIOGPT_HIP_ATTN_GROUP_MIN", 32) && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+                // a pass of many query columns: one workgroup per (head, 8 queries) shares every K / V row it loads
+                a.t_cap = std::min(P, t_max);
+                hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
             } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
                 // loads are bounded by t_cap (= P when the table is not a multiple of 64; the workgroup stays whole
                 // waves); 4 lanes per key, 16 prefetched V rows per lane

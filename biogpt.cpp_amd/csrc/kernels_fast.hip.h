@@ -383,6 +383,13 @@ __device__ __forceinline__ float inv_sum_f32(double s) {
     return (float)r;
 }
 
+// LDS of attn_group_kernel: max(scores [G][pitch] floats, partial outputs [8][G][64] doubles) + [G] reciprocal sums
+__host__ __device__ inline size_t attn_group_main_bytes(int t_cap, int g = 8) {
+    const size_t sc = (size_t)g * ((t_cap + 3) & ~3) * 4, po = (size_t)8 * g * 64 * 8;
+    return sc > po ? sc : po;
+}
+__host__ __device__ inline size_t attn_group_smem_bytes(int t_cap, int g = 8) { return attn_group_main_bytes(t_cap, g) + 64; }
+
 // One head's 64 outputs, held one per lane by wave 0: F32 row for the reference layout and, for the fast
 // out_proj, the two Q8 blocks of its activation row (amax / roundf / block sum as quantize_row_q8_0/_1).
 __device__ __forceinline__ void store_head_output(const AttnParams &p, int i, int h, int tid, float o, bool q8) {
@@ -666,6 +673,124 @@ __global__ __launch_bounds__(64) void attn_split_combine_kernel(const AttnParams
         if (s + 1 < ns) t1 += pr[s + 1];
     }
     store_head_output(p, 0, h, tid, (float)(t0 + t1), p.oq_q != nullptr);
+}
+
+// ---- attention for a pass of many query columns of ONE sequence (prompt passes) ------------------------------
+// attn_fast_kernel gives every (head, query) its own workgroup, so a 128-column pass re-reads a head's K and V
+// 128 times and launches 2048 workgroups (43 us per layer at 512 keys).  Here a workgroup takes one head and G = 8
+// consecutive queries: a key row is loaded once and scored against the 8 queries (their 16 dims per lane live in
+// registers), a V row is loaded once and accumulated into 8 outputs.  Per (query, key) the arithmetic is that of
+// attn_fast_kernel -- scores with four double accumulators per lane and a quad reduce, fp16-table exp, double row
+// sum, p = fl(e * (float)(1/sum)), V*p in double -- so the outputs agree bit for bit; each query keeps its own
+// visible-key limit (visible_keys: the chunk it belongs to).
+template <int G>
+__global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
+    constexpr int DK = 64, NT = 512, KPP = NT / 4, NSL = NT / 64;
+    static_assert(G == NSL, "one wave per query in the softmax and output phases");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int t_cap = p.t_cap, SP = (t_cap + 3) & ~3;
+    float *const S = reinterpret_cast<float *>(smem_raw);                  // [G][SP] scores, then e_j
+    double *const pv = reinterpret_cast<double *>(smem_raw);               // [NSL][G][DK], reuses S after the PV loop
+    float *const inv_s = reinterpret_cast<float *>(smem_raw + attn_group_main_bytes(t_cap));   // [G]
+    const int h = blockIdx.x, i0 = blockIdx.y * G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ksub = tid & 3, kidx = tid >> 2;
+    const int N = p.N, D = p.D;
+
+    int Tq[G], Tmax = 0;
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+        Tq[q] = (i0 + q < N) ? visible_keys(p.st, i0 + q, N) : 0;
+        Tmax = max(Tmax, Tq[q]);
+    }
+    float4 qv[G][4];
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+        const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)min(i0 + q, N - 1) * D + (size_t)h * DK) + ksub;
+#pragma unroll
+        for (int m = 0; m < 4; m++) qv[q][m] = qp[4 * m];
+    }
+    // ---- scores: 4 lanes per key, KPP keys per trip ----
+    const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + ksub;
+    for (int j0 = 0; j0 < Tmax; j0 += KPP) {
+        const int j = j0 + kidx, jc = min(j, t_cap - 1);
+        float4 kr[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) kr[m] = kbase[(size_t)jc * (DK / 4) + 4 * m];
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                a0 += (double)__fmul_rn(kr[m].x, qv[q][m].x); a1 += (double)__fmul_rn(kr[m].y, qv[q][m].y);
+                a2 += (double)__fmul_rn(kr[m].z, qv[q][m].z); a3 += (double)__fmul_rn(kr[m].w, qv[q][m].w);
+            }
+            double acc = (a0 + a1) + (a2 + a3);
+            acc += dpp_d<DPP_QUAD_XOR1>(acc);
+            acc += dpp_d<DPP_QUAD_XOR2>(acc);
+            if (ksub == 0 && j < t_cap) S[q * SP + j] = (j < Tq[q]) ? (float)acc : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // ---- softmax: wave q owns query q (ggml_soft_max: fp16-table exp, double row sum) ----
+    const int Tw = (i0 + wave < N) ? visible_keys(p.st, i0 + wave, N) : 0;
+    if (Tw > 0) {
+        float *Sr = S + wave * SP;
+        float mx = -INFINITY;
+        for (int j = lane; j < Tw; j += 64) mx = fmaxf(mx, Sr[j]);
+        mx = wave_max_f32(mx);
+        double sum = 0.0;
+        for (int j0 = lane; j0 < Tw; j0 += 256) {          // 4 table lookups in flight per lane
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                e[u] = (j < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                if (j < Tw) { Sr[j] = e[u]; sum += (double)e[u]; }
+            }
+        }
+        sum = wave_sum_f64(sum);
+        if (lane == 0) inv_s[wave] = inv_sum_f32(sum);
+    }
+    __syncthreads();
+    // ---- PV: NSL key slices x 64 dims, one V load feeds the G queries ----
+    const int d = lane, sl = wave;
+    float inv[G];
+#pragma unroll
+    for (int q = 0; q < G; q++) inv[q] = inv_s[q];
+    double acc[G];
+#pragma unroll
+    for (int q = 0; q < G; q++) acc[q] = 0.0;
+    const float *__restrict__ vbase = p.vcache + (size_t)h * p.P * DK + d;
+    for (int j = sl; j < Tmax; j += NSL * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = vbase[(size_t)min(j + NSL * k, t_cap - 1) * DK];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int jj = j + NSL * k;
+#pragma unroll
+            for (int q = 0; q < G; q++)
+                if (jj < Tq[q]) acc[q] += (double)__fmul_rn(v[k], __fmul_rn(S[q * SP + jj], inv[q]));
+        }
+    }
+    __syncthreads();                                         // every read of S is done: the area becomes pv
+#pragma unroll
+    for (int q = 0; q < G; q++) pv[(size_t)(sl * G + q) * DK + d] = acc[q];
+    __syncthreads();
+    if (i0 + wave < N) {                                     // wave q: the 64 outputs of query q
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < NSL; s2 += 2) {
+            t0 += pv[(size_t)(s2 * G + wave) * DK + lane];
+            t1 += pv[(size_t)((s2 + 1) * G + wave) * DK + lane];
+        }
+        store_head_output(p, i0 + wave, h, lane, (float)(t0 + t1), p.oq_q != nullptr);
+    }
 }
 
 // ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
