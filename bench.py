@@ -218,7 +218,7 @@ def main():
 
     if prefill:
         chunk_calls = bool(os.environ.get("BIOGPT_BENCH_CHUNK_CALLS"))
-        cols = 8 if chunk_calls else max(8, int(os.environ.get("BIOGPT_HIP_PROMPT_COLS", "128")) // 8 * 8)
+        cols = 8 if chunk_calls else max(8, int(os.environ.get("BIOGPT_HIP_PROMPT_COLS", "512")) // 8 * 8)
         out["config"]["workload"] = ("%d-token prompt = %d reference evals of n_batch=8 tokens (no mask inside an eval, F1), BioGPT-base %s; "
                                      "%s; 1 step = 1 prompt per rank; attention path: %s" % (
                                          n_prompt, (n_prompt + 7) // 8, args.ftype.upper(),

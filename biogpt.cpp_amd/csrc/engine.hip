@@ -500,7 +500,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
     const bool pchain = chain && (N > 1 || batch);   // several columns: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
     // enough columns to fill 16-wide MFMA tiles: the chain runs on the int8 matrix cores from the row-tiled weight image
-    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && c->tile_img != nullptr;
+    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && c->tile_img != nullptr;
     bgk::DevMatrix img;
     auto tile = [&](const MatSlot &m) -> const bgk::DevMatrix * { if (!mfma) return nullptr; img = tile_matrix(c, m); return &img; };
     if (batch && !chain) BG_FAIL(false, "batched decode needs the BioGPT-base fast chain (block-quantized weights, d_model 1024, d_ff 4096, head size 64)");
@@ -1033,13 +1033,13 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
 // Prompt ingestion = consecutive evals of n_batch tokens (main.cpp:129-137), each attending to everything before
 // it and to its own chunk (no mask inside an eval, F1).  Nothing else couples the chunks, so up to
 // BIOGPT_HIP_PROMPT_COLS columns (several chunks) go through the layers in ONE pass -- every weight byte is
-// streamed once for all of them (default 128 columns) -- with the attention of column i limited to the keys its own chunk would
+// streamed once for all of them (default 512 columns) -- with the attention of column i limited to the keys its own chunk would
 // have seen (DevState::chunk).  Per-column arithmetic is unchanged: logits and KV rows are bit-identical to
 // the chunk-by-chunk evaluation.  Leaves the last token's logits in ctx->logits.
 bool enqueue_prompt(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, int n_batch, int *last_cols = nullptr) {
-    const int max_cols = std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 128));   // measured: 16 -> 17.9k, 32 -> 27.1k, 64 -> 36.0k, 128 -> 41.6k, 256 -> 43.1k prompt tok/s (Q4_0, -b 8)
+    const int max_cols = std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 512));   // measured (Q4_0, -b 8, 512-token prompt): 16 -> 17.9k, 64 -> 36k, 128 -> 66k, 256 -> 87k, 512 -> 97k prompt tok/s
     const int group = n_batch >= max_cols ? n_batch : (max_cols / n_batch) * n_batch;   // whole chunks per pass
-    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
+    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
     for (int at = 0; at < n;) {
         const int m = std::min(group, n - at);
         if (!upload_state(c, tokens + at, m, n_past + at, m > n_batch ? n_batch : 0)) return false;
@@ -1133,7 +1133,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
         ctx->batch_cap = n_seqs;
         for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     }
-    if (n_seqs >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 32) && !ensure_tile_images(ctx)) return -2;   // before any graph capture
+    if (n_seqs >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && !ensure_tile_images(ctx)) return -2;   // before any graph capture
     if ((size_t)n_seqs > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
         ctx->logits_all = nullptr;

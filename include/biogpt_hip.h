@@ -124,7 +124,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_to
 /* Prompt ingestion: the result of calling biogpt_hip_eval() on consecutive chunks of n_batch tokens
  * (main.cpp:129-137 with -b n_batch) -- same KV rows, same logits for the last token, bit for bit -- but several
  * chunks travel through the layers per pass (column i only attends to the keys its own chunk would have seen),
- * so the weights are streamed once per pass of up to 128 tokens (BIOGPT_HIP_PROMPT_COLS) instead of once per n_batch.  logits_out may be NULL: the call
+ * so the weights are streamed once per pass of up to 512 tokens (BIOGPT_HIP_PROMPT_COLS) instead of once per n_batch.  logits_out may be NULL: the call
  * is then asynchronous (biogpt_hip_logits_device() / biogpt_hip_synchronize()). */
 int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t n_batch,
                            float *logits_out);

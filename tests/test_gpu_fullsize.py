@@ -274,3 +274,27 @@ def test_batched_decode_on_the_matrix_cores(pkg, oracle, files, name):
         assert list(ids[s]) == list(one)
     single.close()
     g.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+def test_prompt_pass_full_context(pkg, oracle, files, name):
+    """A 1024-token prompt (-b 8: 128 reference chunks) in two passes of 512 columns -- the matrix-core chain, the
+    grouped-query attention at up to 1024 keys -- against the oracle fed chunk by chunk; every 64th chunk's KV rows too."""
+    g = pkg.BiogptModel.load(files[name])
+    o = oracle.OracleModel(files[name], n_threads=16)
+    rng = np.random.default_rng(17)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 1023)]
+    lo = None
+    for at in range(0, 1024, 8):
+        lo = o.eval(toks[at:at + 8], at)
+    lg = g.eval_prompt(toks, 0, 8)
+    d = float(np.abs(lg - lo).max())
+    print("%s 1024-token prompt pass: worst |diff| %.2e" % (name, d))
+    assert d <= ATOL and int(lg.argmax()) == int(lo.argmax())
+    L, P, D = KW["n_layer"], KW["n_positions"], KW["d_model"]
+    for which in (0, 1):
+        kv = g.read_kv(which, 0, L * P * D).reshape(L, P, D)
+        ref = o.kv(which)
+        for pos in (0, 7, 8, 511, 512, 1000, 1023):
+            assert np.abs(kv[:, pos] - ref[:, pos]).max() <= 1e-4, (which, pos)
+    g.close()

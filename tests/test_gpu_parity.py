@@ -176,9 +176,9 @@ def test_external_arena_and_attach(pkg, oracle, tiny_models):
 LONG_PROMPT = [2] + [(37 * i + 11) % 316 + 4 for i in range(52)]     # 53 tokens (tiny n_positions = 64)
 
 
-@pytest.fixture(params=[16, 128])
+@pytest.fixture(params=[16, 512])
 def prompt_cols(request, monkeypatch):
-    """columns per pass of the prompt path: several passes (16) and the whole 53-token prompt in one (128, the default)"""
+    """columns per pass of the prompt path: several passes (16) and the whole 53-token prompt in one (512, the default)"""
     monkeypatch.setenv("BIOGPT_HIP_PROMPT_COLS", str(request.param))
     return request.param
 
