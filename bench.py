@@ -275,12 +275,22 @@ def main():
             # (configs[1] is single-stream), reported because it is what the HBM-bound regime of this chip looks like
             if args.ftype.startswith("q"):
                 ms = {}
-                for S in (8, 32):
+                for S in (8, 32, 64):       # 64: enough columns for the int8 matrix-core chain (kernels_mfma.hip.h)
                     prompts = [make_prompt(hp.n_vocab, 9000 + i) for i in range(S)]
                     model.generate_greedy_batch(prompts, 8, n_batch=8)            # warm-up: allocations + graph capture
                     ids_b, secs_b = model.generate_greedy_batch(prompts, n_predict, n_batch=8)
                     ms["S=%d" % S] = {"tokens_per_s": round(S * n_predict / secs_b, 1), "ms_per_step_all_seqs": round(secs_b / n_predict * 1e3, 4)}
                 out["multi_stream"] = ms
+            # prompt ingestion (configs[2] in short): a 512-token prompt with -b 8 semantics through biogpt_hip_eval_prompt
+            rngp = np.random.default_rng(7000)
+            ptoks = [2] + [int(v) for v in rngp.integers(4, hp.n_vocab, 511)]
+            model.eval_prompt(ptoks, 0, 8, want_logits=False); model.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model.eval_prompt(ptoks, 0, 8, want_logits=False)
+            model.synchronize()
+            out["prompt_pass"] = {"tokens_per_s": round(3 * 512 / (time.perf_counter() - t1), 1),
+                                  "note": "512-token prompt, 64 reference evals of n_batch=8 in one pass (bench.py --workload prefill is the full bench line)"}
             # the drop-in API loop: logits cross PCIe every token, host arg-max (never `value`)
             pr = make_prompt(hp.n_vocab, 7)
             t1 = time.perf_counter()
