@@ -385,7 +385,7 @@ __device__ __forceinline__ float inv_sum_f32(double s) {
 
 // LDS of attn_group_kernel: max(scores [G][pitch] floats, partial outputs [8][G][64] doubles) + [G] reciprocal sums
 __host__ __device__ inline size_t attn_group_main_bytes(int t_cap, int g = 8) {
-    const size_t sc = (size_t)g * ((t_cap + 3) & ~3) * 4, po = (size_t)8 * g * 64 * 8;
+    const size_t sc = (size_t)g * t_cap * 4, po = (size_t)8 * g * 64 * 8;
     return sc > po ? sc : po;
 }
 __host__ __device__ inline size_t attn_group_smem_bytes(int t_cap, int g = 8) { return attn_group_main_bytes(t_cap, g) + 64; }
@@ -686,12 +686,11 @@ __global__ __launch_bounds__(64) void attn_split_combine_kernel(const AttnParams
 template <int G>
 __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
     constexpr int DK = 64, NT = 512, KPP = NT / 4, NSL = NT / 64;
-    static_assert(G == NSL, "one wave per query in the softmax and output phases");
+    static_assert(G == NSL && G == 8, "one wave per query in the softmax and output phases; 8 probabilities = two 16-byte LDS reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int t_cap = p.t_cap, SP = (t_cap + 3) & ~3;
-    float *const S = reinterpret_cast<float *>(smem_raw);                  // [G][SP] scores, then e_j
+    const int t_cap = p.t_cap;
+    float *const S = reinterpret_cast<float *>(smem_raw);                  // [key][G]: scores, then probabilities p = fl(e * 1/sum)
     double *const pv = reinterpret_cast<double *>(smem_raw);               // [NSL][G][DK], reuses S after the PV loop
-    float *const inv_s = reinterpret_cast<float *>(smem_raw + attn_group_main_bytes(t_cap));   // [G]
     const int h = blockIdx.x, i0 = blockIdx.y * G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksub = tid & 3, kidx = tid >> 2;
@@ -717,6 +716,7 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
         float4 kr[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) kr[m] = kbase[(size_t)jc * (DK / 4) + 4 * m];
+        float sc[G];
 #pragma unroll
         for (int q = 0; q < G; q++) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -728,40 +728,48 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
             double acc = (a0 + a1) + (a2 + a3);
             acc += dpp_d<DPP_QUAD_XOR1>(acc);
             acc += dpp_d<DPP_QUAD_XOR2>(acc);
-            if (ksub == 0 && j < t_cap) S[q * SP + j] = (j < Tq[q]) ? (float)acc : -INFINITY;
+            sc[q] = (j < Tq[q]) ? (float)acc : -INFINITY;
+        }
+        if (ksub == 0 && j < t_cap) {
+            float4 *dst = reinterpret_cast<float4 *>(S + (size_t)j * G);
+            dst[0] = make_float4(sc[0], sc[1], sc[2], sc[3]);
+            dst[1] = make_float4(sc[4], sc[5], sc[6], sc[7]);
         }
     }
     __syncthreads();
-    // ---- softmax: wave q owns query q (ggml_soft_max: fp16-table exp, double row sum) ----
+    // ---- softmax: wave q owns query q (ggml_soft_max: fp16-table exp, double row sum); the column is left as the
+    //      probabilities the PV product uses, p_j = fl(e_j * (float)(1/sum)), and 0 for the keys it may not see ----
     const int Tw = (i0 + wave < N) ? visible_keys(p.st, i0 + wave, N) : 0;
-    if (Tw > 0) {
-        float *Sr = S + wave * SP;
-        float mx = -INFINITY;
-        for (int j = lane; j < Tw; j += 64) mx = fmaxf(mx, Sr[j]);
-        mx = wave_max_f32(mx);
-        double sum = 0.0;
-        for (int j0 = lane; j0 < Tw; j0 += 256) {          // 4 table lookups in flight per lane
-            float e[4];
+    {
+        float *Sq = S + wave;                                // element j at Sq[j * G]
+        float inv = 0.0f;
+        if (Tw > 0) {
+            float mx = -INFINITY;
+            for (int j = lane; j < Tw; j += 64) mx = fmaxf(mx, Sq[(size_t)j * G]);
+            mx = wave_max_f32(mx);
+            double sum = 0.0;
+            for (int j0 = lane; j0 < Tw; j0 += 256) {      // 4 table lookups in flight per lane
+                float e[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + 64 * u;
-                e[u] = (j < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]) : 0.0f;
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 64 * u;
+                    e[u] = (j < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(Sq[(size_t)j * G], mx))]) : 0.0f;
+                }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + 64 * u;
-                if (j < Tw) { Sr[j] = e[u]; sum += (double)e[u]; }
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 64 * u;
+                    if (j < Tw) { Sq[(size_t)j * G] = e[u]; sum += (double)e[u]; }
+                }
             }
+            sum = wave_sum_f64(sum);
+            inv = inv_sum_f32(sum);
         }
-        sum = wave_sum_f64(sum);
-        if (lane == 0) inv_s[wave] = inv_sum_f32(sum);
+        for (int j = lane; j < Tmax; j += 64) Sq[(size_t)j * G] = (j < Tw) ? __fmul_rn(Sq[(size_t)j * G], inv) : 0.0f;
     }
     __syncthreads();
-    // ---- PV: NSL key slices x 64 dims, one V load feeds the G queries ----
+    // ---- PV: NSL key slices x 64 dims; one V load and two 16-byte LDS reads feed the G queries (a hidden key has p = 0
+    //      and adds +-0 to the double accumulator, which leaves it unchanged) ----
     const int d = lane, sl = wave;
-    float inv[G];
-#pragma unroll
-    for (int q = 0; q < G; q++) inv[q] = inv_s[q];
     double acc[G];
 #pragma unroll
     for (int q = 0; q < G; q++) acc[q] = 0.0;
@@ -773,9 +781,13 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int jj = j + NSL * k;
-#pragma unroll
-            for (int q = 0; q < G; q++)
-                if (jj < Tq[q]) acc[q] += (double)__fmul_rn(v[k], __fmul_rn(S[q * SP + jj], inv[q]));
+            if (jj < Tmax) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(S + (size_t)jj * G), p1 = *reinterpret_cast<const float4 *>(S + (size_t)jj * G + 4);
+                acc[0] += (double)__fmul_rn(v[k], p0.x); acc[1] += (double)__fmul_rn(v[k], p0.y);
+                acc[2] += (double)__fmul_rn(v[k], p0.z); acc[3] += (double)__fmul_rn(v[k], p0.w);
+                acc[4] += (double)__fmul_rn(v[k], p1.x); acc[5] += (double)__fmul_rn(v[k], p1.y);
+                acc[6] += (double)__fmul_rn(v[k], p1.z); acc[7] += (double)__fmul_rn(v[k], p1.w);
+            }
         }
     }
     __syncthreads();                                         // every read of S is done: the area becomes pv
