@@ -24,7 +24,7 @@
 //   * activations: the 16 columns of the workgroup are staged once into LDS with coalesced 16-byte loads and
 //     shared by its 4 waves (= 4 row tiles); the row pitch K + 16 bytes makes the 8-byte operand reads
 //     conflict-free (4 lanes per bank pair, the minimum for 512 bytes).
-// Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)).  A loads are batched 8 blocks at a
+// Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)).  A loads are batched 4 blocks at a
 // time and double-buffered against the arithmetic.
 #pragma once
 
@@ -66,11 +66,12 @@ __device__ __forceinline__ float mfma_block_term(int dot, uint32_t sc, float xd,
 }
 
 template <int WT>
-struct MfmaBatch {                       // one lane's weight-side operands for 8 consecutive blocks
+struct MfmaBatch {                       // one lane's weight-side operands for CH consecutive blocks
+    static constexpr int CH = 4;         // blocks per load batch (8 costs ~60 more VGPRs and an occupancy step)
     static constexpr int SW = TypeInfo<WT>::q81 ? 4 : 2;   // dwords of the lane's 4 row scales per block
-    uint2 q[8];                          // raw operand bytes (nibbles / int8)
-    uint32_t sc[8][SW];                  // scales of rows 4g .. 4g+3 (fp16 d, or half2 {d, m})
-    uint32_t qh[8];                      // Q5: fifth bits of the lane's A row
+    uint2 q[CH];                         // raw operand bytes (nibbles / int8)
+    uint32_t sc[CH][SW];                 // scales of rows 4g .. 4g+3 (fp16 d, or half2 {d, m})
+    uint32_t qh[CH];                     // Q5: fifth bits of the lane's A row
 };
 
 // image addressing: `base` = (tile * BPR) * 16, block b adds b * 16
@@ -78,7 +79,7 @@ template <int WT>
 __device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const DevMatrix &img, int64_t base, int b0, int li, int g) {
     using TI = TypeInfo<WT>;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < MfmaBatch<WT>::CH; j++) {
         const int64_t e = base + (int64_t)(b0 + j) * 16;                     // first of the tile's 16 entries of this block
         if (WT == W_Q8_0) t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 32 + 8 * g);
         else t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 16 + 8 * (g & 1));
@@ -117,7 +118,7 @@ template <int WT, int EPI, int K>
 __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
-    constexpr int BPR = K / QK, NB = BPR / 8, PITCH = K + 16, SP = BPR + 1;   // SP: per-column pitch of the scale arrays (bank skew)
+    constexpr int CH = MfmaBatch<WT>::CH, BPR = K / QK, NB = BPR / CH, PITCH = K + 16, SP = BPR + 1;   // SP: per-column pitch of the scale arrays (bank skew)
     static_assert(NB % 2 == 0, "K must be a multiple of 512");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint8_t *const s_q = smem_raw;                                              // [16 columns][PITCH] int8
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     auto consume = [&](const MfmaBatch<WT> &t, int b0) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < CH; j++) {
             const int b = b0 + j;
             const long bop = *reinterpret_cast<const long *>(bq + b * QK);
             const float xd = bd[b];
@@ -192,10 +193,10 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
     };
 #pragma unroll 1
     for (int nb = 0; nb < NB; nb += 2) {
-        mfma_load_batch<WT>(t1, img, base, (nb + 1) * 8, li, g);
-        consume(t0, nb * 8);
-        if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, (nb + 2) * 8, li, g);
-        consume(t1, (nb + 1) * 8);
+        mfma_load_batch<WT>(t1, img, base, (nb + 1) * CH, li, g);
+        consume(t0, nb * CH);
+        if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, (nb + 2) * CH, li, g);
+        consume(t1, (nb + 1) * CH);
     }
 
     const bool ok = col_ok && tile_ok;
