@@ -109,7 +109,8 @@ __device__ __forceinline__ long mfma_a_operand(const MfmaBatch<WT> &t, int j, in
 }
 
 __host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool gelu_q8) {
-    const size_t act = (size_t)16 * (K + 16) + 2 * (size_t)16 * (K / QK + 1) * 4;
+    const int kp = K > 2048 ? 2048 : K;                                        // staged K phase
+    const size_t act = (size_t)16 * (kp + 16) + 2 * (size_t)16 * (kp / QK + 1) * 4;
     const size_t tail = gelu_q8 ? (size_t)16 * 64 * 4 : 0;
     return (act > tail ? act : tail) + 64;    // the GELU_Q8 exchange reuses the activation area after the last block
 }
@@ -118,7 +119,10 @@ template <int WT, int EPI, int K>
 __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
-    constexpr int CH = MfmaBatch<WT>::CH, BPR = K / QK, NB = BPR / CH, PITCH = K + 16, SP = BPR + 1;   // SP: per-column pitch of the scale arrays (bank skew)
+    // KP: columns of K staged in LDS at a time (K = 4096 goes in two phases: 41 KB instead of 82 KB, so three workgroups
+    // fit a compute unit instead of one; the accumulators simply carry over, block order is unchanged)
+    constexpr int KP = K > 2048 ? 2048 : K, NPH = K / KP, BPP = KP / QK;
+    constexpr int CH = MfmaBatch<WT>::CH, BPR = K / QK, NB = BPP / CH, PITCH = KP + 16, SP = BPP + 1;   // SP: per-column pitch of the scale arrays (bank skew)
     static_assert(NB % 2 == 0, "K must be a multiple of 512");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint8_t *const s_q = smem_raw;                                              // [16 columns][PITCH] int8
@@ -149,33 +153,11 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
     int e_npast = 0;
     if (EPI == EPI_QKV) e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
 
-    // ---- stage the 16 activation columns of this workgroup in LDS (coalesced 16-byte pieces) -------------------
-    {
-        constexpr int PPC = K / 16;                                             // 16-byte pieces per column
-#pragma unroll
-        for (int i = 0; i < 16 * PPC / 256; i++) {
-            const int pc = tid + 256 * i, c = pc / PPC, o = (pc - c * PPC) * 16;
-            const int cc = min(col0 + c, p.N - 1);                              // idle columns re-read the last one
-            *reinterpret_cast<uint4 *>(s_q + c * PITCH + o) = *reinterpret_cast<const uint4 *>(p.aq_q + (size_t)cc * K + o);
-        }
-#pragma unroll
-        for (int i = 0; i < (16 * BPR + 255) / 256; i++) {
-            const int e = tid + 256 * i;
-            if (e < 16 * BPR) {
-                const int c = e / BPR, b = e - c * BPR;
-                const int cc = min(col0 + c, p.N - 1);
-                s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + b];
-                s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + b];
-            }
-        }
-    }
-    __syncthreads();
-
     const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15, k-group g
     const float *bd = s_d + li * SP;
     const uint32_t *bs = s_s + li * SP;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto consume = [&](const MfmaBatch<WT> &t, int b0) {
+    auto consume = [&](const MfmaBatch<WT> &t, int b0) {                        // b0: block index inside the staged phase
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const int b = b0 + j;
@@ -192,11 +174,37 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
         }
     };
 #pragma unroll 1
-    for (int nb = 0; nb < NB; nb += 2) {
-        mfma_load_batch<WT>(t1, img, base, (nb + 1) * CH, li, g);
-        consume(t0, nb * CH);
-        if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, (nb + 2) * CH, li, g);
-        consume(t1, (nb + 1) * CH);
+    for (int ph = 0; ph < NPH; ph++) {
+        // ---- stage this phase of the 16 activation columns in LDS (coalesced 16-byte pieces) ----
+        if (ph > 0) __syncthreads();                                            // the previous phase has been consumed
+        {
+            constexpr int PPC = KP / 16;                                        // 16-byte pieces per column
+#pragma unroll
+            for (int i = 0; i < 16 * PPC / 256; i++) {
+                const int pc = tid + 256 * i, c = pc / PPC, o = (pc - c * PPC) * 16;
+                const int cc = min(col0 + c, p.N - 1);                          // idle columns re-read the last one
+                *reinterpret_cast<uint4 *>(s_q + c * PITCH + o) = *reinterpret_cast<const uint4 *>(p.aq_q + (size_t)cc * K + ph * KP + o);
+            }
+#pragma unroll
+            for (int i = 0; i < (16 * BPP + 255) / 256; i++) {
+                const int e = tid + 256 * i;
+                if (e < 16 * BPP) {
+                    const int c = e / BPP, b = e - c * BPP;
+                    const int cc = min(col0 + c, p.N - 1);
+                    s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
+                    s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + ph * BPP + b];
+                }
+            }
+        }
+        if (ph > 0) mfma_load_batch<WT>(t0, img, base, ph * BPP, li, g);
+        __syncthreads();
+#pragma unroll 1
+        for (int nb = 0; nb < NB; nb += 2) {
+            mfma_load_batch<WT>(t1, img, base, ph * BPP + (nb + 1) * CH, li, g);
+            consume(t0, nb * CH);
+            if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, ph * BPP + (nb + 2) * CH, li, g);
+            consume(t1, (nb + 1) * CH);
+        }
     }
 
     const bool ok = col_ok && tile_ok;
