@@ -1100,12 +1100,15 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
     return n_predict;
 }
 
+static int hp_cols(const biogpt_hip_ctx *c) { return c->hp.n_positions; }   // scratch is sized [n_positions] columns
+
 int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_seqs,
                                      int32_t n_batch, int32_t n_predict, int32_t *out_ids, double *seconds_out) {
     clear_error();
     if (!ctx || !prompts || !prompt_lens || !out_ids) BG_FAIL(-1, "null argument");
     if (!ctx->ready) BG_FAIL(-1, "model has no tensors loaded (empty model): cannot evaluate");
-    if (n_seqs < 1 || n_seqs > 64) BG_FAIL(-1, "n_seqs must be in [1, 64]");
+    if (n_seqs < 1 || n_seqs > 512) BG_FAIL(-1, "n_seqs must be in [1, 512]");   // activation buffers hold n_positions >= 512 columns; each sequence owns a full F32 KV cache
+    if (n_seqs > hp_cols(ctx)) BG_FAIL(-1, "n_seqs (%d) exceeds the %d activation columns of this model", n_seqs, hp_cols(ctx));
     if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
     const auto &hp = ctx->hp;
     const int P = hp.n_positions, D = hp.d_model, V = hp.n_vocab;

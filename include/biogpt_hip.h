@@ -145,7 +145,8 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
  * (per-column arithmetic is unchanged).  No counterpart in the reference (it decodes one sequence); this is
  * the single-GPU form of "independent prompts" sharding.  prompts = the prompts concatenated,
  * prompt_lens[n_seqs] their lengths; n_predict is clamped to n_positions - max(prompt_lens); out_ids is
- * [n_seqs][returned n_predict].  Needs the BioGPT-base fast chain (block-quantized weights). */
+ * [n_seqs][returned n_predict].  Needs the BioGPT-base fast chain (block-quantized weights); n_seqs <= 512 (each
+ * sequence owns a full F32 KV cache: 192 MiB at BioGPT-base); from 48 sequences the chain runs on the int8 matrix cores. */
 int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens,
                                      int32_t n_seqs, int32_t n_batch, int32_t n_predict, int32_t *out_ids,
                                      double *seconds_out);
