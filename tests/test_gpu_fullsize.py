@@ -298,3 +298,32 @@ def test_prompt_pass_full_context(pkg, oracle, files, name):
         for pos in (0, 7, 8, 511, 512, 1000, 1023):
             assert np.abs(kv[:, pos] - ref[:, pos]).max() <= 1e-4, (which, pos)
     g.close()
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[3] <= 300], ids=lambda s: "V%d_L%d_H%d_P%d_F%d_D%d" % s)
+@pytest.mark.parametrize("name", ["f32", "q4_0", "q8_0"])
+def test_prompt_pass_odd_shapes(pkg, oracle, tmp_path_factory, shape, name):
+    """The pass form of prompt ingestion on the generic kernels (shapes the specialised chain does not cover, head sizes
+    32 / 64 / 128, position tables that are not multiples of 64): the whole table as one prompt, -b 4 and -b 7."""
+    V, L, H, P, F, D = shape
+    d = tmp_path_factory.mktemp("oddp")
+    kw = dict(n_vocab=V, n_layer=L, n_head=H, n_positions=P, d_ff=F, d_model=D, n_merges=2)
+    if name == "f32":
+        path = str(d / "f32.bin")
+        pkg.write_synthetic(path, **kw)
+    else:
+        f32 = str(d / "f32.bin")
+        pkg.write_synthetic(f32, **kw)
+        path = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, path, name)
+    rng = np.random.default_rng(P + D)
+    toks = [2] + [int(v) for v in rng.integers(0, V, P - 1)]
+    for nb in (4, 7):
+        g = pkg.BiogptModel.load(path)
+        o = oracle.OracleModel(path, n_threads=8)
+        lo = None
+        for at in range(0, P, nb):
+            lo = o.eval(toks[at:at + nb], at)
+        lg = g.eval_prompt(toks, 0, nb)
+        assert float(np.abs(lg - lo).max()) <= ATOL and int(lg.argmax()) == int(lo.argmax()), (shape, name, nb)
+        g.close()
