@@ -197,6 +197,8 @@ struct biogpt_hip_ctx {
     // batched multi-sequence decode (biogpt_hip_generate_greedy_batch): per-sequence caches + state
     float *bk = nullptr, *bv = nullptr;   // [cap][n_layer][n_head][n_positions][dk]
     bgk::SeqState *seq = nullptr;         // [cap]
+    bgk::SeqState *cols = nullptr;        // column states of a multi-sequence prompt pass
+    size_t cols_cap = 0;
     int32_t *seq_gen = nullptr;           // [cap][n_positions]
     int batch_cap = 0;
     bool mfma_attr_set = false;
@@ -482,7 +484,9 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
     return true;
 }
 
-bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false) {
+// batch: one column per sequence (decode step).  cols != null: the columns are prompt tokens of several sequences
+// (column states with seq_id / t_vis), no lm_head -- the caller gets the logits from the following decode step.
+bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false, const bgk::SeqState *cols = nullptr) {
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
     const int dk = D / H;
@@ -511,7 +515,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
 
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
-                       sqrtf((float)D), c->x, D, batch ? c->seq : nullptr);
+                       sqrtf((float)D), c->x, D, batch ? (cols ? cols : c->seq) : nullptr);
     for (int l = 0; l < hp.n_layer; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
@@ -523,7 +527,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             p.q_out = c->q;
             p.kcache = kroot + (size_t)l * P * D;
             p.vcache = vroot + (size_t)l * P * D;
-            if (batch) { p.seq = c->seq; p.kv_seq_stride = seq_stride; }
+            if (batch) { p.seq = cols ? cols : c->seq; p.col_mode = cols ? 1 : 0; p.kv_seq_stride = seq_stride; }
             p.q_scale = 1.0f / sqrtf((float)dk);
             if (pchain) {
                 HIP_TRY(false, launch_lnq(c, c->x, N, L.ln0_w, L.ln0_b, q81, st));
@@ -536,7 +540,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
         {  // attention
             bgk::AttnParams a{};
             a.q = c->q; a.kcache = kroot + (size_t)l * P * D; a.vcache = vroot + (size_t)l * P * D;
-            if (batch) { a.seq = c->seq; a.kv_seq_stride = seq_stride; }
+            if (batch) { a.seq = cols ? cols : c->seq; a.col_mode = cols ? 1 : 0; a.kv_seq_stride = seq_stride; }
             a.out = c->att; a.st = c->state;
             a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
             a.N = N; a.D = D; a.dk = dk; a.P = P;
@@ -624,6 +628,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             }
         }
     }
+    if (batch && cols) return true;   // prompt columns: only the KV rows matter
     if (batch) {  // every sequence needs its logits row: LayerNorm+Q8 once, then the 8-column mat-vec
         const MatSlot &m = c->plan.lm_head;
         const MvShape s = mv_shape(m.type, m.M, m.K, tw, N);
@@ -828,7 +833,7 @@ void destroy(biogpt_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
-    for (void *p : {(void *)c->bk, (void *)c->bv, (void *)c->seq, (void *)c->seq_gen}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->bk, (void *)c->bv, (void *)c->seq, (void *)c->seq_gen, (void *)c->cols}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1136,7 +1141,11 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
         ctx->batch_cap = n_seqs;
         for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     }
-    if (n_seqs >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && !ensure_tile_images(ctx)) return -2;   // before any graph capture
+    {   // matrix-core chain: decode steps have n_seqs columns, the prompt pass all prompt tokens; build the tiled weights before any graph capture
+        long total = 0;
+        for (int s = 0; s < n_seqs; s++) total += prompt_lens[s];
+        if (std::max<long>(n_seqs, total) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && !ensure_tile_images(ctx)) return -2;
+    }
     if ((size_t)n_seqs > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
         ctx->logits_all = nullptr;
@@ -1149,7 +1158,15 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
         ctx->graph_batch_n = n_seqs;
     }
     std::vector<bgk::SeqState> hs((size_t)n_seqs);
-    for (int s = 0; s < n_seqs; s++) hs[(size_t)s] = bgk::SeqState{prompt_lens[s], 0, 0, 0};
+    for (int s = 0; s < n_seqs; s++) {   // the prompt pass below leaves the LAST prompt token to the first decode step
+        hs[(size_t)s] = bgk::SeqState{};
+        hs[(size_t)s].n_past = prompt_lens[s] - 1;
+        hs[(size_t)s].seq_id = s;
+    }
+    {
+        size_t o = 0;
+        for (int s = 0; s < n_seqs; s++) { o += (size_t)prompt_lens[s]; hs[(size_t)s].token = prompts[o - 1]; }
+    }
     HIP_TRY(-2, hipMemcpy(ctx->seq, hs.data(), sizeof(bgk::SeqState) * n_seqs, hipMemcpyHostToDevice));
 
     auto batch_step = [&](int t_max) -> bool {
@@ -1175,24 +1192,48 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();
-    // prompt ingestion, one sequence after the other, each into its own cache (main.cpp:129-137 per sequence)
-    float *const k0 = ctx->memory_k, *const v0 = ctx->memory_v;
-    size_t off = 0;
-    bool ok = true;
-    for (int s = 0; s < n_seqs && ok; s++) {
-        ctx->memory_k = ctx->bk + (size_t)s * seq_stride;
-        ctx->memory_v = ctx->bv + (size_t)s * seq_stride;
-        const int len = prompt_lens[s];
-        ok = enqueue_prompt(ctx, prompts + off, len, 0, n_batch);
-        if (ok) {  // first sampled token of this sequence
-            hipLaunchKernelGGL(bgk::argmax_rows_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, V, V, ctx->seq, s, ctx->seq_gen, P, 0);
-            ok = hipGetLastError() == hipSuccess;
+    // Prompt ingestion for ALL sequences together (main.cpp:129-137 per sequence): every prompt token is a column that
+    // knows its sequence, its position and the end of its own n_batch-chunk (SeqState::seq_id / n_past / t_vis); whole
+    // chunks are packed into passes of up to BIOGPT_HIP_PROMPT_COLS columns.  The pass only has to fill the KV caches:
+    // the first decode step below re-evaluates each sequence's LAST prompt token (same K/V row, same visible keys as
+    // its chunk gave it) and its arg-max is the first sampled token.
+    {
+        const int max_cols = std::max(std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 512)), n_batch);
+        std::vector<bgk::SeqState> cols;
+        int pass_tmax = 0;
+        auto flush = [&]() -> bool {
+            if (cols.empty()) return true;
+            if (cols.size() > ctx->cols_cap) {
+                if (ctx->cols) (void)hipFree(ctx->cols);
+                ctx->cols = nullptr; ctx->cols_cap = 0;
+                HIP_TRY(false, hipMalloc(&ctx->cols, sizeof(bgk::SeqState) * cols.size()));
+                ctx->cols_cap = cols.size();
+            }
+            HIP_TRY(false, hipMemcpyAsync(ctx->cols, cols.data(), sizeof(bgk::SeqState) * cols.size(), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(false, hipStreamSynchronize(ctx->stream));   // the host vector is reused for the next pass
+            if (!enqueue_forward(ctx, (int)cols.size(), false, pass_tmax, true, ctx->cols)) return false;
+            cols.clear();
+            pass_tmax = 0;
+            return true;
+        };
+        size_t off = 0;
+        for (int s = 0; s < n_seqs; s++) {
+            const int len = prompt_lens[s];
+            for (int at = 0; at < len; at += n_batch) {
+                const int m = std::min(n_batch, len - at);
+                if (!cols.empty() && (int)cols.size() + m > max_cols && !flush()) return -2;
+                for (int i = 0; i < m; i++) {
+                    bgk::SeqState cst{};
+                    cst.n_past = at + i; cst.token = prompts[off + (size_t)(at + i)]; cst.seq_id = s; cst.t_vis = at + m;
+                    cols.push_back(cst);
+                }
+                pass_tmax = std::max(pass_tmax, at + m);
+            }
+            off += (size_t)len;
         }
-        off += (size_t)len;
+        if (!flush()) return -2;
     }
-    ctx->memory_k = k0;
-    ctx->memory_v = v0;
-    if (!ok) return -2;
+    if (!batch_step(max_len)) return -2;   // last prompt token of every sequence -> first sampled token, n_past = prompt length
     for (int k = 1; k < n_predict; k++) {  // batched decode: one column per sequence
         const int t_max = max_len + k;
         if (use_graph) HIP_TRY(-2, hipGraphLaunch(ctx->graph_batch[graph_bucket(t_max)], ctx->stream));

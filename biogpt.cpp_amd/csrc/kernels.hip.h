@@ -69,10 +69,12 @@ __device__ __forceinline__ int32_t *state_tokens(DevState *st) { return reinterp
 // Per-sequence decode state for batched multi-sequence decode (one activation column per sequence):
 // its own position, current token and output count; kernels index it by column.
 struct SeqState {
-    int32_t n_past;
+    int32_t n_past;   // position of this column's token
     int32_t token;
     int32_t n_gen;
-    int32_t pad;
+    int32_t seq_id;   // which sequence's KV cache (batched decode: column i = sequence i)
+    int32_t t_vis;    // keys this column may see; 0 = n_past + 1 (decode).  Prompt columns of several sequences
+    int32_t pad[3];   //   travelling together carry the end of their own reference chunk here (col_mode = 1)
 };
 
 struct DevMatrix {
@@ -225,6 +227,7 @@ struct MatvecParams {
     float q_scale;
     const DevState *st;
     const SeqState *seq;       // batched decode: per-column position (null: columns are consecutive positions of one sequence)
+    int32_t col_mode;          // 1: columns are prompt tokens of several sequences (use seq_id / t_vis of the column state)
     int64_t kv_seq_stride;     // floats between two sequences' caches
     // EPI_GELU
     const uint16_t *gelu_tab;
@@ -668,6 +671,7 @@ struct AttnParams {
     int8_t *oq_q; float *oq_d; uint32_t *oq_s;  // optional Q8 copy of the output for the fast out_proj (null: off)
     int32_t q81;                  // 1: Q8_1 activation form (Q4_1 / Q5_1 weights), 0: Q8_0
     const SeqState *seq;          // batched decode: query row i belongs to sequence i (own cache + position)
+    int32_t col_mode;             // 1: query rows are prompt tokens of several sequences (seq_id / t_vis per row)
     int64_t kv_seq_stride;
     float *sp_scores; float *sp_max; double *sp_pv; int32_t n_split;   // key-split decode attention scratch: [H][P], [H][16], [H][16][64]
     unsigned long long *tstamp;  // profiling (dbg & 32): [16 waves][8] stamps of block (0,0)

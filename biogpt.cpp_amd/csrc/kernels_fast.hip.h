@@ -109,11 +109,14 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     const int f_row = row_base + f_r;
     const bool finisher = lane < rpw * ncols && f_row < M;
     float e_bias = 0.0f, e_res = 0.0f;
-    int e_npast = 0;
+    int e_npast = 0, e_seq = 0;
     if (finisher) {
         if (EPI != EPI_LOGITS) e_bias = p.bias[f_row];
         if (EPI == EPI_RESID) e_res = p.resid[(size_t)(col0 + f_c) * p.ldr + f_row];
-        if (EPI == EPI_QKV) e_npast = p.seq ? p.seq[col0 + f_c].n_past : p.st->n_past + col0 + f_c;   // cache row of this column
+        if (EPI == EPI_QKV) {   // cache row (and, for columns of several sequences, cache) of this column
+            e_npast = p.seq ? p.seq[col0 + f_c].n_past : p.st->n_past + col0 + f_c;
+            e_seq = (p.seq && p.col_mode) ? p.seq[col0 + f_c].seq_id : col0 + f_c;
+        }
     }
 
     // ---- LayerNorm statistics (ggml_norm: double sums; per wave over the whole column) ----------
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
             if (which == 0) {
                 p.q_out[(size_t)col * K + rr] = __fmul_rn(v, p.q_scale);
             } else {
-                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)col * p.kv_seq_stride : 0);
+                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq * p.kv_seq_stride : 0);
                 const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);  // head-major cache: [H][P][dk], dk = 2^k
                 cache[(((size_t)hh * p.P + e_npast) << p.dk_log2) + dd] = v;
             }
@@ -445,7 +448,8 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
 
     // lane ksub of a quad owns float4 #(4m + ksub) of the 16 float4 of a key row: each load instruction
     // of a quad covers 64 contiguous bytes
-    const size_t seq_off = p.seq ? (size_t)i * p.kv_seq_stride : 0;   // batched decode: query row i = sequence i
+    // batched decode: query row i = sequence i; prompt columns of several sequences name their sequence (one more dependent load)
+    const size_t seq_off = p.seq ? (size_t)(p.col_mode ? p.seq[i].seq_id : i) * p.kv_seq_stride : 0;
     const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + seq_off + (size_t)h * p.P * DK) + ksub;   // [H][P][dk]
     const float *__restrict__ vbase = p.vcache + seq_off + (size_t)h * p.P * DK + d;
     const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)i * D + (size_t)h * DK) + ksub;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(1024) void attn_fast_kernel(const AttnParams p) {
         }
     }
     AT_STAMP(1);
-    const int T = p.seq ? n_past + 1 : visible_keys(p.st, i, p.N);
+    const int T = p.seq ? (p.col_mode ? p.seq[i].t_vis : n_past + 1) : visible_keys(p.st, i, p.N);
 
     // ---- scores: 16 dims per lane, quad reduce ----
     float sc[KP];

@@ -150,8 +150,11 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
     float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res = e_bias;
     if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc);
     if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc * p.ldr + orc);
-    int e_npast = 0;
-    if (EPI == EPI_QKV) e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
+    int e_npast = 0, e_seq = 0;
+    if (EPI == EPI_QKV) {
+        e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
+        e_seq = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
+    }
 
     const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15, k-group g
     const float *bd = s_d + li * SP;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
                 v.x = __fmul_rn(v.x, p.q_scale); v.y = __fmul_rn(v.y, p.q_scale); v.z = __fmul_rn(v.z, p.q_scale); v.w = __fmul_rn(v.w, p.q_scale);
                 *reinterpret_cast<float4 *>(p.q_out + (size_t)col * K + rr) = v;
             } else {
-                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)col * p.kv_seq_stride : 0);
+                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq * p.kv_seq_stride : 0);
                 const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);       // head-major cache: [H][P][dk]; 4 | dk
                 *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast) << p.dk_log2) + dd) = v;
             }

@@ -327,3 +327,22 @@ def test_prompt_pass_odd_shapes(pkg, oracle, tmp_path_factory, shape, name):
         lg = g.eval_prompt(toks, 0, nb)
         assert float(np.abs(lg - lo).max()) <= ATOL and int(lg.argmax()) == int(lo.argmax()), (shape, name, nb)
         g.close()
+
+
+@pytest.mark.parametrize("cols", [16, 512])
+@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+def test_batched_prompts_travel_together(pkg, oracle, files, monkeypatch, name, cols):
+    """generate_greedy_batch ingests the prompts of all sequences in common passes (every token a column that knows its
+    sequence, position and the end of its own n_batch-chunk): prompts of 1 .. 61 tokens, -b 4 (several ragged chunks per
+    sequence), packed into passes of 16 columns (many passes, chunk-aligned cuts) or one pass.  Ids per sequence must
+    equal the oracle's single-stream ids with the same -b."""
+    monkeypatch.setenv("BIOGPT_HIP_PROMPT_COLS", str(cols))
+    g = pkg.BiogptModel.load(files[name])
+    rng = np.random.default_rng(31)
+    lens = [1, 4, 9, 17, 26, 5, 61, 2, 33, 12]
+    prompts = [[2] + [int(v) for v in rng.integers(4, KW["n_vocab"], n - 1)] for n in lens]
+    ids, _ = g.generate_greedy_batch(prompts, 6, n_batch=4)
+    for s in range(len(prompts)):
+        ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompts[s], 6, n_batch=4)
+        assert list(ids[s]) == list(ref), (name, cols, s, lens[s])
+    g.close()
