@@ -275,7 +275,7 @@ def main():
             # (configs[1] is single-stream), reported because it is what the HBM-bound regime of this chip looks like
             if args.ftype.startswith("q"):
                 ms = {}
-                for S in (8, 32, 64):       # 64: enough columns for the int8 matrix-core chain (kernels_mfma.hip.h)
+                for S in (8, 32, 64, 256):  # from 48 sequences the chain runs on the int8 matrix cores (kernels_mfma.hip.h)
                     prompts = [make_prompt(hp.n_vocab, 9000 + i) for i in range(S)]
                     model.generate_greedy_batch(prompts, 8, n_batch=8)            # warm-up: allocations + graph capture
                     ids_b, secs_b = model.generate_greedy_batch(prompts, n_predict, n_batch=8)
