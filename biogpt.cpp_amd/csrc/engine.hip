@@ -571,6 +571,11 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(H), dim3(64), 0, st, a);
+                } else if (batch && N >= env_int("BIOGPT_HIP_ATTN_SLIM_MIN", 48)) {
+                    // many (sequence, head) workgroups: throughput over latency -- one lane quad per 4 keys (4 key passes), a
+                    // quarter of the threads, four times as many workgroups resident per compute unit
+                    const int t64 = (a.t_cap + 63) & ~63;
+                    hipLaunchKernelGGL((bgk::attn_fast_kernel<4, false>), dim3(H, N), dim3(std::max(256, t64)), 0, st, a);
                 } else if (a.t_cap <= 256) {
                     hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(H, N), dim3(4 * ((a.t_cap + 63) & ~63)), 0, st, a);
                 } else if (a.t_cap <= 512) {
