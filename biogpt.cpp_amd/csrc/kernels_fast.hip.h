@@ -391,7 +391,7 @@ __host__ __device__ inline size_t attn_group_main_bytes(int t_cap, int g = 8) {
     const size_t sc = (size_t)g * t_cap * 4, po = (size_t)8 * g * 64 * 8;
     return sc > po ? sc : po;
 }
-__host__ __device__ inline size_t attn_group_smem_bytes(int t_cap, int g = 8) { return attn_group_main_bytes(t_cap, g) + 64; }
+__host__ __device__ inline size_t attn_group_smem_bytes(int t_cap, int g = 8) { return attn_group_main_bytes(t_cap, g) + (size_t)g * 64 * 4 + 64; }
 
 // One head's 64 outputs, held one per lane by wave 0: F32 row for the reference layout and, for the fast
 // out_proj, the two Q8 blocks of its activation row (amax / roundf / block sum as quantize_row_q8_0/_1).
@@ -706,13 +706,13 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
         Tq[q] = (i0 + q < N) ? visible_keys(p.st, i0 + q, N) : 0;
         Tmax = max(Tmax, Tq[q]);
     }
-    float4 qv[G][4];
-#pragma unroll
-    for (int q = 0; q < G; q++) {
-        const float4 *qp = reinterpret_cast<const float4 *>(p.q + (size_t)min(i0 + q, N - 1) * D + (size_t)h * DK) + ksub;
-#pragma unroll
-        for (int m = 0; m < 4; m++) qv[q][m] = qp[4 * m];
+    // the G query rows of this head live in LDS (2 KB): holding them in registers costs 128 VGPRs and halves the occupancy
+    float *const s_q = reinterpret_cast<float *>(smem_raw + attn_group_main_bytes(t_cap));   // [G][DK]
+    {
+        const int q = tid >> 6, dd = tid & 63;                                // 512 threads = G x 64 values
+        s_q[tid] = p.q[(size_t)min(i0 + q, N - 1) * D + (size_t)h * DK + dd];
     }
+    __syncthreads();
     // ---- scores: 4 lanes per key, KPP keys per trip ----
     const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + ksub;
     for (int j0 = 0; j0 < Tmax; j0 += KPP) {
@@ -726,8 +726,9 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                a0 += (double)__fmul_rn(kr[m].x, qv[q][m].x); a1 += (double)__fmul_rn(kr[m].y, qv[q][m].y);
-                a2 += (double)__fmul_rn(kr[m].z, qv[q][m].z); a3 += (double)__fmul_rn(kr[m].w, qv[q][m].w);
+                const float4 qm = *reinterpret_cast<const float4 *>(s_q + q * DK + 16 * m + 4 * ksub);   // dims of float4 #(4m + ksub)
+                a0 += (double)__fmul_rn(kr[m].x, qm.x); a1 += (double)__fmul_rn(kr[m].y, qm.y);
+                a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
             }
             double acc = (a0 + a1) + (a2 + a3);
             acc += dpp_d<DPP_QUAD_XOR1>(acc);
