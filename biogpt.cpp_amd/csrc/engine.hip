@@ -504,7 +504,8 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                        !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
     const bool pchain = chain && (N > 1 || batch);   // several columns: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
     // enough columns to fill 16-wide MFMA tiles: the chain runs on the int8 matrix cores from the row-tiled weight image
-    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && c->tile_img != nullptr;
+    // (measured cross-overs: decode steps of S sequences 48; prompt passes 64 columns)
+    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", (batch && !cols) ? 48 : 64) && c->tile_img != nullptr;
     bgk::DevMatrix img;
     auto tile = [&](const MatSlot &m) -> const bgk::DevMatrix * { if (!mfma) return nullptr; img = tile_matrix(c, m); return &img; };
     if (batch && !chain) BG_FAIL(false, "batched decode needs the BioGPT-base fast chain (block-quantized weights, d_model 1024, d_ff 4096, head size 64)");
@@ -555,7 +556,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     c->mfma_attr_set = true;
                 }
                 hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
-            } else if (!batch && dk == 64 && t_max <= 1024 && N >= env_int("BIOGPT_HIP_ATTN_GROUP_MIN", 32) && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+            } else if (!batch && dk == 64 && t_max <= 1024 && N >= env_int("BIOGPT_HIP_ATTN_GROUP_MIN", 80) && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
                 // a pass of many query columns: one workgroup per (head, 8 queries) shares every K / V row it loads
                 a.t_cap = std::min(P, t_max);
                 hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
@@ -1049,7 +1050,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
 bool enqueue_prompt(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, int n_batch, int *last_cols = nullptr) {
     const int max_cols = std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 512));   // measured (Q4_0, -b 8, 512-token prompt): 16 -> 17.9k, 64 -> 36k, 128 -> 66k, 256 -> 87k, 512 -> 97k prompt tok/s
     const int group = n_batch >= max_cols ? n_batch : (max_cols / n_batch) * n_batch;   // whole chunks per pass
-    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
+    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 64) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
     for (int at = 0; at < n;) {
         const int m = std::min(group, n - at);
         if (!upload_state(c, tokens + at, m, n_past + at, m > n_batch ? n_batch : 0)) return false;

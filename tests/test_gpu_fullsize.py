@@ -259,13 +259,13 @@ def test_prompt_pass_full_shape(pkg, oracle, files, monkeypatch, name, cols):
 
 @pytest.mark.parametrize("name", ["q4_0", "q4_1", "q5_0", "q8_0"])
 def test_batched_decode_on_the_matrix_cores(pkg, oracle, files, name):
-    """40 sequences decoded together: enough columns for the int8-MFMA chain (16-wide tiles, row-tiled weight image).
+    """52 sequences decoded together: enough columns for the int8-MFMA chain (16-wide tiles, row-tiled weight image).
     Every sequence's ids must equal the oracle's single-stream ids, like in the 8-column path."""
     g = pkg.BiogptModel.load(files[name])
     rng = np.random.default_rng(21)
-    prompts = [[2] + [int(v) for v in rng.integers(4, KW["n_vocab"], int(rng.integers(2, 7)))] for _ in range(40)]
+    prompts = [[2] + [int(v) for v in rng.integers(4, KW["n_vocab"], int(rng.integers(2, 7)))] for _ in range(52)]
     ids, _ = g.generate_greedy_batch(prompts, 7)
-    for s in (0, 7, 19, 39):
+    for s in (0, 7, 19, 51):
         ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompts[s], 7)
         assert list(ids[s]) == list(ref), (name, s)
     single = pkg.BiogptModel.load(files[name])
