@@ -74,23 +74,39 @@ struct MfmaBatch {                       // one lane's weight-side operands for 
     uint32_t qh[CH];                     // Q5: fifth bits of the lane's A row
 };
 
-// image addressing: `base` = (tile * BPR) * 16, block b adds b * 16
+// this lane's three image pointers at block 0 of its tile; block b is a CONSTANT stride further (256 / 512 bytes of
+// quants, 32 / 64 bytes of scales, 64 bytes of fifth bits), so a batch is one base address plus immediate offsets
 template <int WT>
-__device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const DevMatrix &img, int64_t base, int b0, int li, int g) {
+struct MfmaLanePtrs {
+    const uint8_t *q, *sc;
+    const uint32_t *qh;
+};
+template <int WT>
+__device__ __forceinline__ MfmaLanePtrs<WT> mfma_lane_ptrs(const DevMatrix &img, int64_t base, int li, int g) {
     using TI = TypeInfo<WT>;
+    MfmaLanePtrs<WT> p;
+    p.q = (WT == W_Q8_0) ? img.qs + (base + li) * 32 + 8 * g : img.qs + (base + li) * 16 + 8 * (g & 1);
+    p.sc = img.sc + (base + 4 * g) * (TI::q81 ? 4 : 2);
+    p.qh = img.qh + base + li;
+    return p;
+}
+template <int WT>
+__device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const MfmaLanePtrs<WT> &lp, int b0) {
+    using TI = TypeInfo<WT>;
+    constexpr int QS = (WT == W_Q8_0) ? 512 : 256, SS = TI::q81 ? 64 : 32;   // bytes per block of one tile
+    const uint8_t *q = lp.q + (size_t)b0 * QS, *sc = lp.sc + (size_t)b0 * SS;
+    const uint32_t *qh = lp.qh + (size_t)b0 * 16;
 #pragma unroll
     for (int j = 0; j < MfmaBatch<WT>::CH; j++) {
-        const int64_t e = base + (int64_t)(b0 + j) * 16;                     // first of the tile's 16 entries of this block
-        if (WT == W_Q8_0) t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 32 + 8 * g);
-        else t.q[j] = *reinterpret_cast<const uint2 *>(img.qs + (e + li) * 16 + 8 * (g & 1));
+        t.q[j] = *reinterpret_cast<const uint2 *>(q + j * QS);
         if (TI::q81) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(img.sc + (e + 4 * g) * 4);
+            const uint4 v = *reinterpret_cast<const uint4 *>(sc + j * SS);
             t.sc[j][0] = v.x; t.sc[j][1] = v.y; t.sc[j][2] = v.z; t.sc[j][3] = v.w;
         } else {
-            const uint2 v = *reinterpret_cast<const uint2 *>(img.sc + (e + 4 * g) * 2);
+            const uint2 v = *reinterpret_cast<const uint2 *>(sc + j * SS);
             t.sc[j][0] = v.x; t.sc[j][1] = v.y;
         }
-        if (WT == W_Q5_0 || WT == W_Q5_1) t.qh[j] = img.qh[e + li];
+        if (WT == W_Q5_0 || WT == W_Q5_1) t.qh[j] = qh[j * 16];
     }
 }
 
@@ -143,8 +159,9 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
     const int colc = min(col, p.N - 1);
     const int orow = row0 + 4 * g;                                              // outputs: rows 4g .. 4g+3, column lane & 15
 
+    const MfmaLanePtrs<WT> lp = mfma_lane_ptrs<WT>(img, base, li, g);
     MfmaBatch<WT> t0, t1;
-    mfma_load_batch<WT>(t0, img, base, 0, li, g);
+    mfma_load_batch<WT>(t0, lp, 0);
     // epilogue inputs (independent loads); M is a multiple of 4 everywhere
     const int orc = min(orow, M - 4);
     float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res = e_bias;
@@ -199,13 +216,13 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
                 }
             }
         }
-        if (ph > 0) mfma_load_batch<WT>(t0, img, base, ph * BPP, li, g);
+        if (ph > 0) mfma_load_batch<WT>(t0, lp, ph * BPP);
         __syncthreads();
 #pragma unroll 1
         for (int nb = 0; nb < NB; nb += 2) {
-            mfma_load_batch<WT>(t1, img, base, ph * BPP + (nb + 1) * CH, li, g);
+            mfma_load_batch<WT>(t1, lp, ph * BPP + (nb + 1) * CH);
             consume(t0, nb * CH);
-            if (nb + 2 < NB) mfma_load_batch<WT>(t0, img, base, ph * BPP + (nb + 2) * CH, li, g);
+            if (nb + 2 < NB) mfma_load_batch<WT>(t0, lp, ph * BPP + (nb + 2) * CH);
             consume(t1, (nb + 1) * CH);
         }
     }
