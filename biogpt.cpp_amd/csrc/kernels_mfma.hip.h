@@ -21,9 +21,10 @@
 //   * weights: a second, ROW-TILED copy of the matrix (retile_kernel, built once on first use): the 16 rows of
 //     a tile are contiguous per block, so an A-operand load of a wave covers 256 contiguous bytes and the four
 //     scales a lane needs are 8 contiguous bytes;
-//   * activations: the 16 columns of the workgroup are staged once into LDS with coalesced 16-byte loads and
-//     shared by its 4 waves (= 4 row tiles); the row pitch K + 16 bytes makes the 8-byte operand reads
-//     conflict-free (4 lanes per bank pair, the minimum for 512 bytes).
+//   * activations: the 16 columns of the workgroup are staged in LDS with coalesced 16-byte loads (up to 2048
+//     elements of K at a time: K = 4096 goes in two phases, 41 KB, three workgroups per compute unit) and shared
+//     by its 4 waves (= 4 row tiles); the row pitch + 16 bytes makes the 8-byte operand reads conflict-free
+//     (4 lanes per bank pair, the minimum for 512 bytes).
 // Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)).  A loads are batched 4 blocks at a
 // time and double-buffered against the arithmetic.
 #pragma once
