@@ -110,3 +110,32 @@ def test_greedy_harness_counts(oracle, tiny_models):
     # n_predict is clamped to n_positions - len(prompt) (main.cpp:82)
     ids2, _ = oracle.OracleModel(tiny_models["q8_0"]).generate_greedy([2] * 60, 200)
     assert len(ids2) == 4
+
+
+@pytest.mark.parametrize("name,type_id", [("q4_0", 2), ("q4_1", 3), ("q5_0", 6), ("q5_1", 7), ("q8_0", 8)])
+def test_quantized_modes_compute_the_dequantized_model(oracle, tiny_models, tmp_path, name, type_id):
+    """Semantic bound for the W x A8 integer path (whose exact ggml arithmetic is unpinned): evaluating a quantized file
+    must equal, up to the activation quantization (one Q8 rounding per 32-element block), evaluating a FLOAT file that
+    holds the dequantized weights.  Independent of the block-dot code: the float file goes through the f32 mat-mul."""
+    from modelfile_py import read_model, write_model
+    hp, vocab, merges, tensors = read_model(tiny_models[name])
+    ft = []
+    for t in tensors:
+        if t["type"] in (0, 1):
+            ft.append(t)
+            continue
+        k, rows = t["ne"][0], t["ne"][1]
+        raw = np.frombuffer(t["raw"], dtype=np.uint8)
+        rb = len(raw) // rows
+        w = np.stack([oracle.dequantize_row(type_id, raw[r * rb:(r + 1) * rb].copy(), k) for r in range(rows)])
+        ft.append(dict(name=t["name"], type=0, ne=t["ne"], raw=w.astype(np.float32).tobytes()))
+    fpath = str(tmp_path / "deq.bin")
+    write_model(fpath, dict(hp, ftype=0), vocab, merges, ft)
+    q, f = oracle.OracleModel(tiny_models[name]), oracle.OracleModel(fpath)
+    toks = np.array([2, 17, 45, 300, 9, 128, 64, 255, 31, 7], dtype=np.int32)
+    worst, scale = 0.0, 0.0
+    for j in range(len(toks)):
+        lq, lf = q.eval(toks[j:j + 1], j), f.eval(toks[j:j + 1], j)
+        worst, scale = max(worst, float(np.abs(lq - lf).max())), max(scale, float(np.abs(lf).max()))
+    assert worst < 0.02 * scale + 1e-3, (name, worst, scale)       # ~1/127 per rounding, averaged over a row
+    assert worst > 0.0                                              # and it is NOT the float path in disguise
