@@ -279,7 +279,11 @@ def main():
                     prompts = [make_prompt(hp.n_vocab, 9000 + i) for i in range(S)]
                     model.generate_greedy_batch(prompts, 8, n_batch=8)            # warm-up: allocations + graph capture
                     ids_b, secs_b = model.generate_greedy_batch(prompts, n_predict, n_batch=8)
-                    ms["S=%d" % S] = {"tokens_per_s": round(S * n_predict / secs_b, 1), "ms_per_step_all_seqs": round(secs_b / n_predict * 1e3, 4)}
+                    # algorithmic HBM bytes of the run: weights once per step + every sequence's KV read/write and logits row
+                    w_bytes = pkg.decode_bytes_per_token(hp, 0) - (2 * hp.n_layer * hp.d_model * 4 + hp.n_vocab * 4)   # weights only
+                    run_bytes = sum(w_bytes + S * (pkg.decode_bytes_per_token(hp, 4 + k) - w_bytes) for k in range(1, n_predict + 1))
+                    ms["S=%d" % S] = {"tokens_per_s": round(S * n_predict / secs_b, 1), "ms_per_step_all_seqs": round(secs_b / n_predict * 1e3, 4),
+                                      "GBps": round(run_bytes / secs_b / 1e9, 1), "frac_of_peak": round(run_bytes / secs_b / 1e9 / HBM_PEAK_GBS, 4)}
                 out["multi_stream"] = ms
             # prompt ingestion (configs[2] in short): a 512-token prompt with -b 8 semantics through biogpt_hip_eval_prompt
             rngp = np.random.default_rng(7000)
