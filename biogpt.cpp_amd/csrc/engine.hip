@@ -180,6 +180,7 @@ struct biogpt_hip_ctx {
     float *aq_d[3] = {nullptr, nullptr, nullptr};
     uint32_t *aq_s[3] = {nullptr, nullptr, nullptr};
     float *logits = nullptr;      // [n_vocab]
+    float *logits_host = nullptr; // pinned staging for biogpt_hip_eval
     float *logits_all = nullptr;  // lazily [n][n_vocab]
     size_t logits_all_rows = 0;
     float *pmax_val = nullptr;
@@ -1018,8 +1019,12 @@ int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32
     if (!logits_out) BG_FAIL(-1, "null logits buffer");
     const int rc = biogpt_hip_eval_device(ctx, tokens, n, n_past);
     if (rc) return rc;
-    HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // device -> pinned staging -> caller's (pageable) buffer: one DMA instead of the runtime's chunked staging
+    const size_t bytes = (size_t)ctx->hp.n_vocab * 4;
+    if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), bytes, hipHostMallocDefault));
+    HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    std::memcpy(logits_out, ctx->logits_host, bytes);
     return 0;
 }
 
