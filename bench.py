@@ -185,6 +185,11 @@ def main():
 
     total_tokens = world * args.steps * (n_prompt if prefill else n_predict)
     value = total_tokens / elapsed
+    dump = os.environ.get("BIOGPT_BENCH_DUMP_IDS")   # tests: the last timed continuation of this rank, for the oracle to check
+    if dump and not prefill and last_ids is not None:
+        unit = (args.warmup + args.steps - 1) * world + rank
+        with open("%s.rank%d" % (dump, rank), "w") as f:
+            json.dump({"model": path if rank == 0 else None, "prompt": make_prompt(hp.n_vocab, unit), "ids": [int(v) for v in last_ids]}, f)
 
     if rank != 0:
         if dist is not None:
@@ -333,10 +338,16 @@ def main():
         except Exception as e:
             out["cpu_baseline_error"] = str(e)
 
-    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints its banner through C stdio: flush that first so that the JSON line is the LAST line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbiogpt_hip.so")
+LIB_PATH = os.environ.get("BIOGPT_HIP_LIB") or os.path.join(_HERE, "libbiogpt_hip.so")   # override: profiling builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 FTYPES = {"f32": 0, "f16": 1, "q4_0": 2, "q4_1": 3, "q8_0": 7, "q5_0": 8, "q5_1": 9}
@@ -67,6 +67,7 @@ SYMBOLS = [
     ("biogpt_hip_arena_ptr", _P, [_P]),
     ("biogpt_hip_arena_bytes", C.c_size_t, [_P]),
     ("biogpt_hip_free", None, [_P]),
+    ("biogpt_hip_refresh_options", C.c_int, [_P]),
     ("biogpt_hip_get_hparams", C.c_int, [_P, C.POINTER(HParams)]),
     ("biogpt_hip_n_tensors", C.c_int, [_P]),
     ("biogpt_hip_vocab_token", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
@@ -351,6 +352,11 @@ class BiogptModel:
         if lib().biogpt_hip_bench_stream(self._h, int(rows), int(reps), int(steps), C.byref(secs), C.byref(nbytes)) != 0:
             raise BiogptError(_err())
         return secs.value, nbytes.value
+
+    def refresh_options(self):
+        """Re-read the BIOGPT_HIP_* switches (they are cached at load time) and drop the captured graphs."""
+        if lib().biogpt_hip_refresh_options(self._h) != 0:
+            raise BiogptError(_err())
 
     def bench_decode(self, n_past, reps=50):
         secs = C.c_double(0.0)

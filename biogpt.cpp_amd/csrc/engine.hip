@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +28,7 @@
 #include "kernels.hip.h"
 #include "kernels_fast.hip.h"
 #include "kernels_mfma.hip.h"
+#include "kernels_decode.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
 
@@ -159,8 +161,43 @@ int env_int(const char *name, int dflt) {
 
 }  // namespace
 
+// Tuning / debugging switches.  Read from the environment ONCE, when a context is created (and again only on
+// biogpt_hip_refresh_options): no getenv on any launch path.
+struct EngineOptions {
+    int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min, prefill_mfma,
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves;
+    void load() {
+        auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
+        mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
+        max_wgs = get("BIOGPT_HIP_MAX_WGS", 1024);
+        tree_reduce = get("BIOGPT_HIP_TREE_REDUCE", 0);
+        lm_steps = get("BIOGPT_HIP_LM_STEPS", 8);
+        fast_steps = get("BIOGPT_HIP_FAST_STEPS", 1);
+        no_fast = get("BIOGPT_HIP_NO_FAST", 0);
+        no_chain = get("BIOGPT_HIP_NO_CHAIN", 0);
+        mfma_min_cols = get("BIOGPT_HIP_MFMA_MIN_COLS", -1);      // -1: measured cross-overs (48 decode columns / 64 prompt columns)
+        attn_group_min = get("BIOGPT_HIP_ATTN_GROUP_MIN", 80);
+        prefill_mfma = get("BIOGPT_HIP_PREFILL_MFMA", 0);
+        split_min = get("BIOGPT_HIP_SPLIT_MIN", 256);
+        attn_slim_min = get("BIOGPT_HIP_ATTN_SLIM_MIN", 48);
+        dbg = get("BIOGPT_HIP_DBG", 0);
+        target_wgs = get("BIOGPT_HIP_TARGET_WGS", 256);
+        prompt_cols = get("BIOGPT_HIP_PROMPT_COLS", 512);
+        no_graph = get("BIOGPT_HIP_NO_GRAPH", 0);
+        causal = get("BIOGPT_HIP_CAUSAL", 0);
+        no_fused_decode = get("BIOGPT_HIP_NO_FUSED_DECODE", 0);
+        fc1_blocks = get("BIOGPT_HIP_FC1_BLOCKS", 1);
+        fc2_waves = get("BIOGPT_HIP_FC2_WAVES", 16);
+    }
+    int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
+};
+
+namespace {
+}  // namespace
+
 // ---- context ----------------------------------------------------------------------------------------
 struct biogpt_hip_ctx {
+    EngineOptions opt{};
     biogpt_hip_hparams hp{};
     int device = 0;
     int n_tensors = 0;
@@ -203,6 +240,10 @@ struct biogpt_hip_ctx {
     int32_t *seq_gen = nullptr;           // [cap][n_positions]
     int batch_cap = 0;
     bool mfma_attr_set = false;
+    std::set<const void *> lds_attr_done;     // kernels whose > 64 KB dynamic-LDS opt-in attribute is set on this device
+    unsigned long long *tstamp = nullptr;     // profiling only (opt.dbg & 32)
+    int launch_parity = 0;
+    float *terms = nullptr;                   // fused decode step: out_proj block terms [32][1024]
     hipGraphExec_t graph_batch[6] = {};   // [context bucket], captured for graph_batch_n sequences
     int graph_batch_n = 0;
 
@@ -228,8 +269,10 @@ bgk::DevMatrix dev_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
 const float *dev_vec(const biogpt_hip_ctx *c, size_t off) { return reinterpret_cast<const float *>(c->arena + off); }
 
 struct MvShape { int upr, lpr_log2, nit, rpw, nwaves, grid; };
-unsigned long long *g_tstamp = nullptr;  // profiling only (BIOGPT_HIP_DBG & 32)
-int g_launch_parity = 0;
+// the context whose launches the calling thread is enqueueing (set at every entry point that launches): the launch
+// helpers below read its cached options and per-device state -- one host thread drives one device at a time
+thread_local biogpt_hip_ctx *t_ctx = nullptr;
+const EngineOptions &opt() { return t_ctx->opt; }
 
 MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs, int N = 1) {
     MvShape s;
@@ -240,10 +283,10 @@ MvShape mv_shape(int32_t type, int64_t M, int64_t K, int target_wgs, int N = 1) 
     s.nit = (s.upr + lpr - 1) / lpr;
     const int rps = 64 / lpr;
     // waves per workgroup: as many as possible (up to 4) while keeping >= target_wgs workgroups
-    int nw = env_int("BIOGPT_HIP_MV_WAVES", 4);
+    int nw = opt().mv_waves;
     while (nw > 1 && (M + (int64_t)nw * rps - 1) / ((int64_t)nw * rps) < target_wgs) nw >>= 1;
     int steps = 1;
-    const int max_wgs = env_int("BIOGPT_HIP_MAX_WGS", 1024);
+    const int max_wgs = opt().max_wgs;
     // one finisher lane per (row, column) of a wave: rows_per_wave * columns <= 64
     (void)N;
     while ( (M + (int64_t)nw * rps * steps - 1) / ((int64_t)nw * rps * steps) > max_wgs) steps++;
@@ -260,7 +303,7 @@ hipError_t launch_mv_kch(const bgk::MatvecParams &p, const MvShape &s, hipStream
     const int need = (PRO == bgk::PRO_LN || NC > 1) ? njj : (njj + s.nwaves - 1) / s.nwaves;  // chunks a wave holds per column
     const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NC, s.upr, s.rpw, s.nwaves);
     const int gy = (p.N + NC - 1) / NC;
-    const bool seq = env_int("BIOGPT_HIP_TREE_REDUCE", 0) == 0;  // default: the reference's block order (bit parity)
+    const bool seq = opt().tree_reduce == 0;  // default: the reference's block order (bit parity)
     if (need <= 4) {
         if (seq) hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, true>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
         else hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, false>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
@@ -287,7 +330,7 @@ template <int WT, int PRO, int EPI, int K>
 hipError_t launch_fast_k(bgk::MatvecParams p, hipStream_t st) {
     constexpr int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
     const int M = p.W.M;
-    int steps = (EPI == bgk::EPI_LOGITS) ? env_int("BIOGPT_HIP_LM_STEPS", 8) : env_int("BIOGPT_HIP_FAST_STEPS", 1);
+    int steps = (EPI == bgk::EPI_LOGITS) ? opt().lm_steps : opt().fast_steps;
     while (steps > 1 && (M + 4 * RPS * steps - 1) / (4 * RPS * steps) < 128) steps >>= 1;  // keep the chip covered
     p.rpw = RPS * steps;
     const int grid = (M + 4 * p.rpw - 1) / (4 * p.rpw);
@@ -299,7 +342,7 @@ hipError_t launch_fast_k(bgk::MatvecParams p, hipStream_t st) {
 
 template <int WT, int PRO, int EPI>
 bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err, int *grid_out) {
-    if (p.N != 1 || env_int("BIOGPT_HIP_NO_FAST", 0)) return false;
+    if (p.N != 1 || opt().no_fast) return false;
     const int K = p.W.K;
     if (EPI == bgk::EPI_QKV && p.D != K) return false;
     if (K == 1024) {
@@ -312,7 +355,7 @@ bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err
     }
     if (grid_out) {
         const int BPR = K / 32, LPR = BPR < 64 ? BPR : 64, RPS = 64 / LPR;
-        int steps = (EPI == bgk::EPI_LOGITS) ? env_int("BIOGPT_HIP_LM_STEPS", 8) : env_int("BIOGPT_HIP_FAST_STEPS", 1);
+        int steps = (EPI == bgk::EPI_LOGITS) ? opt().lm_steps : opt().fast_steps;
         while (steps > 1 && (p.W.M + 4 * RPS * steps - 1) / (4 * RPS * steps) < 128) steps >>= 1;
         *grid_out = (p.W.M + 4 * RPS * steps - 1) / (4 * RPS * steps);
     }
@@ -354,12 +397,11 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
 template <int WT, int EPI, int K>
 hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
     const size_t sm = bgk::matmul_mfma_smem_bytes(K, EPI == bgk::EPI_GELU_Q8);
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (one process drives one device)
-    if (sm > 64 * 1024 && !attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>);
+    if (sm > 64 * 1024 && !t_ctx->lds_attr_done.count(fn)) {   // > 64 KB of dynamic LDS needs the opt-in attribute, per device
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        t_ctx->lds_attr_done.insert(fn);
     }
     hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(256), sm, st, p, img);
     return hipGetLastError();
@@ -431,14 +473,14 @@ bgk::MatvecParams mv_base(const biogpt_hip_ctx *c, const MatSlot &m, const MvSha
     p.P = c->hp.n_positions;
     p.st = c->state;
     p.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
-    p.dbg = env_int("BIOGPT_HIP_DBG", 0) | (g_launch_parity << 8);
-    p.tstamp = g_tstamp;
+    p.dbg = c->opt.dbg | (c->launch_parity << 8);
+    p.tstamp = c->tstamp;
     p.inv_k = 1.0 / (double)m.K;
     p.k_pow2 = (m.K & (m.K - 1)) == 0;
     return p;
 }
 
-int target_wgs() { return env_int("BIOGPT_HIP_TARGET_WGS", 256); }
+int target_wgs() { return opt().target_wgs; }
 
 hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_w, size_t ln_b, int q81, hipStream_t st) {
     const double inv_k = 1.0 / 1024.0;
@@ -485,9 +527,103 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
     return true;
 }
 
+// ---- fused single-token decode step (kernels_decode.hip.h): 3 launches per layer + lm_head ---------------------
+// tok_src 1: the token is in the device state (an eval call); 2: arg-max of the previous step's lm_head partials.
+// advance: the lm_head kernel moves the device-side position on by one when the step is done.
+bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max) {
+    const auto &hp = c->hp;
+    return is_quantized(ftype_to_type(hp.ftype)) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 && t_max <= 256 &&
+           hp.n_positions >= 64 && !c->opt.no_fast && !c->opt.no_chain && !c->opt.no_fused_decode && c->terms != nullptr;
+}
+
+template <int WT>
+hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecAttnParams &a, const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2) {
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL((bgk::dec_attn_kernel<WT>), dim3(16), dim3(1024), bgk::dec_attn_smem_bytes(), st, a);
+    if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
+    else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
+    if (c->opt.fc2_waves == 4) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 4>), dim3(256), dim3(256), bgk::dec_fc2_smem_bytes(4), st, f2);
+    else if (c->opt.fc2_waves == 8) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 8>), dim3(128), dim3(512), bgk::dec_fc2_smem_bytes(8), st, f2);
+    else hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 16>), dim3(64), dim3(1024), bgk::dec_fc2_smem_bytes(16), st, f2);
+    return hipGetLastError();
+}
+
+// grid of the single-token lm_head launch (launch_fast_k, K = 1024: 2 rows per wave step, 4 waves)
+int fast_lm_grid(const biogpt_hip_ctx *c) {
+    const int M = c->hp.n_vocab;
+    int steps = c->opt.lm_steps;
+    while (steps > 1 && (M + 8 * steps - 1) / (8 * steps) < 128) steps >>= 1;
+    return (M + 8 * steps - 1) / (8 * steps);
+}
+
+bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance) {
+    t_ctx = c;
+    const auto &hp = c->hp;
+    const int D = hp.d_model, V = hp.n_vocab, P = hp.n_positions;
+    const int lm_parts = fast_lm_grid(c);   // partials the previous step's lm_head left (same launch shape every step)
+    if (lm_parts > c->pmax_cap) BG_FAIL(false, "internal: arg-max partial buffer too small (%d > %d)", lm_parts, c->pmax_cap);
+    const int32_t wt = ftype_to_type(hp.ftype);
+    const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
+    for (int l = 0; l < hp.n_layer; l++) {
+        const LayerSlots &L = c->plan.layers[(size_t)l];
+        bgk::DecAttnParams a{};
+        a.x = c->x; a.x_out = c->x;
+        a.tok_emb = dev_matrix(c, c->plan.embed_tokens); a.pos_emb = dev_matrix(c, c->plan.embed_pos);
+        a.embed_scale = sqrtf((float)D);
+        a.tok_src = (l == 0) ? tok_src : 0;
+        a.pmax_val = c->pmax_val; a.pmax_idx = c->pmax_idx; a.nparts = lm_parts;
+        a.st = c->state; a.n_positions = P; a.n_vocab = V;
+        a.ln_w = dev_vec(c, L.ln0_w); a.ln_b = dev_vec(c, L.ln0_b); a.eps = 1e-5f;
+        a.Wqkv = dev_matrix(c, L.qkv); a.bqkv = dev_vec(c, L.qkv_b); a.q_scale = 1.0f / sqrtf(64.0f);
+        a.kcache = c->memory_k + (size_t)l * P * D; a.vcache = c->memory_v + (size_t)l * P * D;
+        a.P = P; a.t_cap = std::min(P, (t_max + 63) & ~63);
+        a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
+        a.Wo = dev_matrix(c, L.o); a.terms = c->terms; a.att_out = nullptr; a.q81 = q81;
+        a.tstamp = (c->opt.dbg & 96) ? c->tstamp : nullptr; a.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; a.wall_slot = 3 * l;
+        bgk::DecFc1Params f1{};
+        f1.terms = c->terms; f1.x = c->x; f1.bo = dev_vec(c, L.o_b); f1.x1_out = c->x1;
+        f1.ln_w = dev_vec(c, L.ln1_w); f1.ln_b = dev_vec(c, L.ln1_b); f1.eps = 1e-5f;
+        f1.W1 = dev_matrix(c, L.fc1); f1.b1 = dev_vec(c, L.fc1_b);
+        f1.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+        f1.oq_q = c->aq_q[1]; f1.oq_d = c->aq_d[1]; f1.oq_s = c->aq_s[1]; f1.q81 = q81;
+        f1.tstamp = (c->opt.dbg & 96) ? c->tstamp + 16 : nullptr; f1.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; f1.wall_slot = 3 * l + 1;
+        bgk::DecFc2Params f2{};
+        f2.W2 = dev_matrix(c, L.fc2); f2.aq_q = c->aq_q[1]; f2.aq_d = c->aq_d[1]; f2.aq_s = c->aq_s[1];
+        f2.bias = dev_vec(c, L.fc2_b); f2.resid = c->x1; f2.out = c->x;
+        f2.tstamp = (c->opt.dbg & 96) ? c->tstamp + 32 : nullptr; f2.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; f2.wall_slot = 3 * l + 2;
+        hipError_t e = hipErrorInvalidValue;
+        switch (wt) {
+            case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, f1, f2); break;
+            case T_Q4_1: e = launch_decode_layer<bgk::W_Q4_1>(c, a, f1, f2); break;
+            case T_Q5_0: e = launch_decode_layer<bgk::W_Q5_0>(c, a, f1, f2); break;
+            case T_Q5_1: e = launch_decode_layer<bgk::W_Q5_1>(c, a, f1, f2); break;
+            case T_Q8_0: e = launch_decode_layer<bgk::W_Q8_0>(c, a, f1, f2); break;
+            default: break;
+        }
+        HIP_TRY(false, e);
+    }
+    {  // final LayerNorm + lm_head (last row only, F8) + per-workgroup arg-max partials; block 0 advances the position
+        const MatSlot &m = c->plan.lm_head;
+        const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
+        bgk::MatvecParams p = mv_base(c, m, s);
+        p.ln_w = dev_vec(c, c->plan.ln_w); p.ln_b = dev_vec(c, c->plan.ln_b);
+        p.ldx = D; p.ldo = V; p.x = c->x; p.N = 1; p.out = c->logits;
+        p.pmax_val = c->pmax_val; p.pmax_idx = c->pmax_idx;
+        p.st_adv = c->state; p.adv = advance;
+        int lm_grid = 0;
+        HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, c->stream, &lm_grid)));
+        if (lm_grid != lm_parts) BG_FAIL(false, "internal: lm_head grid %d != expected %d", lm_grid, lm_parts);
+        c->lm_blocks = lm_grid;
+    }
+    return true;
+}
+
 // batch: one column per sequence (decode step).  cols != null: the columns are prompt tokens of several sequences
 // (column states with seq_id / t_vis), no lm_head -- the caller gets the logits from the following decode step.
 bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false, const bgk::SeqState *cols = nullptr) {
+    t_ctx = c;
+    if (N < 1 || N > c->hp.n_positions) BG_FAIL(false, "internal: a pass of %d columns exceeds the %d-column activation scratch", N, c->hp.n_positions);
+    if (N == 1 && !batch && !all_rows && fused_decode_ok(c, t_max)) return enqueue_decode_fused(c, t_max, 1, 0);
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
     const int dk = D / H;
@@ -502,11 +638,11 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
     // single-token fast chain: BioGPT-base shapes, block-quantized weights -> producer-side Q8 hand-offs
     const int32_t wt = ftype_to_type(hp.ftype);
     const bool chain = is_quantized(wt) && D == 1024 && F == 4096 && dk == 64 && t_max <= 1024 &&
-                       !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
+                       !opt().no_fast && !opt().no_chain;
     const bool pchain = chain && (N > 1 || batch);   // several columns: LayerNorm+Q8 once per site (lnq_kernel), 8 columns per workgroup
     // enough columns to fill 16-wide MFMA tiles: the chain runs on the int8 matrix cores from the row-tiled weight image
     // (measured cross-overs: decode steps of S sequences 48; prompt passes 64 columns)
-    const bool mfma = pchain && N >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", (batch && !cols) ? 48 : 64) && c->tile_img != nullptr;
+    const bool mfma = pchain && N >= opt().mfma_min((batch && !cols) ? 48 : 64) && c->tile_img != nullptr;
     bgk::DevMatrix img;
     auto tile = [&](const MatSlot &m) -> const bgk::DevMatrix * { if (!mfma) return nullptr; img = tile_matrix(c, m); return &img; };
     if (batch && !chain) BG_FAIL(false, "batched decode needs the BioGPT-base fast chain (block-quantized weights, d_model 1024, d_ff 4096, head size 64)");
@@ -546,10 +682,10 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             a.out = c->att; a.st = c->state;
             a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
             a.N = N; a.D = D; a.dk = dk; a.P = P;
-            a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
+            a.dbg = c->opt.dbg; a.tstamp = c->tstamp;
             a.q81 = q81;
             if (chain) { a.oq_q = c->aq_q[0]; a.oq_d = c->aq_d[0]; a.oq_s = c->aq_s[0]; }
-            if (!batch && dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && env_int("BIOGPT_HIP_PREFILL_MFMA", 0)) {
+            if (!batch && dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && opt().prefill_mfma) {
                 // opt-in: QK^T / PV of the prefill chunk on the matrix cores (f32 MFMA; tolerance parity, not bit parity)
                 const size_t smb = bgk::attn_mfma_smem_bytes(P);
                 if (!c->mfma_attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
@@ -557,15 +693,15 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     c->mfma_attr_set = true;
                 }
                 hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
-            } else if (!batch && dk == 64 && t_max <= 1024 && N >= env_int("BIOGPT_HIP_ATTN_GROUP_MIN", 80) && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+            } else if (!batch && dk == 64 && t_max <= 1024 && N >= opt().attn_group_min && !opt().no_fast) {
                 // a pass of many query columns: one workgroup per (head, 8 queries) shares every K / V row it loads
                 a.t_cap = std::min(P, t_max);
                 hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
-            } else if (dk == 64 && t_max <= 1024 && !env_int("BIOGPT_HIP_NO_FAST", 0)) {
+            } else if (dk == 64 && t_max <= 1024 && !opt().no_fast) {
                 // loads are bounded by t_cap (= P when the table is not a multiple of 64; the workgroup stays whole
                 // waves); 4 lanes per key, 16 prefetched V rows per lane
                 a.t_cap = std::min(P, (t_max + 63) & ~63);
-                static const int split_min = env_int("BIOGPT_HIP_SPLIT_MIN", 256);
+                const int split_min = opt().split_min;
                 if (N == 1 && !batch && a.t_cap > split_min) {
                     // long context, one query: spread the head's keys over the chip (three dependent launches)
                     a.sp_scores = c->sp_scores; a.sp_max = c->sp_max; a.sp_pv = c->sp_pv;
@@ -573,7 +709,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(H), dim3(64), 0, st, a);
-                } else if (batch && N >= env_int("BIOGPT_HIP_ATTN_SLIM_MIN", 48)) {
+                } else if (batch && N >= opt().attn_slim_min) {
                     // many (sequence, head) workgroups: throughput over latency -- one lane quad per 4 keys (4 key passes), a
                     // quarter of the threads, four times as many workgroups resident per compute unit
                     const int t64 = (a.t_cap + 63) & ~63;
@@ -686,7 +822,7 @@ bool upload_state(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, i
     auto *hs = reinterpret_cast<bgk::DevState *>(slot);
     hs->n_past = n_past;
     hs->n_gen = 0;
-    hs->causal = env_int("BIOGPT_HIP_CAUSAL", 0);
+    hs->causal = c->opt.causal;
     hs->chunk = chunk;
     std::memcpy(slot + sizeof(bgk::DevState), tokens, (size_t)n * 4);
     HIP_TRY(false, hipMemcpyAsync(c->state, slot, sizeof(bgk::DevState) + (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -730,6 +866,9 @@ bool alloc_runtime(biogpt_hip_ctx *c) {
     HIP_TRY(false, hipMalloc(&c->sp_max, (size_t)hp.n_head * bgk::SPLIT_MAX * 4));
     HIP_TRY(false, hipMalloc(&c->sp_pv, (size_t)hp.n_head * bgk::SPLIT_MAX * 64 * 8));
     HIP_TRY(false, hipMalloc(&c->pmax_idx, (size_t)c->pmax_cap * 4));
+    HIP_TRY(false, hipMemset(c->pmax_val, 0, (size_t)c->pmax_cap * 4));
+    HIP_TRY(false, hipMemset(c->pmax_idx, 0, (size_t)c->pmax_cap * 4));
+    HIP_TRY(false, hipMalloc(&c->terms, (size_t)32 * 1024 * 4));
     c->state_bytes = sizeof(bgk::DevState) + 2 * P * 4;
     HIP_TRY(false, hipMalloc(&c->state, c->state_bytes));
     HIP_TRY(false, hipMemset(c->state, 0, c->state_bytes));
@@ -767,10 +906,10 @@ bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
         BG_FAIL(false, "ERROR not all tensors loaded from model file - expected %zu, got %zu", expected.size(), mf.tensors.size());
 
     std::vector<uint8_t> raw, qs, sc, qh;
-    auto put_matrix = [&](const std::string &name, const MatSlot &slot, int64_t row0, int64_t rows, int64_t K) -> bool {
+    auto put_matrix = [&](const std::string &name, const MatSlot &slot, int64_t row0, int64_t rows, int64_t K, bool more_rows_ok = false) -> bool {
         const TensorEntry *t = mf.find(name);
         if (!t) BG_FAIL(false, "ERROR not all tensors loaded from model file - missing '%s'", name.c_str());
-        if (t->ne0 != K || t->ne1 != rows)
+        if (t->ne0 != K || (more_rows_ok ? t->ne1 < rows : t->ne1 != rows))
             BG_FAIL(false, "tensor '%s' has wrong shape in model file: got [%lld, %lld], expected [%lld, %lld]", name.c_str(),
                     (long long)t->ne0, (long long)t->ne1, (long long)K, (long long)rows);
         if (t->type != wt) BG_FAIL(false, "tensor '%s' has wrong size in model file: type %s, expected %s", name.c_str(), type_name(t->type), type_name(wt));
@@ -799,7 +938,7 @@ bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
 
     const ArenaPlan &pl = c->plan;
     if (!put_matrix("biogpt.embed_tokens.weight", pl.embed_tokens, 0, hp.n_vocab, D)) return false;
-    if (!put_matrix("biogpt.embed_positions.weight", pl.embed_pos, 0, c->pos_rows, D)) return false;
+    if (!put_matrix("biogpt.embed_positions.weight", pl.embed_pos, 0, c->pos_rows, D, true)) return false;   // first n_positions + 2 rows
     for (int l = 0; l < hp.n_layer; l++) {
         const LayerSlots &L = pl.layers[(size_t)l];
         const std::string p = "biogpt.layers." + std::to_string(l) + ".";
@@ -849,6 +988,10 @@ void destroy(biogpt_hip_ctx *c) {
                     (void *)c->h, (void *)c->logits, (void *)c->aq_q[0], (void *)c->aq_q[1], (void *)c->aq_q[2], (void *)c->aq_d[0], (void *)c->aq_d[1], (void *)c->aq_d[2], (void *)c->aq_s[0], (void *)c->aq_s[1], (void *)c->aq_s[2], (void *)c->logits_all, (void *)c->pmax_val, (void *)c->pmax_idx, (void *)c->sp_scores, (void *)c->sp_max, (void *)c->sp_pv, (void *)c->tile_img, (void *)c->state})
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
+    if (c->logits_host) (void)hipHostFree(c->logits_host);
+    if (c->terms) (void)hipFree(c->terms);
+    if (c->tstamp) (void)hipFree(c->tstamp);
+    if (c->tok_vocab) bg::drop_vocab(c->tok_vocab);
     delete c;
 }
 
@@ -861,6 +1004,7 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
     if (!select_device(device)) return nullptr;
 
     std::unique_ptr<biogpt_hip_ctx, void (*)(biogpt_hip_ctx *)> c(new biogpt_hip_ctx(), destroy);
+    c->opt.load();
     c->hp = mf.hp;
     c->device = device;
     c->n_tensors = (int)mf.tensors.size();
@@ -876,13 +1020,14 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
     if (hp.d_model % 32 != 0 || hp.d_ff % 32 != 0) BG_FAIL(nullptr, "d_model (%d) and d_ff (%d) must be multiples of 32", hp.d_model, hp.d_ff);
     if (dk % 4 != 0 || (dk & (dk - 1)) != 0 || dk > 256) BG_FAIL(nullptr, "head size %d unsupported (needs a power of two in [4, 256])", dk);
 
-    // F5: size embed_positions by what the file holds (must cover n_positions + 2 rows)
+    // F5: the file's embed_positions must cover n_positions + 2 rows; a longer table is cut to that (rows past it are
+    // never indexed), so that the arena layout depends on the 7 header ints only -- a replica that attaches to a
+    // broadcast arena computes the same offsets without the file
     c->pos_rows = (int64_t)hp.n_positions + 2;
     if (const TensorEntry *pe = mf.find("biogpt.embed_positions.weight")) {
         if (pe->ne1 < c->pos_rows)
             BG_FAIL(nullptr, "tensor 'biogpt.embed_positions.weight' has wrong shape in model file: got [%lld, %lld], expected [%d, >=%lld]",
                     (long long)pe->ne0, (long long)pe->ne1, hp.d_model, (long long)c->pos_rows);
-        c->pos_rows = pe->ne1;
     }
     c->plan = plan_arena(hp, c->pos_rows);
     if (ext_arena) {
@@ -923,7 +1068,11 @@ bool ensure_graph(biogpt_hip_ctx *c, int advance, int bucket) {
     if (c->graph_step[advance][bucket]) return true;
     hipGraph_t g = nullptr;
     HIP_TRY(false, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    bool ok = enqueue_forward(c, 1, false, bucket_tmax(c, bucket)) && enqueue_argmax(c, advance);
+    // fused step (contexts up to 256 keys): the sampler of the previous token is the first kernel's prologue and the
+    // lm_head kernel advances the position; otherwise embed ... lm_head + the arg-max kernel
+    const int tmax = bucket_tmax(c, bucket);
+    bool ok = fused_decode_ok(c, tmax) ? enqueue_decode_fused(c, tmax, 2, advance)
+                                       : (enqueue_forward(c, 1, false, tmax) && enqueue_argmax(c, advance));
     hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
     HIP_TRY(false, e);
@@ -958,6 +1107,7 @@ biogpt_hip_ctx *biogpt_hip_attach(const biogpt_hip_hparams *hp, int device, void
     if (ftype_to_type(hp->ftype) == T_INVALID) BG_FAIL(nullptr, "bad ftype value %d", hp->ftype);
     if (!select_device(device)) return nullptr;
     std::unique_ptr<biogpt_hip_ctx, void (*)(biogpt_hip_ctx *)> c(new biogpt_hip_ctx(), destroy);
+    c->opt.load();
     c->hp = *hp;
     c->device = device;
     c->pos_rows = (int64_t)hp->n_positions + 2;
@@ -976,6 +1126,16 @@ void *biogpt_hip_arena_ptr(biogpt_hip_ctx *ctx) { return ctx ? ctx->arena : null
 size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
 
 void biogpt_hip_free(biogpt_hip_ctx *ctx) { destroy(ctx); }
+
+int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
+    if (!ctx) BG_FAIL(-1, "null context");
+    ctx->opt.load();
+    // captured graphs bake launch shapes chosen from the options
+    for (auto &row : ctx->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    ctx->graph_batch_n = 0;
+    return 0;
+}
 
 int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out) {
     if (!ctx || !out) BG_FAIL(-1, "null argument");
@@ -1038,6 +1198,9 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
         ctx->logits_all = nullptr;
         HIP_TRY(-2, hipMalloc(&ctx->logits_all, (size_t)n * ctx->hp.n_vocab * 4));
         ctx->logits_all_rows = (size_t)n;
+        // the captured batched-decode graphs hold the old logits_all pointer
+        for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        ctx->graph_batch_n = 0;
     }
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
     if (!enqueue_forward(ctx, n, true, n_past + n)) return -2;
@@ -1053,9 +1216,9 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
 // have seen (DevState::chunk).  Per-column arithmetic is unchanged: logits and KV rows are bit-identical to
 // the chunk-by-chunk evaluation.  Leaves the last token's logits in ctx->logits.
 bool enqueue_prompt(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, int n_batch, int *last_cols = nullptr) {
-    const int max_cols = std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 512));   // measured (Q4_0, -b 8, 512-token prompt): 16 -> 17.9k, 64 -> 36k, 128 -> 66k, 256 -> 87k, 512 -> 97k prompt tok/s
+    const int max_cols = std::max(1, c->opt.prompt_cols);   // measured (Q4_0, -b 8, 512-token prompt): 16 -> 17.9k, 64 -> 36k, 128 -> 66k, 256 -> 87k, 512 -> 97k prompt tok/s
     const int group = n_batch >= max_cols ? n_batch : (max_cols / n_batch) * n_batch;   // whole chunks per pass
-    if (std::min(group, n) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 64) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
+    if (std::min(group, n) >= c->opt.mfma_min(64) && is_quantized(ftype_to_type(c->hp.ftype)) && !ensure_tile_images(c)) return false;
     for (int at = 0; at < n;) {
         const int m = std::min(group, n - at);
         if (!upload_state(c, tokens + at, m, n_past + at, m > n_batch ? n_batch : 0)) return false;
@@ -1090,24 +1253,39 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
     n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);  // main.cpp:82
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    const bool use_graph = env_int("BIOGPT_HIP_NO_GRAPH", 0) == 0;
+    const bool use_graph = ctx->opt.no_graph == 0;
     if (use_graph)  // instantiate every bucket this run will touch before the clock starts
         for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++)
             if (!ensure_graph(ctx, 1, b)) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();
-    // prompt ingestion in chunks of n_batch (main.cpp:129-137), several chunks per pass; then the first sampled token
+    // prompt ingestion in chunks of n_batch (main.cpp:129-137), several chunks per pass; then the first sampled token.
+    // Fused steps (graph replay, contexts up to 256 keys) sample the PREVIOUS token in their first kernel, so between
+    // them no sampler kernel runs: `pending` = the last lm_head's arg-max has not been recorded yet.
+    auto fused = [&](int T) { return use_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(T))); };
     int last_cols = 0;
-    if (!enqueue_prompt(ctx, prompt, n_prompt, 0, n_batch, &last_cols) || !enqueue_argmax(ctx, last_cols)) return -2;
+    if (!enqueue_prompt(ctx, prompt, n_prompt, 0, n_batch, &last_cols)) return -2;
+    bool pending = n_predict > 1 && fused(n_prompt + 1);
+    if (pending) {
+        hipLaunchKernelGGL(bgk::advance_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->state, last_cols);
+        HIP_TRY(-2, hipGetLastError());
+    } else if (!enqueue_argmax(ctx, last_cols)) {
+        return -2;
+    }
     for (int k = 1; k < n_predict; k++) {  // one eval + one sample per further token
         const int T = n_prompt + k;  // keys visible to this token: n_past + 1
+        if (pending && !fused(T)) {  // leaving the fused range: record the token the unfused step will embed
+            if (!enqueue_argmax(ctx, 0)) return -2;
+            pending = false;
+        }
         if (use_graph) {
             HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1][graph_bucket(T)], ctx->stream));
         } else {
             if (!enqueue_forward(ctx, 1, false, T) || !enqueue_argmax(ctx, 1)) return -2;
         }
     }
+    if (pending && !enqueue_argmax(ctx, 0)) return -2;   // the last token's sampler
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
     const auto t1 = std::chrono::steady_clock::now();
     if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
@@ -1155,7 +1333,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     {   // matrix-core chain: decode steps have n_seqs columns, the prompt pass all prompt tokens; build the tiled weights before any graph capture
         long total = 0;
         for (int s = 0; s < n_seqs; s++) total += prompt_lens[s];
-        if (std::max<long>(n_seqs, total) >= env_int("BIOGPT_HIP_MFMA_MIN_COLS", 48) && !ensure_tile_images(ctx)) return -2;
+        if (std::max<long>(n_seqs, total) >= ctx->opt.mfma_min(48) && !ensure_tile_images(ctx)) return -2;
     }
     if ((size_t)n_seqs > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
@@ -1186,7 +1364,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
         HIP_TRY(false, hipGetLastError());
         return true;
     };
-    const bool use_graph = env_int("BIOGPT_HIP_NO_GRAPH", 0) == 0;
+    const bool use_graph = ctx->opt.no_graph == 0;
     if (use_graph) {
         for (int b = graph_bucket(max_len + 1); b <= graph_bucket(std::max(1, max_len + n_predict - 1)); b++) {
             if (ctx->graph_batch[b]) continue;
@@ -1209,7 +1387,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     // the first decode step below re-evaluates each sequence's LAST prompt token (same K/V row, same visible keys as
     // its chunk gave it) and its arg-max is the first sampled token.
     {
-        const int max_cols = std::max(std::max(1, env_int("BIOGPT_HIP_PROMPT_COLS", 512)), n_batch);
+        const int max_cols = std::min(std::max(std::max(1, ctx->opt.prompt_cols), n_batch), hp_cols(ctx));   // the activation scratch holds n_positions columns
         std::vector<bgk::SeqState> cols;
         int pass_tmax = 0;
         auto flush = [&]() -> bool {
@@ -1282,6 +1460,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer))) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    t_ctx = ctx;
     const auto &hp = ctx->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, P = hp.n_positions;
     const int tw = target_wgs();
@@ -1289,9 +1468,9 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     // fits the 256 MiB Infinity Cache -- stated in DESIGN.md
     const int32_t wt0 = ftype_to_type(hp.ftype);
     const bool chain = is_quantized(wt0) && D == 1024 && F == 4096 && D / hp.n_head == 64 && P <= 1024 &&
-                       !env_int("BIOGPT_HIP_NO_FAST", 0) && !env_int("BIOGPT_HIP_NO_CHAIN", 0);
+                       !opt().no_fast && !opt().no_chain;
     auto launch = [&](int l) -> bool {
-        g_launch_parity ^= 1;
+        ctx->launch_parity ^= 1;
         if (which == 5) {  // attention of layer (l mod L) with `layer` keys in the cache
             bgk::AttnParams a{};
             const int ll = l % hp.n_layer, dk = D / hp.n_head;
@@ -1299,7 +1478,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             a.out = ctx->att; a.st = ctx->state;
             a.exp_tab = reinterpret_cast<const uint16_t *>(ctx->arena + ctx->plan.exp_tab);
             a.N = 1; a.D = D; a.dk = dk; a.P = P;
-            a.dbg = env_int("BIOGPT_HIP_DBG", 0); a.tstamp = g_tstamp;
+            a.dbg = ctx->opt.dbg; a.tstamp = ctx->tstamp;
             a.oq_q = ctx->aq_q[0]; a.oq_d = ctx->aq_d[0]; a.oq_s = ctx->aq_s[0];
             a.t_cap = std::min(P, (layer + 1 + 63) & ~63);
             if (a.t_cap <= 256) hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(hp.n_head, 1), dim3(4 * ((a.t_cap + 63) & ~63)), 0, ctx->stream, a);
@@ -1350,10 +1529,10 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     };
     const int32_t tok0 = 0;
     if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : 0)) return -2;
-    const bool stamps = (env_int("BIOGPT_HIP_DBG", 0) & 32) != 0 && which < 5;
+    const bool stamps = (ctx->opt.dbg & 32) != 0 && which < 5;
     if (stamps) {
-        if (!g_tstamp) HIP_TRY(-2, hipMalloc(&g_tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(-2, hipMemset(g_tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
+        if (!ctx->tstamp) HIP_TRY(-2, hipMalloc(&ctx->tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(-2, hipMemset(ctx->tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
     }
     for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
     HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
@@ -1368,8 +1547,8 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
                           : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
         const int grid = mv_shape(mm->type, mm->M, mm->K, tw).grid;
         std::vector<unsigned long long> h(2 * (size_t)grid * 8);
-        HIP_TRY(-2, hipMemcpy(h.data(), g_tstamp, h.size() * 8, hipMemcpyDeviceToHost));
-        const int pb = g_launch_parity, pa = pb ^ 1;  // B = last launch, A = the one before
+        HIP_TRY(-2, hipMemcpy(h.data(), ctx->tstamp, h.size() * 8, hipMemcpyDeviceToHost));
+        const int pb = ctx->launch_parity, pa = pb ^ 1;  // B = last launch, A = the one before
         auto at = [&](int par, int b, int k) { return h[((size_t)par * grid + b) * 8 + k]; };
         unsigned long long a_min0 = ~0ull, a_max6 = 0, b_min0 = ~0ull, a_max0 = 0;
         std::vector<double> seg[6];
@@ -1403,6 +1582,7 @@ int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int ste
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (ctx->hp.d_model != 1024 || rows < 1024 || rows % 1024 || reps < 1 || steps < 2) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    t_ctx = ctx;
     const size_t nblk = (size_t)rows * 32;
     uint8_t *qs = nullptr, *sc = nullptr;
     float *out = nullptr;
@@ -1445,9 +1625,9 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
     if (reps < 1 || n_past < 0 || n_past >= ctx->hp.n_positions) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     const int b = graph_bucket(n_past + 1);
-    if ((env_int("BIOGPT_HIP_DBG", 0) & 32) && !g_tstamp) {
-        HIP_TRY(-2, hipMalloc(&g_tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(-2, hipMemset(g_tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
+    if ((ctx->opt.dbg & 96) && !ctx->tstamp) {
+        HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
+        HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
     }
     if (!ensure_graph(ctx, 0, b)) return -2;
     const int32_t tok0 = 2;
@@ -1460,9 +1640,48 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
     float ms = 0.0f;
     HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
-    if ((env_int("BIOGPT_HIP_DBG", 0) & 32) && g_tstamp) {
+    if ((ctx->opt.dbg & 64) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
+        // wall-clock (100 MHz) entry / exit of every workgroup of the last replay: per kernel, relative to the previous kernel's last exit
+        const int nk = 3 * ctx->hp.n_layer;
+        std::vector<unsigned long long> w((size_t)nk * 2048);
+        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp + 64, w.size() * 8, hipMemcpyDeviceToHost));
+        const int grids[3] = {16, ctx->opt.fc1_blocks == 2 ? 64 : 128, ctx->opt.fc2_waves == 4 ? 256 : ctx->opt.fc2_waves == 8 ? 128 : 64};
+        const char *kn[3] = {"dec_attn", "dec_fc1 ", "dec_fc2 "};
+        double acc[3][5] = {};
+        unsigned long long prev_exit = 0;
+        for (int k = 0; k < nk; k++) {
+            unsigned long long e0 = ~0ull, e1 = 0, x0 = ~0ull, x1 = 0;
+            for (int g = 0; g < grids[k % 3]; g++) {
+                const unsigned long long en = w[((size_t)k * 1024 + g) * 2], ex = w[((size_t)k * 1024 + g) * 2 + 1];
+                e0 = std::min(e0, en); e1 = std::max(e1, en); x0 = std::min(x0, ex); x1 = std::max(x1, ex);
+            }
+            if (k >= 3) {   // skip layer 0 (no previous stamp)
+                acc[k % 3][0] += (double)(long long)(e0 - prev_exit); acc[k % 3][1] += (double)(e1 - e0);
+                acc[k % 3][2] += (double)(x0 - e0); acc[k % 3][3] += (double)(x1 - e0); acc[k % 3][4] += 1.0;
+            }
+            prev_exit = x1;
+        }
+        fprintf(stderr, "wall-clock timeline per kernel (us, mean over layers 1..): prev last exit -> first entry | entry spread | first exit | last exit (from first entry)\n");
+        for (int j = 0; j < 3; j++)
+            fprintf(stderr, "   %s  gap %.2f | entries within %.2f | first exit %.2f | last exit %.2f\n", kn[j], acc[j][0] / acc[j][4] * 0.01,
+                    acc[j][1] / acc[j][4] * 0.01, acc[j][2] / acc[j][4] * 0.01, acc[j][3] / acc[j][4] * 0.01);
+    }
+    if ((ctx->opt.dbg & 32) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
+        // fused step, last layer, workgroup 0 / thread 0 (needs a build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS)
+        unsigned long long h[48];
+        HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));
+        const char *an[5] = {"entry -> loads issued, x / token known", "-> LayerNorm + Q8 in LDS", "-> q/k/v rows finished, KV appended", "-> attention output quantized", "-> out_proj terms stored"};
+        const char *fn[4] = {"entry -> terms summed (x1)", "-> LayerNorm + Q8 in LDS", "-> rows finished, GELU", "-> Q8 block stored"};
+        const char *gn[3] = {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store"};
+        fprintf(stderr, "dec_attn_kernel segments (shader cycles):\n");
+        for (int k = 0; k < 5; k++) fprintf(stderr, "   %-42s %7lld\n", an[k], (long long)(h[k + 1] - h[k]));
+        fprintf(stderr, "   attn exit -> fc1 entry %lld\ndec_fc1_kernel segments:\n", (long long)(h[16] - h[5]));
+        for (int k = 0; k < 4; k++) fprintf(stderr, "   %-42s %7lld\n", fn[k], (long long)(h[16 + k + 1] - h[16 + k]));
+        fprintf(stderr, "   fc1 exit -> fc2 entry %lld\ndec_fc2_kernel segments:\n", (long long)(h[32] - h[20]));
+        for (int k = 0; k < 3; k++) fprintf(stderr, "   %-42s %7lld\n", gn[k], (long long)(h[32 + k + 1] - h[32 + k]));
+    } else if ((ctx->opt.dbg & 32) && ctx->tstamp) {
         unsigned long long h[16 * 8];
-        HIP_TRY(-2, hipMemcpy(h, g_tstamp, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));
         fprintf(stderr, "attention timeline (block 0, last layer; cycles since wave 0 entry):\n");
         for (int w = 0; w < 16; w += 5) {
             fprintf(stderr, "  wave %2d:", w);

@@ -237,6 +237,8 @@ struct MatvecParams {
     // producer-quantized activations (single-token fast chain): 32 int8 per block + scale + block sum
     const int8_t *aq_q; const float *aq_d; const uint32_t *aq_s;   // PRO_Q8IN input
     int8_t *oq_q; float *oq_d; uint32_t *oq_s;                     // EPI_GELU_Q8 output
+    DevState *st_adv;    // EPI_LOGITS, fused decode step: block 0 moves the device-side position / id count on by `adv`
+    int32_t adv;         //   after the step (the sampler runs in the next step's first kernel); null / 0: off
     double inv_k;        // 1.0 / K
     int32_t k_pow2;      // K is a power of two: sum * inv_k == sum / K exactly (skips two f64 divisions)
     unsigned long long *tstamp;  // profiling: [2][grid][8] shader-clock stamps when dbg & 32

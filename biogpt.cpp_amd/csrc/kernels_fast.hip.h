@@ -295,6 +295,8 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
                 if (sv[w] > best_val || (sv[w] == best_val && si[w] < best_idx)) { best_val = sv[w]; best_idx = si[w]; }
             p.pmax_val[blockIdx.x] = best_val;
             p.pmax_idx[blockIdx.x] = best_idx;
+            // fused decode step (kernels_decode.hip.h): every kernel of this step has read the position by now
+            if (blockIdx.x == 0 && p.st_adv != nullptr && p.adv != 0) { p.st_adv->n_past += p.adv; p.st_adv->n_gen += p.adv; }
         }
     }
 }

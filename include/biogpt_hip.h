@@ -93,6 +93,11 @@ size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx);
 
 void biogpt_hip_free(biogpt_hip_ctx *ctx);
 
+/* The BIOGPT_HIP_* tuning / debugging switches are read from the environment once, when a context is
+ * created (no getenv on any launch path).  This re-reads them for an existing context and drops its
+ * captured graphs (tests and sweep tools; the reference has no counterpart). */
+int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx);
+
 int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out);
 int biogpt_hip_n_tensors(const biogpt_hip_ctx *ctx); /* tensors found in the file (389 for BioGPT) */
 

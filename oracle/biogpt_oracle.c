@@ -287,6 +287,40 @@ static void quantize_row_q8_1(const float *x, blk_q8_1 *y, int64_t k) {
     }
 }
 
+/* ggml's AVX2 quantize_row_q8_0 / q8_1 [ggml-recall]: the multiplier is 127/amax (not 1/d) and the rounding is
+ * _mm256_round_ps(..., _MM_ROUND_NEAREST) = nearest-even.  nearbyintf under the default rounding mode. */
+static void quantize_row_q8_0_simd(const float *x, blk_q8_0 *y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = fabsf(x[i * QK + j]);
+            if (amax < v) amax = v;
+        }
+        const float d  = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d         = bo_fp32_to_fp16(d);
+        for (int j = 0; j < QK; j++) y[i].qs[j] = (int8_t)nearbyintf(x[i * QK + j] * id);
+    }
+}
+static void quantize_row_q8_1_simd(const float *x, blk_q8_1 *y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; j++) {
+            const float v = fabsf(x[i * QK + j]);
+            if (amax < v) amax = v;
+        }
+        const float d  = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d         = d;
+        int sum        = 0;
+        for (int j = 0; j < QK; j++) {
+            y[i].qs[j] = (int8_t)nearbyintf(x[i * QK + j] * id);
+            sum += y[i].qs[j];
+        }
+        y[i].s = d * (float)sum;
+    }
+}
+
 size_t bo_quantize(int type, const float *src, void *dst, int64_t n, int64_t k) {
     const size_t rb = bo_row_bytes(type, k);
     uint8_t *out    = (uint8_t *)dst;
@@ -467,6 +501,89 @@ static float vec_dot_f16(int64_t k, const uint16_t *x, const uint16_t *y) {
     double sumf = 0.0;
     for (int64_t i = 0; i < k; i++) sumf += (double)(F16(x[i]) * F16(y[i]));
     return (float)sumf;
+}
+
+/* ---- the AVX2 shape of the same dots [ggml-recall]: per block, 8 lanes hold the int32 sums of 4 consecutive
+ * byte products (mul_sum_i8_pairs_float), acc_l = fma(d, (float)sum_l, acc_l); at the end hsum_float_8:
+ * ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)).  wv[j] is the weight element j of the block as an integer. ---- */
+static inline float hsum8(const float a[8]) {
+    const float r0 = a[0] + a[4], r1 = a[1] + a[5], r2 = a[2] + a[6], r3 = a[3] + a[7];
+    return (r0 + r2) + (r1 + r3);
+}
+static inline void lanes8(const int wv[32], const int8_t *yq, float q[8]) {
+    for (int l = 0; l < 8; l++) {
+        int s4 = 0;
+        for (int j = 0; j < 4; j++) s4 += wv[4 * l + j] * yq[4 * l + j];
+        q[l] = (float)s4;
+    }
+}
+static float vec_dot_simd(int wtype, int64_t k, const void *w, const void *yv) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float summs  = 0.0f;
+    for (int64_t i = 0; i < k / QK; i++) {
+        int wv[32];
+        float d = 0.0f;
+        const int8_t *yq = NULL;
+        switch (wtype) {
+            case BO_TYPE_Q4_0: {
+                const blk_q4_0 *x = (const blk_q4_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                for (int j = 0; j < 16; j++) { wv[j] = (x[i].qs[j] & 0x0F) - 8; wv[j + 16] = (x[i].qs[j] >> 4) - 8; }
+                d = F16(x[i].d) * F16(y[i].d); yq = y[i].qs;
+            } break;
+            case BO_TYPE_Q5_0: {
+                const blk_q5_0 *x = (const blk_q5_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                uint32_t qh; memcpy(&qh, x[i].qh, 4);
+                for (int j = 0; j < 16; j++) {
+                    wv[j]      = ((x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4)) - 16;
+                    wv[j + 16] = ((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4)) - 16;
+                }
+                d = F16(x[i].d) * F16(y[i].d); yq = y[i].qs;
+            } break;
+            case BO_TYPE_Q8_0: {
+                const blk_q8_0 *x = (const blk_q8_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                for (int j = 0; j < 32; j++) wv[j] = x[i].qs[j];
+                d = F16(x[i].d) * F16(y[i].d); yq = y[i].qs;
+            } break;
+            case BO_TYPE_Q4_1: {
+                const blk_q4_1 *x = (const blk_q4_1 *)w; const blk_q8_1 *y = (const blk_q8_1 *)yv;
+                for (int j = 0; j < 16; j++) { wv[j] = (x[i].qs[j] & 0x0F); wv[j + 16] = (x[i].qs[j] >> 4); }
+                d = F16(x[i].d) * y[i].d; yq = y[i].qs;
+                summs += F16(x[i].m) * y[i].s;
+            } break;
+            case BO_TYPE_Q5_1: {
+                const blk_q5_1 *x = (const blk_q5_1 *)w; const blk_q8_1 *y = (const blk_q8_1 *)yv;
+                uint32_t qh; memcpy(&qh, x[i].qh, 4);
+                for (int j = 0; j < 16; j++) {
+                    wv[j]      = (x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4);
+                    wv[j + 16] = (x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4);
+                }
+                d = F16(x[i].d) * y[i].d; yq = y[i].qs;
+                summs += F16(x[i].m) * y[i].s;
+            } break;
+            default: return NAN;
+        }
+        float q[8];
+        lanes8(wv, yq, q);
+        for (int l = 0; l < 8; l++) acc[l] = fmaf(d, q[l], acc[l]);
+    }
+    return hsum8(acc) + summs;
+}
+/* ggml_vec_dot_f32 with GGML_SIMD (AVX2: step 32 = 4 accumulators x 8 lanes, fma; reduce 0+=2, 1+=3, 0+=1, then
+ * low128 + high128 and two hadds; scalar leftovers in float) */
+static float vec_dot_f32_simd(int64_t n, const float *x, const float *y) {
+    float sum[4][8];
+    memset(sum, 0, sizeof(sum));
+    const int64_t np = n & ~(int64_t)31;
+    for (int64_t i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++)
+            for (int l = 0; l < 8; l++) sum[j][l] = fmaf(x[i + 8 * j + l], y[i + 8 * j + l], sum[j][l]);
+    float t0[4];
+    for (int l = 0; l < 8; l++) { sum[0][l] += sum[2][l]; sum[1][l] += sum[3][l]; }
+    for (int l = 0; l < 8; l++) sum[0][l] += sum[1][l];
+    for (int l = 0; l < 4; l++) t0[l] = sum[0][l] + sum[0][l + 4];
+    float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+    for (int64_t i = np; i < n; i++) sumf += x[i] * y[i];
+    return sumf;
 }
 
 /* activation ("src1") row conversion to the weight type's vec_dot_type [SURVEY A.3] */
@@ -705,8 +822,13 @@ static void mul_mat(const bo_model *mdl, const bo_tensor *W, const float *x, int
     uint8_t *y      = NULL;
     if (vt != BO_TYPE_F32) {
         y = (uint8_t *)malloc(yb * (size_t)N + 64);
-        for (int n = 0; n < N; n++) bo_quantize(vt, x + (size_t)n * K, y + (size_t)n * yb, K, K);
+        for (int n = 0; n < N; n++) {
+            if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_0) quantize_row_q8_0_simd(x + (size_t)n * K, (blk_q8_0 *)(y + (size_t)n * yb), K);
+            else if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_1) quantize_row_q8_1_simd(x + (size_t)n * K, (blk_q8_1 *)(y + (size_t)n * yb), K);
+            else bo_quantize(vt, x + (size_t)n * K, y + (size_t)n * yb, K, K);
+        }
     }
+    const int simd = (mdl->opts.assoc & 1) && W->type != BO_TYPE_F32 && W->type != BO_TYPE_F16;
     const size_t wb   = bo_row_bytes(W->type, K);
     const int threads = mdl->opts.n_threads > 0 ? mdl->opts.n_threads : 1;
     (void)threads;
@@ -715,7 +837,9 @@ static void mul_mat(const bo_model *mdl, const bo_tensor *W, const float *x, int
         const uint8_t *wrow = (const uint8_t *)W->data + (size_t)mm * wb;
         for (int n = 0; n < N; n++) {
             const void *yy            = (vt == BO_TYPE_F32) ? (const void *)(x + (size_t)n * K) : (const void *)(y + (size_t)n * yb);
-            out[(size_t)n * M + mm]   = vec_dot_typed(W->type, K, wrow, yy);
+            out[(size_t)n * M + mm]   = simd ? vec_dot_simd(W->type, K, wrow, yy)
+                                             : ((mdl->opts.assoc & 1) && W->type == BO_TYPE_F32) ? vec_dot_f32_simd(K, (const float *)wrow, (const float *)yy)
+                                                                                               : vec_dot_typed(W->type, K, wrow, yy);
         }
     }
     free(y);
@@ -818,7 +942,8 @@ int bo_eval(bo_model *m, const int32_t *tokens, int N, int n_past, float *logits
             const float *qv = q + (size_t)i * D + (size_t)h * dk;
             int Tlim = T;
             if (m->opts.causal) Tlim = n_past + i + 1;
-            for (int j = 0; j < Tlim; j++) S[j] = vec_dot_f32(dk, Kl + (size_t)j * D + (size_t)h * dk, qv); /* KQ = mul_mat(K, Q) */
+            for (int j = 0; j < Tlim; j++) /* KQ = mul_mat(K, Q) */
+                S[j] = (m->opts.assoc & 1) ? vec_dot_f32_simd(dk, Kl + (size_t)j * D + (size_t)h * dk, qv) : vec_dot_f32(dk, Kl + (size_t)j * D + (size_t)h * dk, qv);
             /* ggml_soft_max */
             float mx = -INFINITY;
             for (int j = 0; j < Tlim; j++)
@@ -838,6 +963,14 @@ int bo_eval(bo_model *m, const int32_t *tokens, int N, int n_past, float *logits
             const float fsum = (float)sum;
             for (int j = 0; j < Tlim; j++) S[j] *= fsum; /* ggml_vec_scale_f32 */
             /* KQV = mul_mat(V_trans, attn_weights): dot over T for each of the dk dims */
+            if (m->opts.assoc & 1) { /* V_trans row (contiguous over the keys) . probabilities, SIMD-shaped */
+                float *vt_row = (float *)malloc(sizeof(float) * (size_t)Tlim);
+                for (int d = 0; d < dk; d++) {
+                    for (int j = 0; j < Tlim; j++) vt_row[j] = Vl[(size_t)j * D + (size_t)h * dk + d];
+                    att[(size_t)i * D + (size_t)h * dk + d] = vec_dot_f32_simd(Tlim, vt_row, S);
+                }
+                free(vt_row);
+            } else
             for (int d = 0; d < dk; d++) {
                 double acc = 0.0;
                 for (int j = 0; j < Tlim; j++) acc += (double)(Vl[(size_t)j * D + (size_t)h * dk + d] * S[j]);

@@ -46,6 +46,15 @@ typedef struct bo_opts {
     int   causal;     /* 0: no intra-chunk mask (reference); 1: causal mask (HF)         */
     float ln_eps;     /* 0 -> 1e-5 (biogpt.cpp:24); HF uses 1e-12                                    */
     int   n_threads;  /* 0 -> 1; rows of each mul_mat are split across threads (deterministic)      */
+    int   assoc;      /* bit mask; how ggml's SIMD kernels differ from its scalar fallbacks [ggml-recall, SURVEY A.2/A.3]:
+                       *   0      scalar fallbacks: one running f32 sum in block order; activations rounded half away from
+                       *          zero (roundf) with id = 1/d  -- the parity mode the HIP kernels are compared with
+                       *   bit 0  dots in the shape of the AVX2 kernels: 8 lane accumulators updated with fma per block and
+                       *          a horizontal add at the end; F32 dots (QK^T, PV) as 4 x 8-lane fma accumulators
+                       *   bit 1  activations quantized as the AVX2 kernels do: id = 127/amax, round to nearest-even
+                       *   3      both = what an AVX2 build of the reference computes
+                       * All are legal outcomes of "the reference's CPU path" (ggml is not bit-reproducible across ISAs);
+                       * tests/test_oracle_assoc.py measures the envelope between them. */
 } bo_opts;
 
 typedef struct bo_model bo_model;

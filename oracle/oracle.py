@@ -32,7 +32,7 @@ def build(force=False):
 
 class _Opts(C.Structure):
     _fields_ = [("gelu_erf", C.c_int), ("exp_f32", C.c_int), ("causal", C.c_int),
-                ("ln_eps", C.c_float), ("n_threads", C.c_int)]
+                ("ln_eps", C.c_float), ("n_threads", C.c_int), ("assoc", C.c_int)]
 
 
 _lib = None
@@ -127,7 +127,8 @@ def quantize_file(src, dst, ftype):
 class OracleModel:
     """CPU restatement of biogpt_model_load + biogpt_eval (biogpt.cpp:27-453, :624-847)."""
 
-    def __init__(self, path, n_threads=1, mode="ggml"):
+    def __init__(self, path, n_threads=1, mode="ggml", assoc=0):
+        self._assoc = int(assoc)
         err = C.create_string_buffer(256)
         self._h = lib().bo_load(path.encode(), err, 256)
         if not self._h:
@@ -150,6 +151,7 @@ class OracleModel:
         if causal is not None:
             o.causal = int(causal)
         o.n_threads = int(n_threads)
+        o.assoc = self._assoc     # 0: ggml's scalar fallbacks (the parity mode); 1: the shape of ggml's AVX2 kernels
         lib().bo_set_opts(self._h, C.byref(o))
 
     def eval(self, tokens, n_past, all_rows=False):

@@ -76,6 +76,24 @@ int main(int argc, char **argv) {
         for (int a = 4; a < argc; a++) prompt.push_back(std::atoi(argv[a]));
     }
 
+    if (argc >= 7 && std::string(argv[1]) == "--sample-only") {
+        // host-only check of biogpt_sample_top_k_top_p: argv = --sample-only FILE rows n_vocab top_k top_p temp [seed];
+        // FILE holds rows x n_vocab float32 logits; one id per row from ONE mt19937 stream
+        FILE *f = fopen(argv[2], "rb");
+        if (!f) return 1;
+        const int rows = std::atoi(argv[3]), nv = std::atoi(argv[4]);
+        biogpt_vocab vocab;
+        for (int i = 0; i < nv; i++) vocab.id_to_token[i] = "t";
+        std::vector<float> lg((size_t)nv);
+        std::mt19937 rng(argc >= 9 ? (unsigned)std::atoi(argv[8]) : 7u);
+        for (int r = 0; r < rows; r++) {
+            if (fread(lg.data(), 4, (size_t)nv, f) != (size_t)nv) return 1;
+            printf("%d ", biogpt_sample_top_k_top_p(vocab, lg.data(), std::atoi(argv[5]), std::atof(argv[6]), std::atof(argv[7]), rng));
+        }
+        printf("\n");
+        fclose(f);
+        return 0;
+    }
     Session s;
     if (!s.open(prm)) {
         fprintf(stderr, "failed to load model from '%s'\n", prm.model.c_str());

@@ -1,0 +1,171 @@
+"""The fused single-token decode step (csrc/kernels_decode.hip.h: 3 launches per layer, sampler folded into the next
+step's first kernel) against (a) the oracle and (b) the unfused five-launch chain it replaces, at BioGPT-base widths;
+the full 24-layer BioGPT-base configuration (biogpt.h:25-35); and bench.py's RCCL replica path on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ATOL = 1e-3
+KW = dict(n_vocab=42384, n_layer=3, n_head=16, n_positions=1024, d_ff=4096, d_model=1024, n_merges=40000)
+QUANT = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"]
+
+
+@pytest.fixture(scope="module")
+def files(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("fused")
+    f32 = str(d / "f32.bin")
+    pkg.write_synthetic(f32, **KW)
+    out = {"f32": f32}
+    for name in QUANT:
+        out[name] = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, out[name], name)
+    return out
+
+
+def _unfused(pkg, path, monkeypatch):
+    monkeypatch.setenv("BIOGPT_HIP_NO_FUSED_DECODE", "1")     # options are read when the context is created
+    g = pkg.BiogptModel.load(path)
+    monkeypatch.delenv("BIOGPT_HIP_NO_FUSED_DECODE")
+    return g
+
+
+@pytest.mark.parametrize("name", QUANT)
+def test_fused_step_equals_unfused_chain_and_oracle(pkg, oracle, files, monkeypatch, name):
+    """Single-token evals at positions around every context bucket of the fused kernels (64 / 128 / 192 / 256 keys) and
+    just past them (257 keys: both contexts run the unfused chain): logits bit-identical between the fused step and the
+    chain it replaces, and within the contract of the oracle (bit-identical in practice)."""
+    gf = pkg.BiogptModel.load(files[name])
+    gu = _unfused(pkg, files[name], monkeypatch)
+    o = oracle.OracleModel(files[name], n_threads=16)
+    rng = np.random.default_rng(17)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 259)]
+    checked = {0, 1, 2, 62, 63, 64, 65, 127, 128, 191, 192, 200, 254, 255, 256, 257}
+    n_past, worst, exact = 0, 0.0, 0
+    # the prompt part in reference chunks, the checked positions one token at a time
+    while n_past < len(toks):
+        if n_past in checked:
+            lf, lu, lo = gf.eval([toks[n_past]], n_past), gu.eval([toks[n_past]], n_past), o.eval([toks[n_past]], n_past)
+            assert (lf == lu).all(), "%s: fused != unfused at n_past %d (max diff %g)" % (name, n_past, np.abs(lf - lu).max())
+            worst = max(worst, float(np.abs(lf - lo).max()))
+            exact += int((lf == lo).all())
+            assert int(lf.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while n_past + m < len(toks) and (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            gf.eval_device(chunk, n_past); gu.eval_device(chunk, n_past); o.eval(chunk, n_past)
+            n_past += m
+    print("%s: fused step worst |diff| vs oracle %.2e, %d/%d positions bit-identical" % (name, worst, exact, len(checked)))
+    assert worst <= ATOL
+    # the KV rows the fused kernel appended are the oracle's
+    K = o.kv(0)
+    for l in (0, KW["n_layer"] - 1):
+        for pos in (0, 64, 255):
+            got = gf.read_kv(0, (l * KW["n_positions"] + pos) * KW["d_model"], KW["d_model"])
+            assert np.abs(got - K[l, pos]).max() <= ATOL
+    gf.close(); gu.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_generation_across_the_fused_range(pkg, oracle, files, monkeypatch, name):
+    """Greedy generation that starts inside the fused range and leaves it (contexts 247 .. 270 keys): the sampler that
+    lives in the next step's first kernel, the hand-over to the unfused graphs at 257 keys and the final sampler launch
+    must give the oracle's ids -- and the unfused build's."""
+    gf = pkg.BiogptModel.load(files[name])
+    gu = _unfused(pkg, files[name], monkeypatch)
+    rng = np.random.default_rng(23)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 245)]
+    ids_f, _ = gf.generate_greedy(prompt, 24, n_batch=8)
+    ids_u, _ = gu.generate_greedy(prompt, 24, n_batch=8)
+    ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompt, 24, n_batch=8)
+    assert list(ids_f) == list(ref) and list(ids_u) == list(ref)
+    for n_predict in (1, 2, 9):                      # ends inside the fused range; n_predict = 1 has no decode step at all
+        ids, _ = gf.generate_greedy(prompt[:5], n_predict, n_batch=8)
+        ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompt[:5], n_predict, n_batch=8)
+        assert list(ids) == list(ref), n_predict
+    # eager (no graph) loop: the fused kernels with the token taken from the device state
+    monkeypatch.setenv("BIOGPT_HIP_NO_GRAPH", "1")
+    gf.refresh_options()
+    monkeypatch.delenv("BIOGPT_HIP_NO_GRAPH")
+    ids_e, _ = gf.generate_greedy(prompt[:7], 12, n_batch=8)
+    ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompt[:7], 12, n_batch=8)
+    assert list(ids_e) == list(ref)
+    gf.close(); gu.close()
+
+
+@pytest.fixture(scope="module")
+def base24(pkg, tmp_path_factory):
+    """The full BioGPT-base configuration (24 layers, biogpt.h:25-35), synthetic seeded weights, Q4_0."""
+    d = tmp_path_factory.mktemp("base24")
+    f32, q40 = str(d / "f32.bin"), str(d / "q4_0.bin")
+    pkg.write_synthetic(f32, seed=0x42494F47, **dict(KW, n_layer=24))
+    pkg.quantize_file(f32, q40, "q4_0")
+    os.remove(f32)
+    return q40
+
+
+def test_biogpt_base_24_layers(pkg, oracle, base24):
+    """configs[1] at full depth: 32 teacher-forced single-token evals (logits vs the oracle) and the bench workload itself,
+    the 200-token greedy continuation of a 4-token prompt (README.md:29 ids), ids == oracle."""
+    g = pkg.BiogptModel.load(base24)
+    o = oracle.OracleModel(base24, n_threads=16)
+    assert g.hparams.n_layer == 24
+    prompt = [2, 7548, 1171, 32924]
+    lg, lo = g.eval(prompt, 0), o.eval(prompt, 0)
+    worst, exact, n_past = float(np.abs(lg - lo).max()), 0, 4
+    for _ in range(32):
+        t = int(lo.argmax())
+        assert int(lg.argmax()) == t
+        lg, lo = g.eval([t], n_past), o.eval([t], n_past)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        exact += int((lg == lo).all())
+        n_past += 1
+    print("24 layers: worst |diff| %.2e, %d/32 steps bit-identical" % (worst, exact))
+    assert worst <= ATOL
+    ids, secs = g.generate_greedy(prompt, 200, n_batch=8)
+    ref, _ = oracle.OracleModel(base24, n_threads=16).generate_greedy(prompt, 200, n_batch=8)
+    assert list(ids) == list(ref)
+    print("24 layers: 200 greedy ids identical, %.0f tok/s" % (200 / secs))
+    g.close()
+
+
+def _last_json_line(text):
+    lines = [ln for ln in text.strip().splitlines() if ln.strip()]
+    assert lines and lines[-1].lstrip().startswith("{"), "the JSON line must be the last line on stdout:\n" + text[-600:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("launcher", ["env", "torchrun"])
+def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
+    """configs[4] plumbing on the GPU that is here: bench.py with the real `nccl` (= RCCL) backend -- broadcast_hparams ->
+    biogpt_hip_load_into a torch-owned arena -> broadcast_arena -> timed region -> max_over_ranks -- replaces the single
+    load at examples/main/main.cpp:38.  The JSON line must be the last stdout line and the ids of the last continuation
+    must be the oracle's."""
+    dump = str(tmp_path / "ids.json")
+    env = dict(os.environ, BIOGPT_BENCH_DUMP_IDS=dump, BIOGPT_BENCH_DIR=str(tmp_path / "work"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--n-layer", "4", "--n-predict", "40"]
+    if launcher == "env":
+        env.update(BIOGPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        cmd = [sys.executable] + args
+    else:
+        env.update(BIOGPT_BENCH_FORCE_DIST="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29532"] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "replicas x1" in out["config"]["parallelism"]
+    assert "broadcast" in r.stderr                      # the arena went through the collective
+    rec = json.load(open(dump + ".rank0"))
+    ref, _ = oracle.OracleModel(rec["model"], n_threads=16).generate_greedy(rec["prompt"], 40, n_batch=8)
+    assert rec["ids"] == [int(v) for v in ref]

@@ -83,6 +83,7 @@ def test_prefill_mfma_attention_opt_in(pkg, oracle, files, name, monkeypatch):
     rng = np.random.default_rng(5)
     toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 39)]
     monkeypatch.setenv("BIOGPT_HIP_PREFILL_MFMA", "1")
+    g.refresh_options()                               # the switches are cached when the context is created
     worst, n_past = 0.0, 0
     for n in (8, 8, 8, 5, 8, 3):                      # full chunks, ragged chunks, growing context
         chunk = toks[n_past:n_past + n]
@@ -93,6 +94,7 @@ def test_prefill_mfma_attention_opt_in(pkg, oracle, files, name, monkeypatch):
         assert int(lg.argmax()) == int(lo.argmax()) or lo.max() - lo[int(lg.argmax())] <= 2 * diff
         n_past += n
     monkeypatch.delenv("BIOGPT_HIP_PREFILL_MFMA")
+    g.refresh_options()
     lg, lo = g.eval([toks[0]], n_past), o.eval([toks[0]], n_past)   # decode on top of the MFMA-built cache
     worst = max(worst, float(np.abs(lg - lo).max()))
     print("%s MFMA prefill: worst |diff| %.2e" % (name, worst))

@@ -190,6 +190,7 @@ def test_prompt_pass_equals_chunk_by_chunk_evals(loaded, pkg, tiny_models, promp
     its own n_batch-chunk would have seen -> the same logits, the same KV rows and the same continuation as
     the reference's chunk-by-chunk prompt loop (oracle), for chunk sizes that do and do not divide the pass."""
     g, o = loaded(name)
+    g.refresh_options()          # the switches are cached per context; this one was loaded by an earlier test
     n_past, lo = 0, None
     while n_past < len(LONG_PROMPT):
         c = LONG_PROMPT[n_past:n_past + n_batch]

@@ -1,0 +1,53 @@
+"""What "within 1e-3 of the reference's logits" can mean: the reference's arithmetic is ggml's CPU backend, whose f32
+association and activation rounding differ between its scalar fallbacks and its SIMD kernels, so the
+reference itself is not one function of its inputs.  The oracle restates both shapes (biogpt_oracle.h, bo_opts.assoc);
+this test measures the envelope between them on the 3-layer BioGPT-base-width model the GPU tests use.  The HIP kernels
+are compared with assoc = 0 (bit-identical); DESIGN.md section 3 quotes the numbers printed here."""
+import numpy as np
+import pytest
+
+KW = dict(n_vocab=42384, n_layer=3, n_head=16, n_positions=1024, d_ff=4096, d_model=1024, n_merges=40000)
+
+
+@pytest.fixture(scope="module")
+def files(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("assoc")
+    f32 = str(d / "f32.bin")
+    pkg.write_synthetic(f32, **KW)                    # host-side writer / quantizer of the build: no GPU needed
+    out = {"f32": f32}
+    for name in ("q4_0", "q8_0"):
+        out[name] = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, out[name], name)
+    return out
+
+
+def _envelope(oracle, path, assoc, steps=24):
+    a = oracle.OracleModel(path, n_threads=8, assoc=0)
+    b = oracle.OracleModel(path, n_threads=8, assoc=assoc)
+    rng = np.random.default_rng(11)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 7)]
+    la, lb = a.eval(prompt, 0), b.eval(prompt, 0)
+    worst, agree, n_past = float(np.abs(la - lb).max()), int(la.argmax() == lb.argmax()), 8
+    for _ in range(steps):                            # teacher-forced with the scalar mode's greedy ids
+        t = int(la.argmax())
+        la, lb = a.eval([t], n_past), b.eval([t], n_past)
+        worst = max(worst, float(np.abs(la - lb).max()))
+        agree += int(la.argmax() == lb.argmax())
+        n_past += 1
+    return worst, agree, steps + 1, float(np.abs(la).max())
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q8_0", "f32"])
+def test_envelope_between_ggml_association_modes(oracle, files, name):
+    rows = []
+    for assoc, what in ((1, "8-lane fma dots"), (2, "nearest-even activations, id = 127/amax"), (3, "both (AVX2 shape)")):
+        worst, agree, n, scale = _envelope(oracle, files[name], assoc)
+        rows.append((assoc, worst, agree, n))
+        print("%s  assoc %d (%s): max |dlogit| vs scalar mode %.3e (logit scale %.2f), arg-max equal %d/%d" % (name, assoc, what, worst, scale, agree, n))
+    # the modes are the same model: the envelope is a fraction of the logit scale, and not zero (they do differ)
+    assert all(0.0 < w < 0.15 for _, w, _, _ in rows if name != "f32" or _ != 2)
+    if name == "f32":
+        assert rows[1][1] == 0.0                      # no activation quantization with float weights
+        assert rows[0][1] < 5e-3
+    # quantized weights: even the pure association change exceeds the 1e-3 logit contract of north_star, because a
+    # 1-ulp difference can flip an int8 code of a downstream Q8 activation block -- documented, not asserted as a bar

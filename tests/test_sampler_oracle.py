@@ -1,0 +1,72 @@
+"""biogpt_sample_top_k_top_p (biogpt.cpp:908-980): the product's host sampler (csrc/compat.cpp, called through the C++
+compat driver) against the oracle's restatement (oracle/sampler.py: own Mersenne Twister stream + libstdc++'s
+discrete_distribution algorithm spelled out) -- same seed, same logits => same ids."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_compat import _build_driver
+
+
+def _sample_ref(oracle_sampler, logits_rows, top_k, top_p, temp, seed=7):
+    rng = oracle_sampler.Mt19937(seed)
+    return [oracle_sampler.sample_top_k_top_p(row, top_k, top_p, temp, rng) for row in logits_rows]
+
+
+@pytest.fixture(scope="module")
+def oracle_sampler():
+    from oracle import sampler
+    return sampler
+
+
+def test_mt19937_known_answer(oracle_sampler):
+    r = oracle_sampler.Mt19937(5489)                  # ISO C++ [rand.predef]: the 10000th output of mt19937() is 4123659995
+    v = 0
+    for _ in range(10000):
+        v = r()
+    assert v == 4123659995
+
+
+@pytest.mark.parametrize("top_k,top_p,temp", [(40, 0.9, 0.9), (40, 1.0, 1.0), (5, 0.5, 0.7), (1, 0.9, 0.9), (320, 0.95, 1.3)])
+def test_host_sampler_equals_restatement_on_random_logits(pkg, oracle_sampler, tmp_path, top_k, top_p, temp):
+    exe = _build_driver(pkg, tmp_path)
+    rng = np.random.default_rng(top_k * 131 + int(temp * 10))
+    rows, nv = 64, 320
+    lg = (rng.standard_normal((rows, nv)) * 2.5).astype(np.float32)
+    path = str(tmp_path / "logits.bin")
+    lg.tofile(path)
+    fp, ft = float(np.float32(top_p)), float(np.float32(temp))      # the CLI's floats (biogpt.h:115-116), widened
+    r = subprocess.run([exe, "--sample-only", path, str(rows), str(nv), str(top_k), repr(fp), repr(ft), "7"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [int(t) for t in r.stdout.split()]
+    assert got == _sample_ref(oracle_sampler, lg, top_k, fp, ft)
+    if top_k > 1:
+        assert len(set(got)) > 4                       # it does sample
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["q8_0", "q4_1"])
+def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny_models, tmp_path, name):
+    """The reference's loop with its default sampler settings (top_k 40, top_p 0.9, temp 0.9; main.cpp:109-128) through
+    the compat driver on the GPU, against oracle logits + restated sampler with the same seed."""
+    exe = _build_driver(pkg, tmp_path)
+    prompt = [2, 17, 45, 300, 9]
+    r = subprocess.run([exe, tiny_models[name], "24", "40"] + [str(t) for t in prompt], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [int(t) for t in r.stdout.split()]
+    o = oracle.OracleModel(tiny_models[name], n_threads=2)
+    rng = oracle_sampler.Mt19937(7)
+    lg = o.eval(prompt, 0)
+    n_past, ref = len(prompt), []
+    fp, ft = float(np.float32(0.9)), float(np.float32(0.9))
+    for k in range(24):
+        t = oracle_sampler.sample_top_k_top_p(lg, 40, fp, ft, rng)
+        ref.append(t)
+        if k + 1 < 24:
+            lg = o.eval([t], n_past)
+            n_past += 1
+    assert got == ref
+    assert len(set(got)) > 3
