@@ -165,7 +165,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min, prefill_mfma,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -188,6 +188,7 @@ struct EngineOptions {
         no_fused_decode = get("BIOGPT_HIP_NO_FUSED_DECODE", 0);
         fc1_blocks = get("BIOGPT_HIP_FC1_BLOCKS", 1);
         fc2_waves = get("BIOGPT_HIP_FC2_WAVES", 16);
+        oproj_waves = get("BIOGPT_HIP_OPROJ_WAVES", 16);
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
 };
@@ -243,7 +244,6 @@ struct biogpt_hip_ctx {
     std::set<const void *> lds_attr_done;     // kernels whose > 64 KB dynamic-LDS opt-in attribute is set on this device
     unsigned long long *tstamp = nullptr;     // profiling only (opt.dbg & 32)
     int launch_parity = 0;
-    float *terms = nullptr;                   // fused decode step: out_proj block terms [32][1024]
     hipGraphExec_t graph_batch[6] = {};   // [context bucket], captured for graph_batch_n sequences
     int graph_batch_n = 0;
 
@@ -533,13 +533,20 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
 bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max) {
     const auto &hp = c->hp;
     return is_quantized(ftype_to_type(hp.ftype)) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 && t_max <= 256 &&
-           hp.n_positions >= 64 && !c->opt.no_fast && !c->opt.no_chain && !c->opt.no_fused_decode && c->terms != nullptr;
+           hp.n_positions >= 64 && !c->opt.no_fast && !c->opt.no_chain && !c->opt.no_fused_decode;
 }
 
 template <int WT>
-hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecAttnParams &a, const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2) {
+hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, const bgk::DecAttnParams &at, const bgk::DecOprojParams &op,
+                               const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2) {
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL((bgk::dec_attn_kernel<WT>), dim3(16), dim3(1024), bgk::dec_attn_smem_bytes(), st, a);
+    hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
+    if (at.t_cap <= 64) hipLaunchKernelGGL(bgk::dec_attn_kernel<16>, dim3(16), dim3(1024), 0, st, at);
+    else if (at.t_cap <= 128) hipLaunchKernelGGL(bgk::dec_attn_kernel<8>, dim3(16), dim3(1024), 0, st, at);
+    else hipLaunchKernelGGL(bgk::dec_attn_kernel<4>, dim3(16), dim3(1024), 0, st, at);
+    if (c->opt.oproj_waves == 4) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 4>), dim3(128), dim3(256), bgk::dec_oproj_smem_bytes(4), st, op);
+    else if (c->opt.oproj_waves == 8) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 8>), dim3(64), dim3(512), bgk::dec_oproj_smem_bytes(8), st, op);
+    else hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 16>), dim3(32), dim3(1024), bgk::dec_oproj_smem_bytes(16), st, op);
     if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
     else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
     if (c->opt.fc2_waves == 4) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 4>), dim3(256), dim3(256), bgk::dec_fc2_smem_bytes(4), st, f2);
@@ -564,9 +571,11 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     if (lm_parts > c->pmax_cap) BG_FAIL(false, "internal: arg-max partial buffer too small (%d > %d)", lm_parts, c->pmax_cap);
     const int32_t wt = ftype_to_type(hp.ftype);
     const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
+    unsigned long long *const ts = (c->opt.dbg & 96) ? c->tstamp : nullptr;
+    unsigned long long *const wall = (c->opt.dbg & 64) ? c->tstamp + 128 : nullptr;
     for (int l = 0; l < hp.n_layer; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
-        bgk::DecAttnParams a{};
+        bgk::DecQkvParams a{};
         a.x = c->x; a.x_out = c->x;
         a.tok_emb = dev_matrix(c, c->plan.embed_tokens); a.pos_emb = dev_matrix(c, c->plan.embed_pos);
         a.embed_scale = sqrtf((float)D);
@@ -575,29 +584,37 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         a.st = c->state; a.n_positions = P; a.n_vocab = V;
         a.ln_w = dev_vec(c, L.ln0_w); a.ln_b = dev_vec(c, L.ln0_b); a.eps = 1e-5f;
         a.Wqkv = dev_matrix(c, L.qkv); a.bqkv = dev_vec(c, L.qkv_b); a.q_scale = 1.0f / sqrtf(64.0f);
-        a.kcache = c->memory_k + (size_t)l * P * D; a.vcache = c->memory_v + (size_t)l * P * D;
-        a.P = P; a.t_cap = std::min(P, (t_max + 63) & ~63);
-        a.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
-        a.Wo = dev_matrix(c, L.o); a.terms = c->terms; a.att_out = nullptr; a.q81 = q81;
-        a.tstamp = (c->opt.dbg & 96) ? c->tstamp : nullptr; a.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; a.wall_slot = 3 * l;
+        a.q_out = c->q;
+        a.kcache = c->memory_k + (size_t)l * P * D; a.vcache = c->memory_v + (size_t)l * P * D; a.P = P;
+        a.tstamp = ts; a.wall = wall; a.wall_slot = 5 * l;
+        bgk::DecAttnParams at{};
+        at.q = c->q; at.kcache = a.kcache; at.vcache = a.vcache; at.st = c->state; at.P = P;
+        at.t_cap = std::min(P, (t_max + 63) & ~63);
+        at.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
+        at.oq_q = c->aq_q[0]; at.oq_d = c->aq_d[0]; at.oq_s = c->aq_s[0]; at.att_out = nullptr; at.q81 = q81;
+        at.tstamp = ts ? ts + 16 : nullptr; at.wall = wall; at.wall_slot = 5 * l + 1;
+        bgk::DecOprojParams op{};
+        op.Wo = dev_matrix(c, L.o); op.aq_q = c->aq_q[0]; op.aq_d = c->aq_d[0]; op.aq_s = c->aq_s[0];
+        op.bias = dev_vec(c, L.o_b); op.resid = c->x; op.out = c->x1;
+        op.tstamp = ts ? ts + 32 : nullptr; op.wall = wall; op.wall_slot = 5 * l + 2;
         bgk::DecFc1Params f1{};
-        f1.terms = c->terms; f1.x = c->x; f1.bo = dev_vec(c, L.o_b); f1.x1_out = c->x1;
+        f1.x1 = c->x1;
         f1.ln_w = dev_vec(c, L.ln1_w); f1.ln_b = dev_vec(c, L.ln1_b); f1.eps = 1e-5f;
         f1.W1 = dev_matrix(c, L.fc1); f1.b1 = dev_vec(c, L.fc1_b);
         f1.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
         f1.oq_q = c->aq_q[1]; f1.oq_d = c->aq_d[1]; f1.oq_s = c->aq_s[1]; f1.q81 = q81;
-        f1.tstamp = (c->opt.dbg & 96) ? c->tstamp + 16 : nullptr; f1.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; f1.wall_slot = 3 * l + 1;
+        f1.tstamp = ts ? ts + 48 : nullptr; f1.wall = wall; f1.wall_slot = 5 * l + 3;
         bgk::DecFc2Params f2{};
         f2.W2 = dev_matrix(c, L.fc2); f2.aq_q = c->aq_q[1]; f2.aq_d = c->aq_d[1]; f2.aq_s = c->aq_s[1];
         f2.bias = dev_vec(c, L.fc2_b); f2.resid = c->x1; f2.out = c->x;
-        f2.tstamp = (c->opt.dbg & 96) ? c->tstamp + 32 : nullptr; f2.wall = (c->opt.dbg & 64) ? c->tstamp + 64 : nullptr; f2.wall_slot = 3 * l + 2;
+        f2.tstamp = ts ? ts + 64 : nullptr; f2.wall = wall; f2.wall_slot = 5 * l + 4;
         hipError_t e = hipErrorInvalidValue;
         switch (wt) {
-            case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, f1, f2); break;
-            case T_Q4_1: e = launch_decode_layer<bgk::W_Q4_1>(c, a, f1, f2); break;
-            case T_Q5_0: e = launch_decode_layer<bgk::W_Q5_0>(c, a, f1, f2); break;
-            case T_Q5_1: e = launch_decode_layer<bgk::W_Q5_1>(c, a, f1, f2); break;
-            case T_Q8_0: e = launch_decode_layer<bgk::W_Q8_0>(c, a, f1, f2); break;
+            case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, at, op, f1, f2); break;
+            case T_Q4_1: e = launch_decode_layer<bgk::W_Q4_1>(c, a, at, op, f1, f2); break;
+            case T_Q5_0: e = launch_decode_layer<bgk::W_Q5_0>(c, a, at, op, f1, f2); break;
+            case T_Q5_1: e = launch_decode_layer<bgk::W_Q5_1>(c, a, at, op, f1, f2); break;
+            case T_Q8_0: e = launch_decode_layer<bgk::W_Q8_0>(c, a, at, op, f1, f2); break;
             default: break;
         }
         HIP_TRY(false, e);
@@ -868,7 +885,6 @@ bool alloc_runtime(biogpt_hip_ctx *c) {
     HIP_TRY(false, hipMalloc(&c->pmax_idx, (size_t)c->pmax_cap * 4));
     HIP_TRY(false, hipMemset(c->pmax_val, 0, (size_t)c->pmax_cap * 4));
     HIP_TRY(false, hipMemset(c->pmax_idx, 0, (size_t)c->pmax_cap * 4));
-    HIP_TRY(false, hipMalloc(&c->terms, (size_t)32 * 1024 * 4));
     c->state_bytes = sizeof(bgk::DevState) + 2 * P * 4;
     HIP_TRY(false, hipMalloc(&c->state, c->state_bytes));
     HIP_TRY(false, hipMemset(c->state, 0, c->state_bytes));
@@ -989,7 +1005,6 @@ void destroy(biogpt_hip_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->logits_host) (void)hipHostFree(c->logits_host);
-    if (c->terms) (void)hipFree(c->terms);
     if (c->tstamp) (void)hipFree(c->tstamp);
     if (c->tok_vocab) bg::drop_vocab(c->tok_vocab);
     delete c;
@@ -1642,43 +1657,57 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
     if ((ctx->opt.dbg & 64) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
         // wall-clock (100 MHz) entry / exit of every workgroup of the last replay: per kernel, relative to the previous kernel's last exit
-        const int nk = 3 * ctx->hp.n_layer;
+        const int nk = 5 * ctx->hp.n_layer;
         std::vector<unsigned long long> w((size_t)nk * 2048);
-        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp + 64, w.size() * 8, hipMemcpyDeviceToHost));
-        const int grids[3] = {16, ctx->opt.fc1_blocks == 2 ? 64 : 128, ctx->opt.fc2_waves == 4 ? 256 : ctx->opt.fc2_waves == 8 ? 128 : 64};
-        const char *kn[3] = {"dec_attn", "dec_fc1 ", "dec_fc2 "};
-        double acc[3][5] = {};
+        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp + 128, w.size() * 8, hipMemcpyDeviceToHost));
+        const int grids[5] = {96, 16, ctx->opt.oproj_waves == 4 ? 128 : ctx->opt.oproj_waves == 8 ? 64 : 32, ctx->opt.fc1_blocks == 2 ? 64 : 128,
+                              ctx->opt.fc2_waves == 4 ? 256 : ctx->opt.fc2_waves == 8 ? 128 : 64};
+        const char *kn[5] = {"dec_qkv  ", "dec_attn ", "dec_oproj", "dec_fc1  ", "dec_fc2  "};
+        double acc[5][5] = {};
         unsigned long long prev_exit = 0;
         for (int k = 0; k < nk; k++) {
             unsigned long long e0 = ~0ull, e1 = 0, x0 = ~0ull, x1 = 0;
-            for (int g = 0; g < grids[k % 3]; g++) {
+            for (int g = 0; g < grids[k % 5]; g++) {
                 const unsigned long long en = w[((size_t)k * 1024 + g) * 2], ex = w[((size_t)k * 1024 + g) * 2 + 1];
                 e0 = std::min(e0, en); e1 = std::max(e1, en); x0 = std::min(x0, ex); x1 = std::max(x1, ex);
             }
-            if (k >= 3) {   // skip layer 0 (no previous stamp)
-                acc[k % 3][0] += (double)(long long)(e0 - prev_exit); acc[k % 3][1] += (double)(e1 - e0);
-                acc[k % 3][2] += (double)(x0 - e0); acc[k % 3][3] += (double)(x1 - e0); acc[k % 3][4] += 1.0;
+            if (k >= 5) {   // skip layer 0 (no previous stamp; embedding variant)
+                acc[k % 5][0] += (double)(long long)(e0 - prev_exit); acc[k % 5][1] += (double)(e1 - e0);
+                acc[k % 5][2] += (double)(x0 - e0); acc[k % 5][3] += (double)(x1 - e0); acc[k % 5][4] += 1.0;
             }
             prev_exit = x1;
         }
-        fprintf(stderr, "wall-clock timeline per kernel (us, mean over layers 1..): prev last exit -> first entry | entry spread | first exit | last exit (from first entry)\n");
-        for (int j = 0; j < 3; j++)
+        fprintf(stderr, "wall-clock timeline per kernel (us, mean over layers 1..): previous kernel's last exit -> first entry | entry spread | first exit | last exit (from first entry)\n");
+        double tot = 0.0;
+        for (int j = 0; j < 5; j++) {
             fprintf(stderr, "   %s  gap %.2f | entries within %.2f | first exit %.2f | last exit %.2f\n", kn[j], acc[j][0] / acc[j][4] * 0.01,
                     acc[j][1] / acc[j][4] * 0.01, acc[j][2] / acc[j][4] * 0.01, acc[j][3] / acc[j][4] * 0.01);
+            tot += (acc[j][0] + acc[j][3]) / acc[j][4] * 0.01;
+        }
+        fprintf(stderr, "   one layer = %.2f us\n", tot);
     }
     if ((ctx->opt.dbg & 32) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
-        // fused step, last layer, workgroup 0 / thread 0 (needs a build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS)
-        unsigned long long h[48];
+        // per-segment shader-clock stamps, last layer, workgroup 0 / thread 0 (build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS)
+        unsigned long long h[80];
         HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));
-        const char *an[5] = {"entry -> loads issued, x / token known", "-> LayerNorm + Q8 in LDS", "-> q/k/v rows finished, KV appended", "-> attention output quantized", "-> out_proj terms stored"};
-        const char *fn[4] = {"entry -> terms summed (x1)", "-> LayerNorm + Q8 in LDS", "-> rows finished, GELU", "-> Q8 block stored"};
-        const char *gn[3] = {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store"};
-        fprintf(stderr, "dec_attn_kernel segments (shader cycles):\n");
-        for (int k = 0; k < 5; k++) fprintf(stderr, "   %-42s %7lld\n", an[k], (long long)(h[k + 1] - h[k]));
-        fprintf(stderr, "   attn exit -> fc1 entry %lld\ndec_fc1_kernel segments:\n", (long long)(h[16] - h[5]));
-        for (int k = 0; k < 4; k++) fprintf(stderr, "   %-42s %7lld\n", fn[k], (long long)(h[16 + k + 1] - h[16 + k]));
-        fprintf(stderr, "   fc1 exit -> fc2 entry %lld\ndec_fc2_kernel segments:\n", (long long)(h[32] - h[20]));
-        for (int k = 0; k < 3; k++) fprintf(stderr, "   %-42s %7lld\n", gn[k], (long long)(h[32 + k + 1] - h[32 + k]));
+        struct Seg { const char *kernel; int base, n; const char *names[5]; };
+        const Seg segs[5] = {
+            {"dec_qkv_kernel", 0, 3, {"entry -> loads issued / token embedded", "-> LayerNorm + Q8 in LDS", "-> rows finished, q / KV stored", "", ""}},
+            {"dec_attn_kernel", 16, 4, {"entry -> loads issued", "-> scores + max", "-> exp table, sum", "-> PV, Q8, stored", ""}},
+            {"dec_oproj_kernel", 32, 3, {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store", "", ""}},
+            {"dec_fc1_kernel", 48, 4, {"entry -> loads issued", "-> LayerNorm + Q8 in LDS", "-> rows finished, GELU", "-> Q8 block stored", ""}},
+            {"dec_fc2_kernel", 64, 3, {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store", "", ""}},
+        };
+        for (const Seg &sg : segs) {
+            fprintf(stderr, "%s segments (shader cycles, workgroup 0 / wave 0):\n", sg.kernel);
+            for (int k = 0; k < sg.n; k++) fprintf(stderr, "   %-42s %7lld\n", sg.names[k], (long long)(h[sg.base + k + 1] - h[sg.base + k]));
+            if (sg.base == 0 || sg.base == 48) {   // inside the shared LayerNorm + Q8
+                const char *ln[7] = {"loads issued -> column arrived", "-> wave sum 1 stored", "-> barrier 1", "-> mean, wave sum 2 stored", "-> barrier 2", "-> normalised value", "-> Q8 written"};
+                const unsigned long long t0 = h[sg.base + 1];
+                unsigned long long prev = t0;
+                for (int k = 0; k < 7; k++) { fprintf(stderr, "      %-39s %7lld\n", ln[k], (long long)(h[sg.base + 8 + k] - prev)); prev = h[sg.base + 8 + k]; }
+            }
+        }
     } else if ((ctx->opt.dbg & 32) && ctx->tstamp) {
         unsigned long long h[16 * 8];
         HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));

@@ -1,26 +1,27 @@
 // Single-token decode at BioGPT-base shapes (d_model 1024, d_ff 4096, 16 heads of 64, block-quantized weights,
-// contexts up to 256 keys): the five dependent launches per layer of the first chain (LN+QKV, attention, out_proj,
-// LN+fc1, fc2) become THREE, and the embedding / arg-max launches disappear.
+// contexts up to 256 keys): five launches per layer like the first chain (kernels_fast.hip.h), but with the embedding
+// and the sampler folded into the first one (122 -> 121 ... -> 5 x 24 + 1 launches per token), every kernel built for
+// the SHORTEST dependent-instruction chain, and 16-wave workgroups that share the LayerNorm statistics.
 //
-// Why this shape (measured on the MI355X, tools/microbench4.hip, profiles/microbench4_r2.txt):
-//   * a dependent kernel boundary costs 1.58 us whatever the grid (16..512 workgroups, 256 or 1024 threads, LDS,
-//     kernarg size); an in-launch last-arriver ticket (sc1 stores -> drain -> agent atomic -> sc1 loads) costs
-//     1.9-2.5 us -- MORE than the boundary it would replace.  So no cross-workgroup hand-offs: every fusion below is
-//     workgroup-local, and a token is 3 x 24 + 1 = 73 launches instead of 122;
-//   * one 1024-thread workgroup pulls 128 KB issued at once in ~1.0 us beyond the boundary (256 KB: 2.2 us), so a
-//     head's whole working set (q/k/v rows 110 KB, its K/V rows, its out_proj columns 36 KB) can go through ONE
-//     compute unit;
-//   * 16 waves per workgroup share the LayerNorm statistics (each wave 1/16 of the column + one LDS exchange)
-//     instead of every wave re-reducing the whole column in double.
+// What bounds this path, measured on the MI355X (tools/microbench4-7.hip, profiles/microbench*_r2.txt):
+//   * a dependent kernel boundary: 1.58 us for an empty kernel whatever its shape; last exit -> next first entry is
+//     1.3-1.5 us for the real kernels (wall clock, profiles/decode_*_timeline_r2.txt);
+//   * a wave issues ONE instruction per 4 cycles (2048 straight-line VALU instructions: 8324 cycles warm, 8750 cold --
+//     the instruction cache is not the limit): a kernel's body is its per-wave instruction count, so the work is spread
+//     over 16 waves per workgroup and nothing is recomputed per wave;
+//   * cross-workgroup hand-offs INSIDE a launch are dearer than the boundary they would replace: last-arriver ticket
+//     (sc1 stores -> drain -> agent atomic -> sc1 loads) +1.9 us at 16 arrivers; device-wide flag barrier 3.3 us at
+//     256 workgroups (1.25 us at 32);
+//   * one workgroup can pull ~100 GB/s: fusions that put a head's q/k/v rows (110 KB) + K/V + out_proj slice through
+//     ONE compute unit were built and measured (13.3 us per layer for that kernel; profiles/decode_fused_per_head_*):
+//     slower than separate launches.  Hence: every launch spreads its bytes over >= 32 compute units.
 //
-//   dec_attn_kernel   one workgroup per HEAD: [embedding (+ arg-max of the previous token's logits partials)] ->
-//                     LayerNorm -> Q8 -> the head's 192 q/k/v rows -> KV append -> attention over the cache ->
-//                     Q8 of the head's 64 outputs -> the head's two out_proj block terms for all 1024 rows
-//                     biogpt.cpp:664-686, :691-764, :767 (the mat-mul part)
-//   dec_fc1_kernel    x1 = x + b_o + sum of the 32 out_proj block terms IN BLOCK ORDER (the reference's scalar
-//                     association) -> LayerNorm -> Q8 -> fc1 rows -> bias -> GELU table -> Q8 block(s) for fc2
-//                     biogpt.cpp:767-787
-//   dec_fc2_kernel    fc2 + bias + residual, one row per wave, 16 rows per workgroup        biogpt.cpp:790-795
+//   dec_qkv_kernel    [embedding (+ arg-max of the previous token's logits partials)] -> LayerNorm -> Q8 -> q/k/v rows
+//                     -> Q scale, KV append                                                    biogpt.cpp:664-727
+//   dec_attn_kernel   one workgroup per head: scores, fp16-table softmax, PV, Q8 of the 64 outputs  biogpt.cpp:729-764
+//   dec_oproj_kernel  out_proj + bias + residual                                                    biogpt.cpp:767-772
+//   dec_fc1_kernel    LayerNorm -> Q8 -> fc1 rows -> bias -> GELU table -> Q8 block(s) for fc2       biogpt.cpp:777-787
+//   dec_fc2_kernel    fc2 + bias + residual, one row per wave                                        biogpt.cpp:790-795
 //   (lm_head stays matvec_fast_kernel<EPI_LOGITS>; its block 0 advances the device-side position.)
 //
 // Arithmetic per element is that of kernels_fast.hip.h (and of the oracle): same Q8 activations, same integer block
@@ -55,6 +56,15 @@ __device__ __forceinline__ int group32_sum(int v) {
     return sum_xor16(v);
 }
 
+// kernel outputs that the NEXT launch reads.  Write-through (sc1) stores were measured against plain stores: 1.60 vs
+// 1.77 us per producer launch in isolation (microbench6), but no gain in the decode chain (462 vs 459 us per token), so
+// plain stores stay; -DBIOGPT_HIP_SC1_STORES rebuilds the other arm.
+#ifdef BIOGPT_HIP_SC1_STORES
+#define DEC_STORE_F32(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define DEC_STORE_F32(ptr, val) (*(ptr) = (val))
+#endif
+
 #ifdef BIOGPT_HIP_PROFILE_HOOKS   // make EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS: per-segment shader-clock stamps of workgroup 0, wave 0
 #define DEC_STAMP(k) do { if (p.tstamp && blockIdx.x == 0 && threadIdx.x == 0) p.tstamp[(k)] = __builtin_readcyclecounter(); } while (0)
 // dbg & 64: entry / exit of EVERY workgroup on the constant 100 MHz clock, [slot][1024 workgroups][2] after the segment stamps
@@ -65,43 +75,68 @@ __device__ __forceinline__ int group32_sum(int v) {
 #define DEC_WALL(which) do {} while (0)
 #endif
 
-// LayerNorm (ggml_norm + affine, double statistics) and Q8_0 / Q8_1 quantization of ONE 1024-element column by a
-// 1024-thread workgroup, thread t holding element t.  Leaves the 32 activation blocks in LDS (s_xq / s_xd / s_xs).
-// s_red: 32 doubles.  Ends with a workgroup barrier.
+// LayerNorm (ggml_norm + affine, double statistics) and Q8_0 / Q8_1 quantization of ONE 1024-element column inside a
+// 1024-thread workgroup.  Measured (profiles/decode_5kernel_timeline_r2.txt): with all 16 waves taking part (one element per
+// thread) the double-precision adds of 16 waves contend for the SIMDs and every barrier waits for the slowest wave --
+// 4300 cycles; so waves 0-3 do it alone (thread t < 256 holds elements 4t .. 4t+3, 8 lanes = one Q8 block; the
+// arithmetic of lnq_kernel) while waves 4-15 are parked at the barriers.  Leaves the 32 activation blocks in LDS
+// (s_xq / s_xd / s_xs); s_red: 8 doubles.  Every thread of the workgroup must call it; ends with a workgroup barrier.
+#ifdef BIOGPT_HIP_PROFILE_HOOKS
+#define LN_STAMP(k) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LN_STAMP(k) do {} while (0)
+#endif
 template <bool Q81>
-__device__ __forceinline__ void coop_ln_q8_1024(float xv, float lnw, float lnb, float eps, double *s_red, uint32_t *s_xq, float *s_xd,
-                                                uint32_t *s_xs) {
+__device__ __forceinline__ void ln4_q8_1024(float4 v, float4 lw, float4 lb, float eps, double *s_red, uint32_t *s_xq, float *s_xd,
+                                            uint32_t *s_xs, unsigned long long *ts = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool worker = tid < 256;
     const double inv_k = 1.0 / 1024.0;
-    const double s1 = wave_sum_f64((double)xv);
-    if (lane == 0) s_red[wave] = s1;
-    __syncthreads();
-    double t1 = 0.0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) t1 += s_red[w];
-    const float mean = (float)(t1 * inv_k);
-    const float dv = __fsub_rn(xv, mean);
-    const double s2 = wave_sum_f64((double)__fmul_rn(dv, dv));
-    if (lane == 0) s_red[16 + wave] = s2;
-    __syncthreads();
-    double t2 = 0.0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) t2 += s_red[16 + w];
-    const float var = (float)(t2 * inv_k);
-    const float scale = 1.0f / sqrtf(__fadd_rn(var, eps));
-    const float y = __fadd_rn(__fmul_rn(lnw, __fmul_rn(dv, scale)), lnb);
-    // quantize_row_q8_0 / q8_1: one block = 32 consecutive lanes
-    const float amax = group32_max(fabsf(y));
-    const float d = amax / 127.0f;
-    const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
-    const int q = (int)roundf(__fmul_rn(y, id));
-    const int isum = group32_sum(q);
-    reinterpret_cast<int8_t *>(s_xq)[tid] = (int8_t)q;
-    if ((lane & 31) == 0) {
-        const int b = tid >> 5;
-        if (Q81) { s_xd[b] = d; s_xs[b] = __float_as_uint(__fmul_rn((float)isum, d)); }
-        else { s_xd[b] = h2f(f2h(d)); s_xs[b] = (uint32_t)isum; }
+#ifdef BIOGPT_HIP_PROFILE_HOOKS
+    asm volatile("" :: "v"(v.x));     // the column has arrived
+#endif
+    LN_STAMP(8);
+    if (worker) {
+        const double s1 = wave_sum_f64(((double)v.x + (double)v.y) + ((double)v.z + (double)v.w));
+        if (lane == 0) s_red[wave] = s1;
     }
+    LN_STAMP(9);
+    __syncthreads();
+    LN_STAMP(10);
+    float mean = 0.0f;
+    float a = 0.0f, b = 0.0f, c = 0.0f, d4 = 0.0f;
+    if (worker) {
+        mean = (float)(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_k);
+        a = __fsub_rn(v.x, mean); b = __fsub_rn(v.y, mean); c = __fsub_rn(v.z, mean); d4 = __fsub_rn(v.w, mean);
+        const double s2 = wave_sum_f64(((double)__fmul_rn(a, a) + (double)__fmul_rn(b, b)) + ((double)__fmul_rn(c, c) + (double)__fmul_rn(d4, d4)));
+        if (lane == 0) s_red[4 + wave] = s2;
+    }
+    LN_STAMP(11);
+    __syncthreads();
+    LN_STAMP(12);
+    if (worker) {
+        const float var = (float)(((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) * inv_k);
+        const float scale = 1.0f / sqrtf(__fadd_rn(var, eps));
+        a = __fadd_rn(__fmul_rn(lw.x, __fmul_rn(a, scale)), lb.x);
+        b = __fadd_rn(__fmul_rn(lw.y, __fmul_rn(b, scale)), lb.y);
+        c = __fadd_rn(__fmul_rn(lw.z, __fmul_rn(c, scale)), lb.z);
+        d4 = __fadd_rn(__fmul_rn(lw.w, __fmul_rn(d4, scale)), lb.w);
+        LN_STAMP(13);
+        // quantize_row_q8_0 / q8_1: one block = 8 consecutive lanes x 4 values
+        const float amax = group8_max(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d4))));
+        const float d = amax / 127.0f;
+        const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+        const int q0 = (int)roundf(__fmul_rn(a, id)), q1 = (int)roundf(__fmul_rn(b, id));
+        const int q2 = (int)roundf(__fmul_rn(c, id)), q3 = (int)roundf(__fmul_rn(d4, id));
+        const int isum = group8_sum(q0 + q1 + q2 + q3);
+        s_xq[tid] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        if ((lane & 7) == 0) {
+            const int blk = tid >> 3;
+            if (Q81) { s_xd[blk] = d; s_xs[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
+            else { s_xd[blk] = h2f(f2h(d)); s_xs[blk] = (uint32_t)isum; }
+        }
+    }
+    LN_STAMP(14);
     __syncthreads();
 }
 
@@ -131,7 +166,8 @@ __device__ __forceinline__ void q8_block32(float v, bool q81, int8_t &q_out, flo
     else { d_out = h2f(f2h(d)); s_out = (uint32_t)isum; }
 }
 
-struct DecAttnParams {
+// ---- A: [embedding (+ sampler of the previous token)] -> LayerNorm -> Q8 -> q/k/v rows -> KV append ---------------
+struct DecQkvParams {
     // layer input: tok_src 0 = x[1024] from memory; 1 = embedding of the state's token; 2 = arg-max of the lm_head
     // partials of the previous token (recorded in the state), then its embedding.  tok_src != 0: workgroup 0 writes x_out.
     const float *x;
@@ -147,95 +183,51 @@ struct DecAttnParams {
     DevMatrix Wqkv;            // [3*1024][1024] row-stacked q, k, v
     const float *bqkv;
     float q_scale;
+    float *q_out;              // [1024] scaled queries
     float *kcache, *vcache;    // layer slice, head-major [H][P][64]
-    int32_t P, t_cap;          // t_cap: launch-time bound of the context (multiple of 64, <= 256) for the cache loads
-    const uint16_t *exp_tab;
-    DevMatrix Wo;              // [1024][1024]
-    float *terms;              // out: out_proj block terms, block-major [32][1024]
-    float *att_out;            // optional: F32 attention output [1024] (null: off)
-    int32_t q81;
+    int32_t P;
     unsigned long long *tstamp;
     unsigned long long *wall;
     int32_t wall_slot;
 };
 
 constexpr int DEC_PS = 36;     // floats between two rows of block terms in LDS (32 + 4: float4 aligned, skewed)
-__host__ __device__ inline size_t dec_attn_smem_bytes() { return 3728 + (size_t)16 * 12 * DEC_PS * 4; }
+__host__ __device__ inline size_t dec_qkv_smem_bytes() { return 1536 + 128 + 128 + (size_t)16 * 2 * DEC_PS * 4; }
 
+// grid = 3072 / 32 = 96 workgroups of 1024 threads: wave w owns rows 32*b + 2*w, +1 (lane = block of the row)
 template <int WT>
-__global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
+__global__ __launch_bounds__(1024) void dec_qkv_kernel(const DecQkvParams p) {
     using TI = TypeInfo<WT>;
-    constexpr int D = 1024, DK = 64, NST = 6, RPWV = 12;   // 192 rows / 16 waves, 2 rows per wave step
+    constexpr int D = 1024, DK = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem);
     float *const s_xd = reinterpret_cast<float *>(smem + 1024);
     uint32_t *const s_xs = reinterpret_cast<uint32_t *>(smem + 1152);
     double *const s_red = reinterpret_cast<double *>(smem + 1280);
-    float *const s_q = reinterpret_cast<float *>(smem + 1536);
-    float *const s_k = s_q + 64, *const s_v = s_q + 128;
-    float *const s_S = reinterpret_cast<float *>(smem + 2304);
-    float *const s_redf = reinterpret_cast<float *>(smem + 3328);
-    double *const s_redd = reinterpret_cast<double *>(smem + 3392);
-    uint32_t *const s_aq = reinterpret_cast<uint32_t *>(smem + 3520);
-    float *const s_ad = reinterpret_cast<float *>(smem + 3584);
-    uint32_t *const s_as = reinterpret_cast<uint32_t *>(smem + 3592);
-    float *const s_amv = reinterpret_cast<float *>(smem + 3600);
-    int *const s_ami = reinterpret_cast<int *>(smem + 3664);
-    float *const s_part = reinterpret_cast<float *>(smem + 3728);
-    double *const s_pv = reinterpret_cast<double *>(smem + 3728);   // reuses the block-term strips after the q/k/v finish
-
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *const s_amv = reinterpret_cast<float *>(smem + 1536);
+    int *const s_ami = reinterpret_cast<int *>(smem + 1536 + 128);
+    float *const s_part = reinterpret_cast<float *>(smem + 1536 + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 31, rsub = lane >> 5;
     DEC_STAMP(0);
     DEC_WALL(0);
 
-    // ---- t = 0: every load that does not depend on the token -------------------------------------------------
-    Unit<WT> wq[NST];
-#pragma unroll
-    for (int s = 0; s < NST; s++) {
-        const int R = wave * RPWV + s * 2 + rsub;                        // row of the head's [q; k; v] stack
-        const int grow = (R >> 6) * D + h * DK + (R & 63);
-        load_unit<WT>(wq[s], p.Wqkv, (int64_t)grow * 32 + sub);
-    }
-    float e_bias = 0.0f;
-    if (lane < RPWV) {
-        const int R = wave * RPWV + lane;
-        e_bias = p.bqkv[(R >> 6) * D + h * DK + (R & 63)];
-    }
-    // this thread's two out_proj units (row tid, blocks 2h / 2h+1); Q8_0 units are twice as large and are fetched once
-    // the q/k/v units have been consumed (register budget of a 1024-thread workgroup: 128)
-    constexpr bool WO_EARLY = (WT != W_Q8_0);
-    Unit<WT> wo[2];
-    if (WO_EARLY) {
-#pragma unroll
-        for (int b = 0; b < 2; b++) load_unit<WT>(wo[b], p.Wo, (int64_t)tid * 32 + 2 * h + b);
-    }
-    const int t_cap = p.t_cap;
-    const int ksub = tid & 3, kidx = tid >> 2;
-    const int dd = tid & (DK - 1), sl = tid >> 6;
-    float4 kr[4];
-    {
-        const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + ksub;
-        if (kidx < t_cap) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) kr[m] = kbase[(size_t)kidx * (DK / 4) + 4 * m];
-        }
-    }
-    float vr[16];
-    {
-        const float *vbase = p.vcache + (size_t)h * p.P * DK + dd;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int j = sl + 16 * k;
-            if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
-        }
-    }
-    const float lnw = p.ln_w[tid], lnb = p.ln_b[tid];
+    // ---- t = 0: the column first (the LayerNorm chain starts from it), then this lane's weight unit ----
     const int n_past = p.st->n_past;
-    float xv;
-    if (p.tok_src == 0) {
-        xv = p.x[tid];
-    } else {
+    const bool worker = tid < 256;                                        // waves 0-3 hold the column, 4 elements per thread
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
+    if (worker) {
+        if (p.tok_src == 0) xv = reinterpret_cast<const float4 *>(p.x)[tid];
+        lnw = reinterpret_cast<const float4 *>(p.ln_w)[tid];
+        lnb = reinterpret_cast<const float4 *>(p.ln_b)[tid];
+    }
+    const int row = blockIdx.x * 32 + wave * 2 + rsub;                    // row of the stacked [q; k; v] matrix
+    Unit<WT> wq;
+    load_unit<WT>(wq, p.Wqkv, (int64_t)row * 32 + sub);
+    const int frow = blockIdx.x * 32 + wave * 2 + (lane & 1);             // finisher lanes 0, 1
+    float e_bias = 0.0f;
+    if (lane < 2) e_bias = p.bqkv[frow];
+    if (p.tok_src != 0) {
         int tok;
         if (p.tok_src == 2) {
             // greedy sampler of the PREVIOUS token (main.cpp:109-128, top_k = 1): finish the arg-max over the lm_head
@@ -261,7 +253,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
                 if (s_amv[w] > bv || (s_amv[w] == bv && s_ami[w] < bi)) { bv = s_amv[w]; bi = s_ami[w]; }
             tok = bi;
             if (tok < 0 || tok >= p.n_vocab) tok = 0;      // partials never written (first replay of a fresh context)
-            if (h == 0 && tid == 0) {
+            if (blockIdx.x == 0 && tid == 0) {
                 int32_t *tokens = state_tokens(p.st);
                 const int g = p.st->n_gen;
                 if (g < p.n_positions) tokens[p.n_positions + g] = tok;
@@ -271,69 +263,116 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
             tok = state_tokens(p.st)[0];
         }
         // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
-        const float te = __fmul_rn(dequant_elem(p.tok_emb, tok, tid), p.embed_scale);
-        const float pe = dequant_elem(p.pos_emb, n_past + 2, tid);
-        xv = __fadd_rn(te, pe);
-        if (h == 0) p.x_out[tid] = xv;
+        if (worker) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+            xv = make_float4(e[0], e[1], e[2], e[3]);
+            if (blockIdx.x == 0) reinterpret_cast<float4 *>(p.x_out)[tid] = xv;
+        }
     }
     DEC_STAMP(1);
-
-    // ---- LayerNorm + Q8 of the column, shared by the 16 waves ---------------------------------------------------
-    if (TI::q81) coop_ln_q8_1024<true>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
-    else coop_ln_q8_1024<false>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+    if (TI::q81) ln4_q8_1024<true>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs, p.tstamp);
+    else ln4_q8_1024<false>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs, p.tstamp);
     DEC_STAMP(2);
-
-    // ---- the head's 192 q/k/v rows: lane = block, 2 rows per wave step ----------------------------------------
     {
         uint32_t ax[8];
         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
         ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
-        const float axd = s_xd[sub];
         const uint32_t axs = s_xs[sub];
-        float *const part = s_part + wave * RPWV * DEC_PS;
-#pragma unroll
-        for (int s = 0; s < NST; s++)
-            part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wq[s], ax, axd, __uint_as_float(axs), (int)axs);
-        if (!WO_EARLY) {
-#pragma unroll
-            for (int b = 0; b < 2; b++) load_unit<WT>(wo[b], p.Wo, (int64_t)tid * 32 + 2 * h + b);
-        }
+        float *const part = s_part + wave * 2 * DEC_PS;
+        part[rsub * DEC_PS + sub] = unit_dot_quant<WT>(wq, ax, s_xd[sub], __uint_as_float(axs), (int)axs);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < RPWV) {
+        if (lane < 2) {
             const float v = __fadd_rn(e_bias, sum32_in_order(part + lane * DEC_PS));
-            const int R = wave * RPWV + lane, which = R >> 6, rr = R & 63;
+            const int which = frow >> 10, rr = frow & (D - 1);
             if (which == 0) {
-                s_q[rr] = __fmul_rn(v, p.q_scale);                     // Q scaled AFTER the bias (biogpt.cpp:708-710)
-            } else {
-                (which == 1 ? s_k : s_v)[rr] = v;
-                (which == 1 ? p.kcache : p.vcache)[((size_t)h * p.P + n_past) * DK + rr] = v;   // KV append (biogpt.cpp:721-727)
+                DEC_STORE_F32(p.q_out + rr, __fmul_rn(v, p.q_scale));   // Q scaled AFTER the bias (biogpt.cpp:708-710)
+            } else {                                                      // KV append (biogpt.cpp:721-727), head-major cache
+                float *cache = (which == 1) ? p.kcache : p.vcache;
+                DEC_STORE_F32(cache + ((size_t)(rr >> 6) * p.P + n_past) * DK + (rr & 63), v);
             }
         }
     }
-    __syncthreads();
     DEC_STAMP(3);
+    DEC_WALL(1);
+}
 
-    // ---- attention of this head over T = n_past + 1 keys (attn_fast_kernel<1, true> at 1024 threads) ----------
-    const int T = n_past + 1;
-    float sc;
-    {
-        if (kidx == n_past) {                                           // this token's key row is still only in LDS
+// ---- B: attention of one head over T = n_past + 1 keys (biogpt.cpp:729-764, no mask needed for one query) --------
+struct DecAttnParams {
+    const float *q;            // [1024] scaled queries
+    const float *kcache, *vcache;
+    const DevState *st;
+    int32_t P, t_cap;          // t_cap: launch-time bound of the context (<= 256) for the cache loads
+    const uint16_t *exp_tab;
+    int8_t *oq_q; float *oq_d; uint32_t *oq_s;   // attention output as 32 Q8 blocks (out_proj's activation row)
+    float *att_out;            // optional F32 copy [1024] (null: off)
+    int32_t q81;
+    unsigned long long *tstamp;
+    unsigned long long *wall;
+    int32_t wall_slot;
+};
+
+// grid = 16 heads, 1024 threads.  Scores: LPK lanes per key (16 / 8 / 4 for contexts up to 64 / 128 / 256 keys), every
+// lane 64 / LPK dims, double partial sums reduced with DPP inside the key's lane group -- all 1024 threads work whatever
+// the context.  PV: 16 key slices x 64 dims.  The query row goes through LDS once (16 lanes load it) instead of being
+// fetched by every quad (1024 x 64 B through one texture addresser).
+template <int LPK>
+__global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
+    constexpr int DK = 64, NF4 = 16 / LPK;          // float4 per lane of a key row
+    static_assert(LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
+    __shared__ __attribute__((aligned(16))) float s_q[DK];
+    __shared__ float s_S[1024 / LPK];
+    __shared__ float s_redf[16];
+    __shared__ double s_redd[16];
+    __shared__ double s_pv[1024];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ksub = tid & (LPK - 1), kidx = tid / LPK;
+    const int dd = tid & (DK - 1), sl = tid >> 6;
+    const int t_cap = p.t_cap;
+    DEC_STAMP(0);
+    DEC_WALL(0);
+    const int n_past = p.st->n_past;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16) q4 = reinterpret_cast<const float4 *>(p.q + h * DK)[tid];
+    float4 kr[NF4];
+    if (kidx < t_cap) {
+        const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK) + (size_t)kidx * (DK / 4) + ksub;
 #pragma unroll
-            for (int m = 0; m < 4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_k + 16 * m + 4 * ksub);
+        for (int m = 0; m < NF4; m++) kr[m] = kbase[LPK * m];       // float4 #(LPK*m + ksub): one load of a lane group covers 16*LPK contiguous bytes
+    }
+    constexpr int NV = 64 / LPK;                     // keys per slice: t_cap <= 16 * NV
+    float vr[NV];
+    {
+        const float *vbase = p.vcache + (size_t)h * p.P * DK + dd;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int j = sl + 16 * k;
+            if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
         }
+    }
+    if (tid < 16) reinterpret_cast<float4 *>(s_q)[tid] = q4;
+    const int T = n_past + 1;
+    __syncthreads();
+    DEC_STAMP(1);
+    float sc = -INFINITY;
+    if ((tid & ~63) < LPK * T) {        // whole waves past the context skip the double-precision work
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const float4 qm = *reinterpret_cast<const float4 *>(s_q + 16 * m + 4 * ksub);
+        for (int m = 0; m < NF4; m++) {
+            const float4 qm = *reinterpret_cast<const float4 *>(s_q + 4 * (LPK * m + ksub));
             a0 += (double)__fmul_rn(kr[m].x, qm.x); a1 += (double)__fmul_rn(kr[m].y, qm.y);
             a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
         }
         double acc = (a0 + a1) + (a2 + a3);
         acc += dpp_d<DPP_QUAD_XOR1>(acc);
         acc += dpp_d<DPP_QUAD_XOR2>(acc);
-        sc = (kidx < T) ? (float)acc : -INFINITY;
+        if (LPK >= 8) acc += dpp_d<DPP_ROW_HALF_MIRROR>(acc);
+        if (LPK >= 16) acc += dpp_d<DPP_ROW_MIRROR>(acc);
+        if (kidx < T) sc = (float)acc;
     }
     float mx = wave_max_f32(sc);
     if (lane == 0) s_redf[wave] = mx;
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
     mx = s_redf[0];
 #pragma unroll
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_redf[w]);
+    DEC_STAMP(2);
     double sum = 0.0;
     if (kidx < T && ksub == 0) {
         const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);
@@ -354,14 +394,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
 #pragma unroll
     for (int w = 0; w < 16; w++) sum += s_redd[w];
     const float inv = inv_sum_f32(sum);
+    DEC_STAMP(3);
     {
         double a0 = 0.0, a1 = 0.0;
-        const float vnew = s_v[dd];
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) {
+        for (int k = 0; k < NV; k += 2) {
             const int j0 = sl + 16 * k, j1 = j0 + 16;
-            if (j0 < T) a0 += (double)__fmul_rn(j0 == n_past ? vnew : vr[k], __fmul_rn(s_S[j0], inv));
-            if (j1 < T) a1 += (double)__fmul_rn(j1 == n_past ? vnew : vr[k + 1], __fmul_rn(s_S[j1], inv));
+            if (j0 < T) a0 += (double)__fmul_rn(vr[k], __fmul_rn(s_S[j0], inv));
+            if (j1 < T) a1 += (double)__fmul_rn(vr[k + 1], __fmul_rn(s_S[j1], inv));
         }
         s_pv[tid] = a0 + a1;
     }
@@ -374,30 +414,65 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
         if (p.att_out) p.att_out[h * DK + tid] = o;
         int8_t q8; float d8; uint32_t s8;
         q8_block32(o, p.q81 != 0, q8, d8, s8);
-        reinterpret_cast<int8_t *>(s_aq)[tid] = q8;
-        if ((tid & 31) == 0) { s_ad[tid >> 5] = d8; s_as[tid >> 5] = s8; }
+        const int blk = h * 2 + (tid >> 5);
+        p.oq_q[blk * 32 + (tid & 31)] = q8;
+        if ((tid & 31) == 0) { p.oq_d[blk] = d8; p.oq_s[blk] = s8; }
     }
-    __syncthreads();
     DEC_STAMP(4);
-
-    // ---- the head's share of out_proj: block terms 2h, 2h+1 of every row (summed in block order by dec_fc1_kernel) ----
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        uint32_t ax[8];
-        const uint4 a = *reinterpret_cast<const uint4 *>(s_aq + b * 8), c = *reinterpret_cast<const uint4 *>(s_aq + b * 8 + 4);
-        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = c.x; ax[5] = c.y; ax[6] = c.z; ax[7] = c.w;
-        const uint32_t xs = s_as[b];
-        p.terms[(size_t)(2 * h + b) * D + tid] = unit_dot_quant<WT>(wo[b], ax, s_ad[b], __uint_as_float(xs), (int)xs);
-    }
-    DEC_STAMP(5);
     DEC_WALL(1);
 }
 
+// ---- C: out_proj + bias + residual (biogpt.cpp:767-772); Q8 activation row from the attention kernel --------------
+struct DecOprojParams {
+    DevMatrix Wo;              // [1024][1024]
+    const int8_t *aq_q; const float *aq_d; const uint32_t *aq_s;   // 32 Q8 blocks
+    const float *bias;
+    const float *resid;        // x
+    float *out;                // x1
+    unsigned long long *tstamp;
+    unsigned long long *wall;
+    int32_t wall_slot;
+};
+__host__ __device__ inline size_t dec_oproj_smem_bytes(int waves) { return (size_t)waves * 2 * DEC_PS * 4; }
+
+// NW waves per workgroup, 2 rows per wave (lane = block): grid = 1024 / (2 * NW)
+template <int WT, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_oproj_kernel(const DecOprojParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *const s_part = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 31, rsub = lane >> 5;
+    const int row = (blockIdx.x * NW + wave) * 2 + rsub;
+    DEC_STAMP(0);
+    DEC_WALL(0);
+    Unit<WT> wq;
+    load_unit<WT>(wq, p.Wo, (int64_t)row * 32 + sub);
+    uint32_t ax[8];
+    {
+        const uint4 *aq = reinterpret_cast<const uint4 *>(p.aq_q) + sub * 2;
+        const uint4 a = aq[0], b = aq[1];
+        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+    }
+    const float axd = p.aq_d[sub];
+    const uint32_t axs = p.aq_s[sub];
+    const int frow = (blockIdx.x * NW + wave) * 2 + (lane & 1);
+    float e_bias = 0.0f, e_res = 0.0f;
+    if (lane < 2) { e_bias = p.bias[frow]; e_res = p.resid[frow]; }
+    DEC_STAMP(1);
+    float *const part = s_part + wave * 2 * DEC_PS;
+    part[rsub * DEC_PS + sub] = unit_dot_quant<WT>(wq, ax, axd, __uint_as_float(axs), (int)axs);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DEC_STAMP(2);
+    if (lane < 2) DEC_STORE_F32(p.out + frow, __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), e_bias), e_res));
+    DEC_STAMP(3);
+    DEC_WALL(1);
+}
+
+// ---- D: LayerNorm -> Q8 -> fc1 rows -> bias -> GELU table -> Q8 block(s) for fc2 (biogpt.cpp:777-787) -------------
 struct DecFc1Params {
-    const float *terms;        // [32][1024] out_proj block terms of this layer (dec_attn_kernel)
-    const float *x;            // [1024] the layer's input (residual of out_proj)
-    const float *bo;           // out_proj bias
-    float *x1_out;             // [1024] x1 = x + out_proj(...) + b_o, written by workgroup 0 (fc2's residual)
+    const float *x1;           // [1024] x + out_proj(...) + b_o
     const float *ln_w, *ln_b;
     float eps;
     DevMatrix W1;              // [4096][1024]
@@ -417,7 +492,6 @@ template <int WT, int NB>
 __global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
     using TI = TypeInfo<WT>;
     static_assert(NB == 1 || NB == 2, "one wave quantizes the workgroup's output blocks");
-    constexpr int D = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem);
     float *const s_xd = reinterpret_cast<float *>(smem + 1024);
@@ -431,26 +505,21 @@ __global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
     DEC_STAMP(0);
     DEC_WALL(0);
 
+    float4 x1 = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1, lnb = x1;      // the column first: the LayerNorm chain starts from it
+    if (tid < 256) {
+        x1 = reinterpret_cast<const float4 *>(p.x1)[tid];
+        lnw = reinterpret_cast<const float4 *>(p.ln_w)[tid];
+        lnb = reinterpret_cast<const float4 *>(p.ln_b)[tid];
+    }
     Unit<WT> wq[NB];
 #pragma unroll
     for (int s = 0; s < NB; s++) load_unit<WT>(wq[s], p.W1, (int64_t)(row0 + s * 32 + wave * 2 + rsub) * 32 + sub);
     float e_bias = 0.0f;
     if (lane < 2 * NB) e_bias = p.b1[row0 + (lane >> 1) * 32 + wave * 2 + (lane & 1)];
-    float t[32];
-#pragma unroll
-    for (int b = 0; b < 32; b++) t[b] = p.terms[(size_t)b * D + tid];
-    const float xres = p.x[tid], bo = p.bo[tid];
-    const float lnw = p.ln_w[tid], lnb = p.ln_b[tid];
-    // out_proj: the row's 32 block terms in block order, then bias, then residual (biogpt.cpp:767-772)
-    float sumf = 0.0f;
-#pragma unroll
-    for (int b = 0; b < 32; b++) sumf = __fadd_rn(sumf, t[b]);
-    const float x1 = __fadd_rn(__fadd_rn(sumf, bo), xres);
-    if (blockIdx.x == 0) p.x1_out[tid] = x1;
     DEC_STAMP(1);
 
-    if (TI::q81) coop_ln_q8_1024<true>(x1, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
-    else coop_ln_q8_1024<false>(x1, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+    if (TI::q81) ln4_q8_1024<true>(x1, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs, p.tstamp);
+    else ln4_q8_1024<false>(x1, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs, p.tstamp);
     DEC_STAMP(2);
 
     {
@@ -485,6 +554,7 @@ __global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
     DEC_WALL(1);
 }
 
+// ---- E: fc2 + bias + residual (biogpt.cpp:790-795) ------------------------------------------------------------------
 struct DecFc2Params {
     DevMatrix W2;              // [1024][4096]
     const int8_t *aq_q; const float *aq_d; const uint32_t *aq_s;   // fc1 output as 128 Q8 blocks
@@ -548,7 +618,7 @@ __global__ __launch_bounds__(NW * 64) void dec_fc2_kernel(const DecFc2Params p) 
                 sumf = __fadd_rn(sumf, t[j].z); sumf = __fadd_rn(sumf, t[j].w);
             }
         }
-        p.out[row] = __fadd_rn(__fadd_rn(sumf, e_bias), e_res);      // biogpt.cpp:790-795
+        DEC_STORE_F32(p.out + row, __fadd_rn(__fadd_rn(sumf, e_bias), e_res));      // biogpt.cpp:790-795
     }
     DEC_STAMP(3);
     DEC_WALL(1);

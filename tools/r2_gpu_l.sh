@@ -1,0 +1,6 @@
+mkdir -p gpurun_out/r2l
+timeout 900 python -m pytest tests/test_gpu_decode_fused.py -x -q > gpurun_out/r2l/pytest_fused.txt 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r2l/pytest_fused.txt
+M=/tmp/biogpt_amd_bench/synthetic-L24-q4_0.bin
+[ -f $M ] || python bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+BIOGPT_HIP_DBG=96 BIOGPT_HIP_LIB=$PWD/biogpt.cpp_amd/libbiogpt_hip_prof.so python tools/decode_timeline.py $M 103 2>&1 | grep -v "loading model" | head -30
+for i in 1 2; do python tools/decode_timeline.py $M 40 103 180 255 2>&1 | grep -v "loading model"; done
