@@ -68,6 +68,13 @@ SYMBOLS = [
     ("biogpt_hip_arena_bytes", C.c_size_t, [_P]),
     ("biogpt_hip_free", None, [_P]),
     ("biogpt_hip_refresh_options", C.c_int, [_P]),
+    ("biogpt_hip_share_vocab", C.c_int, [_P, _P]),
+    ("biogpt_hip_replicas_load", _P, [C.c_char_p, _P, C.c_int, C.c_int]),
+    ("biogpt_hip_replicas_count", C.c_int, [_P]),
+    ("biogpt_hip_replicas_ctx", _P, [_P, C.c_int]),
+    ("biogpt_hip_replicas_broadcast_seconds", C.c_double, [_P]),
+    ("biogpt_hip_replicas_generate_greedy", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_double)]),
+    ("biogpt_hip_replicas_free", None, [_P]),
     ("biogpt_hip_get_hparams", C.c_int, [_P, C.POINTER(HParams)]),
     ("biogpt_hip_n_tensors", C.c_int, [_P]),
     ("biogpt_hip_vocab_token", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
@@ -383,6 +390,53 @@ class BiogptModel:
     def close(self):
         if self._h:
             lib().biogpt_hip_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Replicas:
+    """biogpt_hip_replicas_*: one process, one context per device, weights loaded once and RCCL-broadcast."""
+
+    def __init__(self, fname, devices, verbosity=0):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self._h = lib().biogpt_hip_replicas_load(_bytes(fname), devs.ctypes.data, int(devs.size), int(verbosity))
+        if not self._h:
+            raise BiogptError(_err())
+
+    @property
+    def count(self):
+        return lib().biogpt_hip_replicas_count(self._h)
+
+    @property
+    def broadcast_seconds(self):
+        return lib().biogpt_hip_replicas_broadcast_seconds(self._h)
+
+    def vocab_of(self, i):
+        """The tokenizer handle of replica i (attached replicas share the root's tables)."""
+        ctx = lib().biogpt_hip_replicas_ctx(self._h, int(i))
+        h = lib().biogpt_hip_ctx_vocab(ctx)
+        return Vocab(h, False) if h else None
+
+    def generate_greedy(self, prompts, n_predict, n_batch=8):
+        flat = np.ascontiguousarray([t for p in prompts for t in p], dtype=np.int32)
+        lens = np.ascontiguousarray([len(p) for p in prompts], dtype=np.int32)
+        out = np.zeros((len(prompts), int(n_predict)), dtype=np.int32)
+        counts = np.zeros(len(prompts), dtype=np.int32)
+        secs = C.c_double(0.0)
+        rc = lib().biogpt_hip_replicas_generate_greedy(self._h, flat.ctypes.data, lens.ctypes.data, len(prompts), int(n_batch), int(n_predict),
+                                                       out.ctypes.data, counts.ctypes.data, C.byref(secs))
+        if rc < 0:
+            raise BiogptError(_err())
+        return [out[g, :counts[g]].copy() for g in range(len(prompts))], secs.value
+
+    def close(self):
+        if self._h:
+            lib().biogpt_hip_replicas_free(self._h)
             self._h = None
 
     def __del__(self):

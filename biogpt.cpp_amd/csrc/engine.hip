@@ -536,22 +536,31 @@ bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max) {
            hp.n_positions >= 64 && !c->opt.no_fast && !c->opt.no_chain && !c->opt.no_fused_decode;
 }
 
+// only: -1 = the five kernels of the layer in order; 0..4 = just that kernel (biogpt_hip_bench_matvec)
 template <int WT>
 hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, const bgk::DecAttnParams &at, const bgk::DecOprojParams &op,
-                               const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2) {
+                               const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2, int only = -1) {
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
-    if (at.t_cap <= 64) hipLaunchKernelGGL(bgk::dec_attn_kernel<16>, dim3(16), dim3(1024), 0, st, at);
-    else if (at.t_cap <= 128) hipLaunchKernelGGL(bgk::dec_attn_kernel<8>, dim3(16), dim3(1024), 0, st, at);
-    else hipLaunchKernelGGL(bgk::dec_attn_kernel<4>, dim3(16), dim3(1024), 0, st, at);
-    if (c->opt.oproj_waves == 4) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 4>), dim3(128), dim3(256), bgk::dec_oproj_smem_bytes(4), st, op);
-    else if (c->opt.oproj_waves == 8) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 8>), dim3(64), dim3(512), bgk::dec_oproj_smem_bytes(8), st, op);
-    else hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 16>), dim3(32), dim3(1024), bgk::dec_oproj_smem_bytes(16), st, op);
-    if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
-    else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
-    if (c->opt.fc2_waves == 4) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 4>), dim3(256), dim3(256), bgk::dec_fc2_smem_bytes(4), st, f2);
-    else if (c->opt.fc2_waves == 8) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 8>), dim3(128), dim3(512), bgk::dec_fc2_smem_bytes(8), st, f2);
-    else hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 16>), dim3(64), dim3(1024), bgk::dec_fc2_smem_bytes(16), st, f2);
+    if (only < 0 || only == 0) hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
+    if (only < 0 || only == 1) {
+        if (at.t_cap <= 64) hipLaunchKernelGGL(bgk::dec_attn_kernel<16>, dim3(16), dim3(1024), 0, st, at);
+        else if (at.t_cap <= 128) hipLaunchKernelGGL(bgk::dec_attn_kernel<8>, dim3(16), dim3(1024), 0, st, at);
+        else hipLaunchKernelGGL(bgk::dec_attn_kernel<4>, dim3(16), dim3(1024), 0, st, at);
+    }
+    if (only < 0 || only == 2) {
+        if (c->opt.oproj_waves == 4) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 4>), dim3(128), dim3(256), bgk::dec_oproj_smem_bytes(4), st, op);
+        else if (c->opt.oproj_waves == 8) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 8>), dim3(64), dim3(512), bgk::dec_oproj_smem_bytes(8), st, op);
+        else hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 16>), dim3(32), dim3(1024), bgk::dec_oproj_smem_bytes(16), st, op);
+    }
+    if (only < 0 || only == 3) {
+        if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
+        else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
+    }
+    if (only < 0 || only == 4) {
+        if (c->opt.fc2_waves == 4) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 4>), dim3(256), dim3(256), bgk::dec_fc2_smem_bytes(4), st, f2);
+        else if (c->opt.fc2_waves == 8) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 8>), dim3(128), dim3(512), bgk::dec_fc2_smem_bytes(8), st, f2);
+        else hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 16>), dim3(64), dim3(1024), bgk::dec_fc2_smem_bytes(16), st, f2);
+    }
     return hipGetLastError();
 }
 
@@ -563,7 +572,8 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
     return (M + 8 * steps - 1) / (8 * steps);
 }
 
-bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance) {
+// l0 / l1 / only: biogpt_hip_bench_matvec launches one kernel of one layer; the decode step is all layers + lm_head
+bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1) {
     t_ctx = c;
     const auto &hp = c->hp;
     const int D = hp.d_model, V = hp.n_vocab, P = hp.n_positions;
@@ -573,7 +583,8 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
     unsigned long long *const ts = (c->opt.dbg & 96) ? c->tstamp : nullptr;
     unsigned long long *const wall = (c->opt.dbg & 64) ? c->tstamp + 128 : nullptr;
-    for (int l = 0; l < hp.n_layer; l++) {
+    if (l1 < 0) l1 = hp.n_layer;
+    for (int l = l0; l < l1; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         bgk::DecQkvParams a{};
         a.x = c->x; a.x_out = c->x;
@@ -610,15 +621,16 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         f2.tstamp = ts ? ts + 64 : nullptr; f2.wall = wall; f2.wall_slot = 5 * l + 4;
         hipError_t e = hipErrorInvalidValue;
         switch (wt) {
-            case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, at, op, f1, f2); break;
-            case T_Q4_1: e = launch_decode_layer<bgk::W_Q4_1>(c, a, at, op, f1, f2); break;
-            case T_Q5_0: e = launch_decode_layer<bgk::W_Q5_0>(c, a, at, op, f1, f2); break;
-            case T_Q5_1: e = launch_decode_layer<bgk::W_Q5_1>(c, a, at, op, f1, f2); break;
-            case T_Q8_0: e = launch_decode_layer<bgk::W_Q8_0>(c, a, at, op, f1, f2); break;
+            case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, at, op, f1, f2, only); break;
+            case T_Q4_1: e = launch_decode_layer<bgk::W_Q4_1>(c, a, at, op, f1, f2, only); break;
+            case T_Q5_0: e = launch_decode_layer<bgk::W_Q5_0>(c, a, at, op, f1, f2, only); break;
+            case T_Q5_1: e = launch_decode_layer<bgk::W_Q5_1>(c, a, at, op, f1, f2, only); break;
+            case T_Q8_0: e = launch_decode_layer<bgk::W_Q8_0>(c, a, at, op, f1, f2, only); break;
             default: break;
         }
         HIP_TRY(false, e);
     }
+    if (only >= 0) return true;
     {  // final LayerNorm + lm_head (last row only, F8) + per-workgroup arg-max partials; block 0 advances the position
         const MatSlot &m = c->plan.lm_head;
         const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
@@ -1072,7 +1084,7 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
 
 // The single-token decode step is captured once per context bucket (the attention workgroup size is a
 // launch parameter, everything else reads n_past / the token from HBM) and replayed per token.
-constexpr int N_BUCKETS = 6;   // 64 / 128 / 192 / 256 / 512 / n_positions keys
+// context buckets of the captured decode graphs: 64 / 128 / 192 / 256 / 512 / n_positions keys
 int graph_bucket(int T) { return T <= 256 ? (T - 1) / 64 : (T <= 512 ? 4 : 5); }
 int bucket_tmax(const biogpt_hip_ctx *c, int b) {
     const int t = b < 4 ? 64 * (b + 1) : (b == 4 ? 512 : c->hp.n_positions);
@@ -1141,6 +1153,16 @@ void *biogpt_hip_arena_ptr(biogpt_hip_ctx *ctx) { return ctx ? ctx->arena : null
 size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
 
 void biogpt_hip_free(biogpt_hip_ctx *ctx) { destroy(ctx); }
+
+int biogpt_hip_share_vocab(biogpt_hip_ctx *dst, const biogpt_hip_ctx *src) {
+    if (!dst || !src) BG_FAIL(-1, "null context");
+    if (dst == src) return 0;
+    if (dst->tok_vocab) { bg::drop_vocab(dst->tok_vocab); dst->tok_vocab = nullptr; }
+    dst->vocab = src->vocab;
+    dst->merges = src->merges;
+    dst->tok_vocab = bg::make_vocab(dst->vocab, dst->merges);
+    return 0;
+}
 
 int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
@@ -1473,7 +1495,8 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer))) BG_FAIL(-1, "bad argument");
+    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 10) BG_FAIL(-1, "bad argument");
+    if (which >= 6 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     t_ctx = ctx;
     const auto &hp = ctx->hp;
@@ -1486,6 +1509,10 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
                        !opt().no_fast && !opt().no_chain;
     auto launch = [&](int l) -> bool {
         ctx->launch_parity ^= 1;
+        if (which >= 6 && which <= 10) {   // one kernel of the five-launch decode layer (kernels_decode.hip.h), layer l mod L, `layer` = n_past for attention
+            const int ll = l % hp.n_layer;
+            return enqueue_decode_fused(ctx, 104, 0, 0, ll, ll + 1, which - 6);
+        }
         if (which == 5) {  // attention of layer (l mod L) with `layer` keys in the cache
             bgk::AttnParams a{};
             const int ll = l % hp.n_layer, dk = D / hp.n_head;
@@ -1543,19 +1570,43 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
         return true;
     };
     const int32_t tok0 = 0;
-    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : 0)) return -2;
+    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : (which >= 6 ? 103 : 0))) return -2;
     const bool stamps = (ctx->opt.dbg & 32) != 0 && which < 5;
     if (stamps) {
         if (!ctx->tstamp) HIP_TRY(-2, hipMalloc(&ctx->tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
         HIP_TRY(-2, hipMemset(ctx->tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
     }
-    for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
-    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; i++) if (!launch(layer + i)) return -2;
-    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
-    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (which >= 6) {
+        // the decode-layer kernels finish faster than the host can launch them one by one (~3.3 us per eager launch):
+        // capture one sweep over the layers and time graph replays, as the decode step itself is replayed
+        const int per = std::max(1, hp.n_layer);
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        bool ok = true;
+        for (int i = 0; i < per && ok; i++) ok = launch(layer + i);
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+        if (!ok || ce != hipSuccess) { if (g) (void)hipGraphDestroy(g); BG_FAIL(-2, "graph capture of the decode kernel failed"); }
+        HIP_TRY(-2, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        const int sweeps = std::max(1, reps / per);
+        for (int i = 0; i < 2; i++) HIP_TRY(-2, hipGraphLaunch(ge, ctx->stream));
+        HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int i = 0; i < sweeps; i++) HIP_TRY(-2, hipGraphLaunch(ge, ctx->stream));
+        HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
+        HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        (void)hipGraphExecDestroy(ge);
+        reps = sweeps * per;
+    } else {
+        for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
+        HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int i = 0; i < reps; i++) if (!launch(layer + i)) return -2;
+        HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
+        HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    }
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
     if (stamps) {  // timeline of the last two launches (A then B), shader-clock cycles
         const MatSlot *mm = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
@@ -1582,6 +1633,12 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     }
     if (bytes_out) {
         if (which == 5) { *bytes_out = 2.0 * (layer + 1) * D * 4; return 0; }  // K and V rows of one layer
+        if (which == 7) { *bytes_out = 2.0 * 104 * D * 4 + 4.0 * D + 1.0 * D + 8.0 * (D / 32); return 0; }   // K, V rows at 104 keys + q + Q8 output
+        if (which >= 6) {   // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
+            const MatSlot *m6 = which == 6 ? &ctx->plan.layers[0].qkv : which == 8 ? &ctx->plan.layers[0].o : which == 9 ? &ctx->plan.layers[0].fc1 : &ctx->plan.layers[0].fc2;
+            *bytes_out = (double)file_row_bytes(m6->type, m6->K) * (double)m6->M + 4.0 * (double)m6->K + 4.0 * (double)m6->M;
+            return 0;
+        }
         const MatSlot *m = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
                          : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
         // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)

@@ -93,6 +93,26 @@ size_t biogpt_hip_arena_bytes(const biogpt_hip_ctx *ctx);
 
 void biogpt_hip_free(biogpt_hip_ctx *ctx);
 
+/* An attached context (biogpt_hip_attach) has weights but no vocabulary: copy the token / merge tables of a context
+ * that was loaded from the file, so that every replica can tokenize and decode (biogpt.cpp:850-906). */
+int biogpt_hip_share_vocab(biogpt_hip_ctx *dst, const biogpt_hip_ctx *src);
+
+/* ---- single-process multi-GPU replicas (replaces the ONE biogpt_model_load of examples/main/main.cpp:38) ----
+ * The file is read once on devices[0]; the packed weight arena goes to the other devices with ONE RCCL broadcast
+ * (ncclCommInitAll, in-process; librccl.so is resolved at run time); every device gets its own context.  Prompt g is
+ * served by replica g mod n, one host thread per device, no collective on the data path.  NULL + message on failure. */
+typedef struct biogpt_hip_replicas biogpt_hip_replicas;
+biogpt_hip_replicas *biogpt_hip_replicas_load(const char *fname, const int *devices, int n_devices, int verbosity);
+int biogpt_hip_replicas_count(const biogpt_hip_replicas *r);
+biogpt_hip_ctx *biogpt_hip_replicas_ctx(biogpt_hip_replicas *r, int i);   /* borrowed: freed by biogpt_hip_replicas_free */
+double biogpt_hip_replicas_broadcast_seconds(const biogpt_hip_replicas *r);
+/* Greedy continuations (main.cpp:91-151 with --top_k 1) of n_prompts independent prompts (ids concatenated, lengths in
+ * prompt_lens): out_ids[g][n_predict], out_counts[g] = ids produced for prompt g (n_predict clamped like main.cpp:82; may
+ * be NULL); *seconds_out = wall time of the whole call.  Returns n_prompts or < 0. */
+int biogpt_hip_replicas_generate_greedy(biogpt_hip_replicas *r, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_prompts,
+                                        int32_t n_batch, int32_t n_predict, int32_t *out_ids, int32_t *out_counts, double *seconds_out);
+void biogpt_hip_replicas_free(biogpt_hip_replicas *r);
+
 /* The BIOGPT_HIP_* tuning / debugging switches are read from the environment once, when a context is
  * created (no getenv on any launch path).  This re-reads them for an existing context and drops its
  * captured graphs (tests and sweep tools; the reference has no counterpart). */

@@ -169,3 +169,24 @@ def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     rec = json.load(open(dump + ".rank0"))
     ref, _ = oracle.OracleModel(rec["model"], n_threads=16).generate_greedy(rec["prompt"], 40, n_batch=8)
     assert rec["ids"] == [int(v) for v in ref]
+
+
+def test_c_abi_replicas_single_process(pkg, oracle, files):
+    """biogpt_hip_replicas_*: the C++-side multi-GPU entry (single process, ncclCommInitAll, one arena broadcast,
+    one host thread per device).  On this one-GPU box the communicator has one rank -- the RCCL calls, the per-replica
+    contexts, the prompt sharding g mod n and the shared vocabulary all run; ids == oracle for every prompt."""
+    r = pkg.Replicas(files["q4_0"], [0], verbosity=1)
+    assert r.count == 1 and r.broadcast_seconds >= 0.0
+    rng = np.random.default_rng(77)
+    prompts = [[2] + [int(v) for v in rng.integers(4, KW["n_vocab"], int(rng.integers(1, 9)))] for _ in range(3)]
+    ids, secs = r.generate_greedy(prompts, 12, n_batch=8)
+    assert secs > 0 and len(ids) == 3
+    for g, p in enumerate(prompts):
+        ref, _ = oracle.OracleModel(files["q4_0"], n_threads=16).generate_greedy(p, 12, n_batch=8)
+        assert list(ids[g]) == list(ref), g
+    assert r.vocab_of(0) is not None
+    with pytest.raises(pkg.BiogptError):
+        pkg.Replicas(files["q4_0"], [0, 0])           # a device listed twice
+    with pytest.raises(pkg.BiogptError):
+        pkg.Replicas(files["q4_0"], [0, 63])          # no such device
+    r.close()

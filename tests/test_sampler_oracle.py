@@ -48,20 +48,22 @@ def test_host_sampler_equals_restatement_on_random_logits(pkg, oracle_sampler, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["q8_0", "q4_1"])
-def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny_models, tmp_path, name):
-    """The reference's loop with its default sampler settings (top_k 40, top_p 0.9, temp 0.9; main.cpp:109-128) through
-    the compat driver on the GPU, against oracle logits + restated sampler with the same seed."""
+@pytest.mark.parametrize("name,temp,top_p", [("q8_0", 0.9, 0.9), ("q4_1", 6.0, 0.95), ("q5_0", 25.0, 1.0)])
+def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny_models, tmp_path, name, temp, top_p):
+    """The reference's loop (main.cpp:109-128) with top_k 40 through the compat driver on the GPU -- the CLI defaults
+    (top_p 0.9, temp 0.9) and two hot settings that make the tiny model actually spread its samples -- against oracle
+    logits + restated sampler with the same seed."""
     exe = _build_driver(pkg, tmp_path)
     prompt = [2, 17, 45, 300, 9]
-    r = subprocess.run([exe, tiny_models[name], "24", "40"] + [str(t) for t in prompt], capture_output=True, text=True)
+    r = subprocess.run([exe, "--flags", "-m", tiny_models[name], "-n", "24", "--top_k", "40", "--top_p", repr(top_p), "--temp", repr(temp),
+                        "-p", " ".join(str(t) for t in prompt)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = [int(t) for t in r.stdout.split()]
     o = oracle.OracleModel(tiny_models[name], n_threads=2)
     rng = oracle_sampler.Mt19937(7)
     lg = o.eval(prompt, 0)
     n_past, ref = len(prompt), []
-    fp, ft = float(np.float32(0.9)), float(np.float32(0.9))
+    fp, ft = float(np.float32(top_p)), float(np.float32(temp))       # biogpt_params holds floats (biogpt.h:115-116)
     for k in range(24):
         t = oracle_sampler.sample_top_k_top_p(lg, 40, fp, ft, rng)
         ref.append(t)
@@ -69,4 +71,5 @@ def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny
             lg = o.eval([t], n_past)
             n_past += 1
     assert got == ref
-    assert len(set(got)) > 3
+    if temp > 1.0:
+        assert len(set(got)) > 3, got                                # the hot settings do sample
