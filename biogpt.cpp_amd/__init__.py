@@ -81,6 +81,7 @@ SYMBOLS = [
     ("biogpt_hip_merge", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     ("biogpt_hip_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
     ("biogpt_hip_synchronize", C.c_int, [_P]),
     ("biogpt_hip_eval_all", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
@@ -90,6 +91,7 @@ SYMBOLS = [
     ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
     ("biogpt_hip_bench_matvec", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_decode", C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(C.c_double)]),
+    ("biogpt_hip_bench_api_loop", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_stream", C.c_int, [_P, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_quantize_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
     ("biogpt_hip_write_synthetic", C.c_int, [C.c_char_p, C.POINTER(HParams), C.c_uint64]),
@@ -293,6 +295,16 @@ class BiogptModel:
             raise BiogptError(_err())
         return out
 
+    def eval_topk(self, tokens, n_past, k):
+        """biogpt_eval + device-side top-k: (values descending, ids) of the k <= 64 largest logits of the last token."""
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        vals = np.zeros(64, dtype=np.float32)
+        ids = np.zeros(64, dtype=np.int32)
+        got = lib().biogpt_hip_eval_topk(self._h, toks.ctypes.data, toks.size, int(n_past), int(k), vals.ctypes.data, ids.ctypes.data)
+        if got < 0:
+            raise BiogptError(_err())
+        return vals[:got].copy(), ids[:got].copy()
+
     def eval_all(self, tokens, n_past):
         toks = np.ascontiguousarray(tokens, dtype=np.int32)
         out = np.empty((toks.size, self.n_vocab), dtype=np.float32)
@@ -359,6 +371,16 @@ class BiogptModel:
         if lib().biogpt_hip_bench_stream(self._h, int(rows), int(reps), int(steps), C.byref(secs), C.byref(nbytes)) != 0:
             raise BiogptError(_err())
         return secs.value, nbytes.value
+
+    def bench_api_loop(self, prompt, n_predict, mode):
+        """The reference's greedy host loop in C++ on this library (mode 0: full logits row per token, 1: device top-40)."""
+        pr = np.ascontiguousarray(prompt, dtype=np.int32)
+        out = np.zeros(int(n_predict), dtype=np.int32)
+        secs = C.c_double(0.0)
+        got = lib().biogpt_hip_bench_api_loop(self._h, pr.ctypes.data, pr.size, int(n_predict), int(mode), out.ctypes.data, C.byref(secs))
+        if got < 0:
+            raise BiogptError(_err())
+        return out[:got], secs.value
 
     def refresh_options(self):
         """Re-read the BIOGPT_HIP_* switches (they are cached at load time) and drop the captured graphs."""

@@ -210,16 +210,11 @@ bool biogpt_eval(const biogpt_model &model, const token_sequence &embed_inp, std
 
 // temperature -> top-k (partial sort) -> softmax in double -> top-p cut + renormalise -> one draw
 // (biogpt.cpp:908-980).  With top_k == 1 this is arg-max, the draw is still consumed.
-biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
-                                           double temp, std::mt19937 &rng) {
-    const int n = (int)vocab.id_to_token.size();
-    typedef std::pair<double, biogpt_vocab::id> scored;
-    std::vector<scored> cand((size_t)n);
-    const double inv_t = 1.0 / temp;
-    for (int i = 0; i < n; i++) cand[(size_t)i] = scored(logits[i] * inv_t, i);
-    top_k = std::max(1, std::min(top_k, n));
-    std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(), [](const scored &a, const scored &b) { return a.first > b.first; });
-    cand.resize((size_t)top_k);
+namespace {
+typedef std::pair<double, biogpt_vocab::id> scored;
+// everything after the partial sort: cand = the top_k (scaled logit, id) pairs, best first (biogpt.cpp:938-980)
+biogpt_vocab::id sample_from_top(std::vector<scored> &cand, double top_p, std::mt19937 &rng) {
+    int top_k = (int)cand.size();
     double peak = -INFINITY;
     for (const scored &c : cand) peak = std::max(peak, c.first);
     std::vector<double> prob(cand.size());
@@ -237,6 +232,43 @@ biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const floa
     }
     std::discrete_distribution<> pick(prob.begin(), prob.end());
     return cand[(size_t)pick(rng)].second;
+}
+}  // namespace
+
+biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
+                                           double temp, std::mt19937 &rng) {
+    const int n = (int)vocab.id_to_token.size();
+    std::vector<scored> cand((size_t)n);
+    const double inv_t = 1.0 / temp;
+    for (int i = 0; i < n; i++) cand[(size_t)i] = scored(logits[i] * inv_t, i);
+    top_k = std::max(1, std::min(top_k, n));
+    std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(), [](const scored &a, const scored &b) { return a.first > b.first; });
+    cand.resize((size_t)top_k);
+    return sample_from_top(cand, top_p, rng);
+}
+
+// Extension (no reference counterpart): biogpt_eval + biogpt_sample_top_k_top_p in one call, the top-k selection done on
+// the device (biogpt_hip_eval_topk) so that 512 bytes instead of the 170 KB logits row cross PCIe per token.  Same ids
+// as the two reference calls whenever the k-th and (k+1)-th logits differ (ties are "lower id first" here and
+// unspecified in the reference's std::partial_sort).  top_k > 64 falls back to the two-call form.
+biogpt_vocab::id biogpt_eval_sample_top_k_top_p(const biogpt_model &model, const biogpt_vocab &vocab, const token_sequence &embed_inp,
+                                                const int n_past, int top_k, double top_p, double temp, std::mt19937 &rng) {
+    biogpt_hip_ctx *ctx = biogpt_model_hip(model);
+    const int n = (int)vocab.id_to_token.size();
+    top_k = std::max(1, std::min(top_k, n));
+    if (top_k > 64) {
+        std::vector<float> logits;
+        if (!biogpt_eval(model, embed_inp, logits, nullptr, n_past, 1)) throw std::runtime_error(biogpt_hip_last_error());
+        return biogpt_sample_top_k_top_p(vocab, logits.data(), top_k, top_p, temp, rng);
+    }
+    float vals[64];
+    int32_t ids[64];
+    const int got = biogpt_hip_eval_topk(ctx, embed_inp.data(), (int32_t)embed_inp.size(), n_past, top_k, vals, ids);
+    if (got < 0) throw std::runtime_error(biogpt_hip_last_error());
+    std::vector<scored> cand((size_t)got);
+    const double inv_t = 1.0 / temp;
+    for (int i = 0; i < got; i++) cand[(size_t)i] = scored(vals[i] * inv_t, ids[i]);
+    return sample_from_top(cand, top_p, rng);
 }
 
 // ---- CLI flags of the reference's `biogpt` tool (biogpt.cpp:982-1040), table-driven -------------------

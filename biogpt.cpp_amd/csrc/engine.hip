@@ -250,6 +250,11 @@ struct biogpt_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
+    hipGraphExec_t graph_eval[4] = {};     // single-token biogpt_hip_eval*: the five-launch decode step with the token taken from the state
+    uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
+    int32_t *mbox_host = nullptr;          // pinned ring of 64 x {n_past, causal, token}: inputs of the graph-replayed single-token evals
+    uint32_t *mbox_ctr = nullptr;          // device: replays consumed
+    uint32_t mbox_sent = 0, mbox_synced = 0;
     int lm_blocks = 0;
     bool ready = false;  // weights present
 };
@@ -575,6 +580,7 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 // l0 / l1 / only: biogpt_hip_bench_matvec launches one kernel of one layer; the decode step is all layers + lm_head
 bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1) {
     t_ctx = c;
+    (void)hipGetLastError();
     const auto &hp = c->hp;
     const int D = hp.d_model, V = hp.n_vocab, P = hp.n_positions;
     const int lm_parts = fast_lm_grid(c);   // partials the previous step's lm_head left (same launch shape every step)
@@ -651,6 +657,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
 // (column states with seq_id / t_vis), no lm_head -- the caller gets the logits from the following decode step.
 bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false, const bgk::SeqState *cols = nullptr) {
     t_ctx = c;
+    (void)hipGetLastError();   // a failed call of some OTHER context / API leaves its code behind; the checks below are about these launches
     if (N < 1 || N > c->hp.n_positions) BG_FAIL(false, "internal: a pass of %d columns exceeds the %d-column activation scratch", N, c->hp.n_positions);
     if (N == 1 && !batch && !all_rows && fused_decode_ok(c, t_max)) return enqueue_decode_fused(c, t_max, 1, 0);
     const auto &hp = c->hp;
@@ -1006,7 +1013,11 @@ void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &g : c->graph_eval) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
+    if (c->topk_host) (void)hipHostFree(c->topk_host);
+    if (c->mbox_host) (void)hipHostFree(c->mbox_host);
+    if (c->mbox_ctr) (void)hipFree(c->mbox_ctr);
     for (void *p : {(void *)c->bk, (void *)c->bv, (void *)c->seq, (void *)c->seq_gen, (void *)c->cols}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1169,6 +1180,7 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     ctx->opt.load();
     // captured graphs bake launch shapes chosen from the options
     for (auto &row : ctx->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &g : ctx->graph_eval) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     ctx->graph_batch_n = 0;
     return 0;
@@ -1199,9 +1211,111 @@ int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
     clear_error();
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    // one token at a position of the five-launch decode step: replay its captured graph -- its first node pulls the
+    // token and the position from a pinned mailbox slot -- instead of a copy command and 121 launches one by one
+    if (n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, n_past + 1)) {
+        const int b = graph_bucket(n_past + 1);
+        if (!ctx->mbox_host) {
+            HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->mbox_host), 64 * 8 * 4, hipHostMallocDefault));
+            HIP_TRY(-2, hipMalloc(&ctx->mbox_ctr, 16));
+            HIP_TRY(-2, hipMemset(ctx->mbox_ctr, 0, 16));
+        }
+        if (!ctx->graph_eval[b]) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
+            const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0);
+            const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+            if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
+            HIP_TRY(-2, e);
+            HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[b], g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+        if (ctx->mbox_sent - ctx->mbox_synced >= 64) {   // never overwrite a slot a queued replay has not read yet
+            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+            ctx->mbox_synced = ctx->mbox_sent;
+        }
+        int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
+        slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
+        ctx->mbox_sent++;
+        HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[b], ctx->stream));
+        return 0;
+    }
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
     if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
     return 0;
+}
+
+int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int32_t k, float *vals_out, int32_t *ids_out) {
+    if (!vals_out || !ids_out) BG_FAIL(-1, "null output buffer");
+    if (!ctx) BG_FAIL(-1, "null context");
+    if (k < 1 || k > 64) BG_FAIL(-1, "k must be in [1, 64]");
+    k = std::min<int32_t>(k, ctx->hp.n_vocab);
+    const int rc = biogpt_hip_eval_device(ctx, tokens, n, n_past);
+    if (rc) return rc;
+    if (!ctx->topk_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->topk_host), 64 * 8 + 16, hipHostMallocDefault));
+    // the kernel writes its <= 64 pairs straight into pinned host memory: no copy command behind it
+    float *out_val = reinterpret_cast<float *>(ctx->topk_host);
+    int32_t *out_idx = reinterpret_cast<int32_t *>(ctx->topk_host + 64 * 4);
+    hipLaunchKernelGGL(bgk::topk_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->hp.n_vocab, k, ctx->pmax_val, ctx->lm_blocks,
+                       out_val, out_idx, out_idx + 64);
+    HIP_TRY(-2, hipGetLastError());
+    // low-latency wait: poll the stream instead of sleeping on it (the caller is blocked on this token anyway)
+    for (;;) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(-2, q);
+    }
+    ctx->mbox_synced = ctx->mbox_sent;
+    const float *hv = reinterpret_cast<const float *>(ctx->topk_host);
+    const int32_t *hi = reinterpret_cast<const int32_t *>(ctx->topk_host + 64 * 4);
+    if (hi[64] == k) {
+        std::memcpy(vals_out, hv, (size_t)k * 4);
+        std::memcpy(ids_out, hi, (size_t)k * 4);
+        return k;
+    }
+    // degenerate row (thousands of logits tie with the k-th workgroup maximum, or NaNs): the full row and a host partial sort
+    const size_t V = (size_t)ctx->hp.n_vocab;
+    std::vector<float> row(V);
+    HIP_TRY(-2, hipMemcpy(row.data(), ctx->logits, V * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> order(V);
+    for (size_t i = 0; i < V; i++) order[i] = (int32_t)i;
+    std::partial_sort(order.begin(), order.begin() + k, order.end(), [&](int32_t a, int32_t b) { return row[(size_t)a] > row[(size_t)b] || (row[(size_t)a] == row[(size_t)b] && a < b); });
+    for (int i = 0; i < k; i++) { vals_out[i] = row[(size_t)order[(size_t)i]]; ids_out[i] = order[(size_t)i]; }
+    return k;
+}
+
+// The reference's host loop (main.cpp:91-151, greedy) as a C++ caller would run it on this library -- one eval call per
+// token, the sampler on the host -- timed without any scripting-language overhead: mode 0 = biogpt_hip_eval (the whole
+// logits row crosses PCIe, host arg-max), mode 1 = biogpt_hip_eval_topk with k = 40 (the CLI's top_k; 512 bytes cross).
+int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_predict, int32_t mode, int32_t *out_ids,
+                              double *seconds_out) {
+    clear_error();
+    if (!ctx || !prompt || n_prompt < 1 || n_predict < 1 || (mode != 0 && mode != 1)) BG_FAIL(-1, "bad argument");
+    if (!check_eval_args(ctx, prompt, n_prompt, 0)) return -1;
+    n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);
+    const size_t V = (size_t)ctx->hp.n_vocab;
+    std::vector<float> logits(mode == 0 ? V : 64);
+    int32_t ids[64];
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t tok = 0;
+    int n_past = 0;
+    for (int k = 0; k < n_predict; k++) {
+        const int32_t *in = (k == 0) ? prompt : &tok;
+        const int n_in = (k == 0) ? n_prompt : 1;
+        if (mode == 0) {
+            if (biogpt_hip_eval(ctx, in, n_in, n_past, logits.data()) != 0) return -2;
+            tok = (int32_t)(std::max_element(logits.begin(), logits.end()) - logits.begin());
+        } else {
+            if (biogpt_hip_eval_topk(ctx, in, n_in, n_past, 40, logits.data(), ids) < 0) return -2;
+            tok = ids[0];
+        }
+        n_past += n_in;
+        if (out_ids) out_ids[k] = tok;
+    }
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return n_predict;
 }
 
 const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) { return ctx ? ctx->logits : nullptr; }

@@ -624,6 +624,75 @@ __global__ __launch_bounds__(NW * 64) void dec_fc2_kernel(const DecFc2Params p) 
     DEC_WALL(1);
 }
 
+// ---- device-side top-k of the logits row (the sampler needs k <= 64 candidates, not 170 KB over PCIe) ----
+// Exact selection of the k largest logits, best first (equal logits: lower id first), one 1024-thread workgroup:
+//   1. the k-th largest of the lm_head kernel's per-workgroup maxima is a lower bound T0 of the k-th largest logit (k
+//      workgroups each hold a logit >= it), so every member of the top k is >= T0;
+//   2. one sweep over the row collects the logits >= T0 (a few dozen) in LDS;
+//   3. every candidate counts the candidates that beat it: its rank; ranks < k are the answer, already ordered.
+// out_n[0] = k, or -1 if more than TOPK_CAP logits reach T0 (degenerate rows: the caller falls back to the full row).
+// biogpt_sample_top_k_top_p (biogpt.cpp:908-980) only ever looks at these k logits.
+constexpr int TOPK_CAP = 4096;
+__global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, int k, const float *pmax_val, int nparts, float *out_val,
+                                                    int32_t *out_idx, int32_t *out_n) {
+    __shared__ float s_pm[1024];
+    __shared__ float s_cv[TOPK_CAP];
+    __shared__ int s_ci[TOPK_CAP];
+    __shared__ float s_t0;
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_t0 = -INFINITY; s_n = 0; }
+    const int np = min(nparts, 1024);
+    const float mine = (tid < np) ? pmax_val[tid] : -INFINITY;
+    s_pm[tid] = mine;
+    __syncthreads();
+    if (k <= np && tid < np) {                      // rank of this partial maximum among the partials (ties: by index)
+        int beat = 0;
+        for (int j = 0; j < np; j++) {
+            const float o = s_pm[j];
+            beat += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+        }
+        if (beat == k - 1) s_t0 = mine;
+    }
+    __syncthreads();
+    const float t0 = (nparts <= 1024) ? s_t0 : -INFINITY;
+    for (int i = tid; i < V; i += 1024) {
+        const float x = logits[i];
+        if (x >= t0) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < TOPK_CAP) { s_cv[slot] = x; s_ci[slot] = i; }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n > TOPK_CAP || n < k) { if (tid == 0) out_n[0] = -1; return; }   // n < k only if the row holds NaNs
+    for (int c = tid; c < n; c += 1024) {
+        const float x = s_cv[c];
+        const int ix = s_ci[c];
+        int beat = 0;
+        for (int j = 0; j < n; j++) {
+            const float o = s_cv[j];
+            beat += (o > x || (o == x && s_ci[j] < ix)) ? 1 : 0;
+        }
+        if (beat < k) { out_val[beat] = x; out_idx[beat] = ix; }
+    }
+    if (tid == 0) out_n[0] = k;
+}
+
+// Single-token evals through the C API: the host drops {n_past, causal, token} into a ring of pinned slots and replays the
+// captured step; this first node of the graph pulls the next slot into the device state (one PCIe read instead of a copy
+// command + its blit kernel in front of every token).  ctr counts the replays; the host mirrors it.
+__global__ void fetch_state_kernel(const int32_t *mbox, uint32_t *ctr, DevState *st) {
+    const uint32_t n = *ctr;
+    const int32_t *slot = mbox + (size_t)(n & 63u) * 8;
+    st->n_past = slot[0];
+    st->n_gen = 0;
+    st->causal = slot[1];
+    st->chunk = 0;
+    state_tokens(st)[0] = slot[2];
+    *ctr = n + 1u;
+}
+
 // the device-side position moves on without a sampler launch: after a prompt pass, before the first fused step
 __global__ void advance_state_kernel(DevState *st, int n_eval) { st->n_past = st->n_past + n_eval; }
 

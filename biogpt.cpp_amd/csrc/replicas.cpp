@@ -89,6 +89,10 @@ biogpt_hip_replicas *biogpt_hip_replicas_load(const char *fname, const int *devi
     for (int i = 0; i < n_devices; i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) BG_FAIL(nullptr, "device %d listed twice", devices[i]);
+    int n_found = 0;
+    if (hipGetDeviceCount(&n_found) != hipSuccess || n_found <= 0) { (void)hipGetLastError(); BG_FAIL(nullptr, "no HIP device available: this engine has no CPU fallback"); }
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= n_found) BG_FAIL(nullptr, "HIP device %d out of range (found %d)", devices[i], n_found);
     std::unique_ptr<biogpt_hip_replicas, void (*)(biogpt_hip_replicas *)> r(new biogpt_hip_replicas(), biogpt_hip_replicas_free);
     r->devices.assign(devices, devices + n_devices);
     biogpt_hip_ctx *root = biogpt_hip_load(fname, devices[0], verbosity);

@@ -137,6 +137,11 @@ void biogpt_model_quantize_internal(std::ifstream &fin, std::ofstream &fout, con
 
 biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
                                            double temp, std::mt19937 &rng);
+/* Extension, not in the reference: biogpt_eval (biogpt.h:145-151) + biogpt_sample_top_k_top_p (:163-169) in one call with
+ * the top-k selection on the device -- the logits row stays in HBM, 512 bytes cross PCIe.  Replaces the pair at
+ * examples/main/main.cpp:98 + :118 for callers that opt in. */
+biogpt_vocab::id biogpt_eval_sample_top_k_top_p(const biogpt_model &model, const biogpt_vocab &vocab, const token_sequence &embed_inp,
+                                                const int n_past, int top_k, double top_p, double temp, std::mt19937 &rng);
 
 bool biogpt_params_parse(int argc, char **argv, biogpt_params &params);
 void biogpt_print_usage(char **argv, const biogpt_params &params);

@@ -141,6 +141,13 @@ int          biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, 
 const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx);
 int          biogpt_hip_synchronize(biogpt_hip_ctx *ctx);
 
+/* biogpt_eval + the top-k selection of biogpt_sample_top_k_top_p (biogpt.cpp:929-936) on the device: evaluates like
+ * biogpt_hip_eval and returns the k <= 64 largest logits of the last token (descending; equal logits: lower id first)
+ * and their ids -- 512 bytes over PCIe instead of the 170 KB logits row (main.cpp:98-128 only ever samples from the
+ * top_k = 40 candidates).  Returns k (clamped to n_vocab) or < 0. */
+int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t k,
+                         float *vals_out, int32_t *ids_out);
+
 /* All-rows variant used by parity tests: logits_out is [n_tokens][n_vocab] on the host
  * (the reference computes all rows and returns the last, biogpt.cpp:803,844; F8). */
 int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
@@ -199,6 +206,12 @@ int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int ste
  * side effects beyond the KV row at n_past): average seconds per token over `reps` replays,
  * HIP-event timed on the context's stream. */
 int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out);
+
+/* The reference's greedy host loop (main.cpp:91-151: one eval call per token, sampler on the host) run in C++ on this
+ * library and timed as a whole: mode 0 = biogpt_hip_eval + host arg-max (the logits row crosses PCIe every token),
+ * mode 1 = biogpt_hip_eval_topk with k = 40.  out_ids (may be NULL) receives the n_predict ids.  Measurement aid. */
+int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_predict, int32_t mode,
+                              int32_t *out_ids, double *seconds_out);
 
 /* ---- text <-> ids (host-only, no GPU needed) -------------------------------------
  * The reference's tokenizer stack -- moses_tokenize (mosestokenizer.cpp:290-358), bpe (bpe.cpp:20-91),

@@ -65,7 +65,8 @@ int main(int argc, char **argv) {
     biogpt_params prm;
     token_sequence prompt;
     const bool text_mode = argc >= 2 && std::string(argv[1]) == "--text";
-    if (argc >= 2 && (text_mode || std::string(argv[1]) == "--flags")) {
+    const bool fused_sampler = argc >= 2 && std::string(argv[1]) == "--flags-device-topk";   // biogpt_eval_sample_top_k_top_p instead of eval + sample
+    if (argc >= 2 && (text_mode || fused_sampler || std::string(argv[1]) == "--flags")) {
         if (!biogpt_params_parse(argc - 1, argv + 1, prm)) return 2;
         if (!text_mode) prompt = parse_ids(prm.prompt);
     } else {
@@ -116,10 +117,16 @@ int main(int argc, char **argv) {
     // phase 2: sample, print, feed back (the last sampled id is not evaluated)
     std::mt19937 rng(7);
     for (int k = 0; k < budget; k++) {
-        const biogpt_vocab::id id = biogpt_sample_top_k_top_p(s.vocab, s.logits.data(), prm.top_k, prm.top_p, prm.temp, rng);
+        biogpt_vocab::id id;
+        if (fused_sampler && k > 0) {   // evaluate the previous id and sample in one call: only the top-k logits leave the device
+            id = biogpt_eval_sample_top_k_top_p(s.model, s.vocab, token_sequence(1, sampled.back()), s.n_past, prm.top_k, prm.top_p, prm.temp, rng);
+            s.n_past += 1;
+        } else {
+            id = biogpt_sample_top_k_top_p(s.vocab, s.logits.data(), prm.top_k, prm.top_p, prm.temp, rng);
+        }
         printf("%d ", id);
         sampled.push_back(id);
-        if (k + 1 < budget && !s.feed(token_sequence(1, id), prm.n_threads)) return 1;
+        if (!fused_sampler && k + 1 < budget && !s.feed(token_sequence(1, id), prm.n_threads)) return 1;
     }
     printf("\n");
     if (text_mode) {

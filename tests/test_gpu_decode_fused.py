@@ -190,3 +190,23 @@ def test_c_abi_replicas_single_process(pkg, oracle, files):
     with pytest.raises(pkg.BiogptError):
         pkg.Replicas(files["q4_0"], [0, 63])          # no such device
     r.close()
+
+
+@pytest.mark.parametrize("k", [1, 7, 40, 64])
+def test_device_top_k_equals_sorted_logits(pkg, files, k):
+    """biogpt_hip_eval_topk: the k largest logits of the row (radix select on the device) == numpy on the full row that
+    biogpt_hip_eval returns for the same token; a prompt chunk and single tokens (the graph-replayed eval path)."""
+    g = pkg.BiogptModel.load(files["q5_0"])
+    rng = np.random.default_rng(k)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 12)]
+    n_past = 0
+    for chunk in (toks[:8], toks[8:9], toks[9:10], toks[10:13]):
+        full = g.eval(chunk, n_past)
+        vals, ids = g.eval_topk(chunk, n_past, k)        # same tokens, same position: same cache rows, same logits
+        order = np.lexsort((np.arange(full.size), -full))[:k]      # logit descending, ties: lower id first
+        assert list(ids) == [int(i) for i in order]
+        assert (vals == full[order]).all()
+        n_past += len(chunk)
+    with pytest.raises(pkg.BiogptError):
+        g.eval_topk([2], 0, 65)
+    g.close()

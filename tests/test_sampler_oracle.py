@@ -48,14 +48,17 @@ def test_host_sampler_equals_restatement_on_random_logits(pkg, oracle_sampler, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--flags", "--flags-device-topk"])
 @pytest.mark.parametrize("name,temp,top_p", [("q8_0", 0.9, 0.9), ("q4_1", 6.0, 0.95), ("q5_0", 25.0, 1.0)])
-def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny_models, tmp_path, name, temp, top_p):
+def test_sampled_generation_equals_oracle_loop(pkg, oracle, oracle_sampler, tiny_models, tmp_path, name, temp, top_p, mode):
     """The reference's loop (main.cpp:109-128) with top_k 40 through the compat driver on the GPU -- the CLI defaults
     (top_p 0.9, temp 0.9) and two hot settings that make the tiny model actually spread its samples -- against oracle
     logits + restated sampler with the same seed."""
     exe = _build_driver(pkg, tmp_path)
     prompt = [2, 17, 45, 300, 9]
-    r = subprocess.run([exe, "--flags", "-m", tiny_models[name], "-n", "24", "--top_k", "40", "--top_p", repr(top_p), "--temp", repr(temp),
+    # mode --flags-device-topk: biogpt_eval_sample_top_k_top_p -- the top-k selection runs on the GPU (topk_kernel), the host
+    # samples from the 40 candidates it gets back
+    r = subprocess.run([exe, mode, "-m", tiny_models[name], "-n", "24", "--top_k", "40", "--top_p", repr(top_p), "--temp", repr(temp),
                         "-p", " ".join(str(t) for t in prompt)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = [int(t) for t in r.stdout.split()]
