@@ -229,7 +229,7 @@ def main():
                                          n_prompt, (n_prompt + 7) // 8, args.ftype.upper(),
                                          "one library call per eval" if chunk_calls else
                                          "biogpt_hip_eval_prompt: %d columns (%d evals) per pass, each column limited to its own eval's keys -- same logits and KV rows" % (cols, cols // 8),
-                                         "MFMA f32 16x16x4 (BIOGPT_HIP_PREFILL_MFMA=1)" if os.environ.get("BIOGPT_HIP_PREFILL_MFMA") == "1" else "VALU, double accumulation (bit-parity path)"))
+                                         "register-tiled VALU kernel, products rounded to f32, double accumulation (bit-parity path)"))
         # weights are streamed once per pass: algorithmic bytes per pass = W + KV read of its columns' contexts
         passes = (n_prompt + cols - 1) // cols
         b = sum(pkg.decode_bytes_per_token(hp, min(n_prompt, cols * (k + 1))) for k in range(passes))

@@ -164,8 +164,8 @@ int env_int(const char *name, int dflt) {
 // Tuning / debugging switches.  Read from the environment ONCE, when a context is created (and again only on
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
-    int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min, prefill_mfma,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves;
+    int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -177,7 +177,6 @@ struct EngineOptions {
         no_chain = get("BIOGPT_HIP_NO_CHAIN", 0);
         mfma_min_cols = get("BIOGPT_HIP_MFMA_MIN_COLS", -1);      // -1: measured cross-overs (48 decode columns / 64 prompt columns)
         attn_group_min = get("BIOGPT_HIP_ATTN_GROUP_MIN", 80);
-        prefill_mfma = get("BIOGPT_HIP_PREFILL_MFMA", 0);
         split_min = get("BIOGPT_HIP_SPLIT_MIN", 256);
         attn_slim_min = get("BIOGPT_HIP_ATTN_SLIM_MIN", 48);
         dbg = get("BIOGPT_HIP_DBG", 0);
@@ -189,6 +188,8 @@ struct EngineOptions {
         fc1_blocks = get("BIOGPT_HIP_FC1_BLOCKS", 1);
         fc2_waves = get("BIOGPT_HIP_FC2_WAVES", 16);
         oproj_waves = get("BIOGPT_HIP_OPROJ_WAVES", 16);
+        attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
+        mfma_nt2_min = get("BIOGPT_HIP_MFMA_NT2_MIN", 64);
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
 };
@@ -240,7 +241,6 @@ struct biogpt_hip_ctx {
     size_t cols_cap = 0;
     int32_t *seq_gen = nullptr;           // [cap][n_positions]
     int batch_cap = 0;
-    bool mfma_attr_set = false;
     std::set<const void *> lds_attr_done;     // kernels whose > 64 KB dynamic-LDS opt-in attribute is set on this device
     unsigned long long *tstamp = nullptr;     // profiling only (opt.dbg & 32)
     int launch_parity = 0;
@@ -399,17 +399,25 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
 }
 // many columns (prompt passes, batched sequences): the same chain on the int8 matrix cores, reading the row-tiled
 // weight image (kernels_mfma.hip.h)
-template <int WT, int EPI, int K>
-hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    const size_t sm = bgk::matmul_mfma_smem_bytes(K, EPI == bgk::EPI_GELU_Q8);
-    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>);
+template <int WT, int EPI, int K, int NT>
+hipError_t launch_mfma_nt(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    const size_t sm = bgk::matmul_mfma_smem_bytes(K, EPI == bgk::EPI_GELU_Q8, NT);
+    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K, NT>);
     if (sm > 64 * 1024 && !t_ctx->lds_attr_done.count(fn)) {   // > 64 KB of dynamic LDS needs the opt-in attribute, per device
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
         t_ctx->lds_attr_done.insert(fn);
     }
-    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(256), sm, st, p, img);
+    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K, NT>), dim3((p.W.M + 63) / 64, (p.N + 16 * NT - 1) / (16 * NT)), dim3(256), sm, st, p, img);
     return hipGetLastError();
+}
+// two 16-column tiles per wave (the weight-side work of a block is shared) from mfma_nt2_min columns (default 64), for
+// matrices of >= 2048 rows only: measured at 512 columns (profiles/mfma_nt2_r2.txt) fc1 28.5 -> 26.5 us, q/k/v 18.7 -> 16.1 us,
+// but fc2 25.3 -> 28.6 us and out_proj 8.6 -> 9.3 us -- 1024 rows x 512 columns are only 1024 such waves, one per SIMD
+template <int WT, int EPI, int K>
+hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    if (opt().mfma_nt2_min > 0 && p.N >= opt().mfma_nt2_min && p.W.M >= 2048) return launch_mfma_nt<WT, EPI, K, 2>(p, img, st);
+    return launch_mfma_nt<WT, EPI, K, 1>(p, img, st);
 }
 template <int WT>
 hipError_t launch_chain_mfma(ChainOp op, const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
@@ -721,18 +729,21 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
             a.dbg = c->opt.dbg; a.tstamp = c->tstamp;
             a.q81 = q81;
             if (chain) { a.oq_q = c->aq_q[0]; a.oq_d = c->aq_d[0]; a.oq_s = c->aq_s[0]; }
-            if (!batch && dk == 64 && N >= 2 && N <= 16 && P % 16 == 0 && opt().prefill_mfma) {
-                // opt-in: QK^T / PV of the prefill chunk on the matrix cores (f32 MFMA; tolerance parity, not bit parity)
-                const size_t smb = bgk::attn_mfma_smem_bytes(P);
-                if (!c->mfma_attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
-                    HIP_TRY(false, hipFuncSetAttribute(reinterpret_cast<const void *>(bgk::attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smb));
-                    c->mfma_attr_set = true;
-                }
-                hipLaunchKernelGGL(bgk::attn_mfma_kernel, dim3(H), dim3(1024), smb, st, a);
-            } else if (!batch && dk == 64 && t_max <= 1024 && N >= opt().attn_group_min && !opt().no_fast) {
-                // a pass of many query columns: one workgroup per (head, 8 queries) shares every K / V row it loads
+            if (!batch && dk == 64 && t_max <= 1024 && N >= opt().attn_group_min && !opt().no_fast) {
+                // a pass of many query columns: register-tiled kernel, 16 queries per workgroup share every K / V row they load
+                // (BIOGPT_HIP_ATTN_TILE=0: the first grouped kernel, 8 queries per workgroup, kept as the A/B arm of the equivalence test)
                 a.t_cap = std::min(P, t_max);
-                hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
+                if (opt().attn_tile) {
+                    const size_t smb = bgk::attn_tile_smem_bytes<16>(a.t_cap);
+                    const void *fn = reinterpret_cast<const void *>(bgk::attn_tile_kernel<16>);
+                    if (smb > 64 * 1024 && !c->lds_attr_done.count(fn)) {
+                        HIP_TRY(false, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgk::attn_tile_smem_bytes<16>(P)));
+                        c->lds_attr_done.insert(fn);
+                    }
+                    hipLaunchKernelGGL((bgk::attn_tile_kernel<16>), dim3(H, (N + 15) / 16), dim3(256), smb, st, a);
+                } else {
+                    hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
+                }
             } else if (dk == 64 && t_max <= 1024 && !opt().no_fast) {
                 // loads are bounded by t_cap (= P when the table is not a multiple of 64; the workgroup stays whole
                 // waves); 4 lanes per key, 16 prefetched V rows per lane

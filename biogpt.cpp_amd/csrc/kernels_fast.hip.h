@@ -812,166 +812,194 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
     }
 }
 
-// ---- batched-prefill attention on the matrix cores (north_star: "MFMA used only for the batched prefill
-// QK^T/PV contraction") ---------------------------------------------------------------------------------
-// One 1024-thread workgroup per head, up to 16 query tokens of one chunk (n_batch = 8 pads the 16-wide tile),
-// head size 64, no intra-chunk mask (F1) unless the opt-in causal flag is set.
-//   QK^T : per 16-key tile  C[key][query] += A[key][d] * B[d][query]  with v_mfma_f32_16x16x4_f32, 16 steps
-//          over the 64 dims (the dims are visited in the order 16m + 4k + c so that every lane's operands are
-//          four consecutive floats = one 16-byte load); tiles round-robin over the 4 waves
-//   soft : 16 lanes per query row (one DPP row), fp16-table exp and double row sums as ggml_soft_max
-//   PV   : C[query][d] += A[query][key] * B[key][d], 4 keys per step, 4 MFMAs (d = 4n + c) per step;
-//          key steps round-robin over the waves, partial tiles summed through LDS
-// f32 MFMA is a k-ordered f32 fmaf chain (MI355X guide): results agree with the reference's double-sum dots
-// to f32 round-off (~1e-6 relative), i.e. inside the 1e-3 logit contract but NOT bit-identical -- this path
-// is opt-in (BIOGPT_HIP_PREFILL_MFMA=1), the default prefill attention stays the bit-parity VALU kernel.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+// ---- attention for a pass of many query columns, register-tiled (prompt passes of >= 80 columns) ---------------------
+// attn_group_kernel above spends its time issuing: per (query, key, dim) one v_mul_f32 + v_cvt_f64_f32 + v_add_f64 PLUS the
+// LDS reads of the query values, a DPP quad reduce per (query, key) and 16-way bank conflicts in its softmax (51 us per
+// layer at 512 columns, all VALU).  Here the two contractions are tiled like a GEMM, only with the reference's arithmetic
+// per element (product rounded to f32, double accumulation):
+//   scores  a thread owns 4 queries x 4 keys and walks the 64 dims IN ORDER (the oracle's own association, no cross-lane
+//           reduce): per 4 dims it reads 4 K float4 (global / L1, one row per key) + 4 Q float4 (LDS) for 64 products
+//   softmax thread = (query, one of 16 key slots): fp16-table exp, double sums, probabilities p = fl(e * (float)(1/sum))
+//           written back as [key][query] -- conflict-free, 16 queries = one 64-byte LDS row
+//   PV      a thread owns 4 queries x 4 dims over a quarter of the keys: per key one V float4 (a wave reads whole 256-byte
+//           rows) + one LDS float4 of 4 probabilities for 16 products; the 4 key slices are added at the end
+// 16 queries share every K / V row they load (8 before); 256 threads, ~40 KB of LDS -> 4 workgroups per compute unit.
+// Visibility per query as everywhere (visible_keys: the end of its own reference chunk, F1).
+template <int G>
+__host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
+    const size_t sc = (size_t)t_cap * G * 4, po = (size_t)4 * G * 64 * 8;
+    return (sc > po ? sc : po) + (size_t)G * 64 * 4 + 16 * G * 4 + 16 * G * 8 + G * 4 + 64;
+}
 
-__global__ __launch_bounds__(1024) void attn_mfma_kernel(const AttnParams p) {
-    constexpr int DK = 64, NW = 16;               // 16 waves: one per query row in the softmax phase
+template <int G>
+__global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
+    constexpr int DK = 64;
+    static_assert(G == 16, "thread maps assume 16 queries: 4 query groups x 64 key groups, 16 queries x 16 key slots, 4 x 16 x 4 for PV");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int t_cap = p.t_cap;
+    const size_t main_bytes = ((size_t)t_cap * G * 4 > (size_t)4 * G * DK * 8) ? (size_t)t_cap * G * 4 : (size_t)4 * G * DK * 8;
+    float *const S = reinterpret_cast<float *>(smem_raw);                       // [key][G]: scores, then e, then probabilities
+    double *const pvp = reinterpret_cast<double *>(smem_raw);                   // [4 slices][G][DK] partial outputs (after the PV loop)
+    float *const Qs = reinterpret_cast<float *>(smem_raw + main_bytes);         // [G][DK]
+    float *const s_mx = Qs + G * DK;                                            // [16 slots][G]
+    double *const s_sum = reinterpret_cast<double *>(s_mx + 16 * G);            // [16 slots][G]
+    float *const s_inv = reinterpret_cast<float *>(s_sum + 16 * G);             // [G]
     const int h = blockIdx.x;
+    // dispatch order: the long-context half of the tiles first (largest first), then the short half in ASCENDING order -- the
+    // second wave of workgroups then lands a short tile next to each long one and every compute unit gets the same work
+    const int ny = (int)gridDim.y, yb = (int)blockIdx.y, nhalf = (ny + 1) / 2;
+    const int i0 = ((yb < nhalf) ? ny - 1 - yb : yb - nhalf) * G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int D = p.D, N = p.N;
-    const int n_past = p.st->n_past;
-    const int T = n_past + N;
-    const int T16 = (T + 15) & ~15;
-    const int TP = p.P + 2;                       // LDS row pitch (floats): pitch % 32 == 2 -> conflict-free A reads in PV
-    float *S = reinterpret_cast<float *>(smem_raw);                       // [16][TP] scores, then probabilities
-    float *R = S + 16 * TP;                                               // [16 waves][16][64] partial outputs
+    const int N = p.N, D = p.D;
 
-    const float *kbase = p.kcache + (size_t)h * p.P * DK;                 // head-major cache [H][P][dk]
-    const float *vbase = p.vcache + (size_t)h * p.P * DK;
-    const int li = lane & 15, lk = lane >> 4;
+    // queries of this tile -> LDS (row-major), 4 floats per thread
+    {
+        const int q = tid >> 4, d4 = tid & 15;
+        reinterpret_cast<float4 *>(Qs)[tid] = *reinterpret_cast<const float4 *>(p.q + (size_t)min(i0 + q, N - 1) * D + (size_t)h * DK + 4 * d4);
+    }
+    const int Tmax = visible_keys(p.st, min(i0 + G - 1, N - 1), N);              // visibility grows with the column index
+    __syncthreads();
 
-    // B operand of QK^T: this lane's query row (li), dims 16m + 4lk + c
-    float4 qv[4];
+    // ---- scores ----
+    {
+        const int kg = tid >> 2, qg = tid & 3;
+        int Tq[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++)
-        qv[m] = (li < N) ? *reinterpret_cast<const float4 *>(p.q + (size_t)li * D + (size_t)h * DK + 16 * m + 4 * lk) : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // ---- QK^T: 16-key tiles round-robin over the 16 waves, 2 tiles per trip (all loads first) ----
-    for (int j0 = wave * 16; j0 < T16; j0 += 2 * NW * 16) {
-        float4 kv[2][4];
+        for (int qi = 0; qi < 4; qi++) Tq[qi] = (i0 + 4 * qg + qi < N) ? visible_keys(p.st, i0 + 4 * qg + qi, N) : 0;
+        const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK);
+        const float4 *qbase = reinterpret_cast<const float4 *>(Qs + 4 * qg * DK);
+        for (int j0 = 0; j0 < Tmax; j0 += 256) {
+            if (j0 + 64 * wave >= Tmax) break;                                   // this wave's 64 keys are past every query's context
+            const int jb = j0 + 4 * kg;
+            const float4 *krow[4];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int jt = j0 + NW * 16 * u;
-            const float *krow = kbase + (size_t)min(jt + li, p.P - 1) * DK + 4 * lk;
+            for (int c = 0; c < 4; c++) krow[c] = kbase + (size_t)min(jb + c, t_cap - 1) * (DK / 4);
+            double acc[4][4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) kv[u][m] = *reinterpret_cast<const float4 *>(krow + 16 * m);
-        }
+            for (int qi = 0; qi < 4; qi++)
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int jt = j0 + NW * 16 * u;
-            if (jt >= T16) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < 4; c++) acc[qi][c] = 0.0;
+#pragma unroll 4
+            for (int m = 0; m < DK / 4; m++) {
+                float4 kv[4], qv[4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].x, qv[m].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].y, qv[m].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].z, qv[m].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[u][m].w, qv[m].w, acc, 0, 0, 0);
+                for (int c = 0; c < 4; c++) kv[c] = krow[c][m];
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++) qv[qi] = qbase[qi * (DK / 4) + m];
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        acc[qi][c] += (double)__fmul_rn(kv[c].x, qv[qi].x);
+                        acc[qi][c] += (double)__fmul_rn(kv[c].y, qv[qi].y);
+                        acc[qi][c] += (double)__fmul_rn(kv[c].z, qv[qi].z);
+                        acc[qi][c] += (double)__fmul_rn(kv[c].w, qv[qi].w);
+                    }
             }
-            // C layout: column (query) = lane & 15, rows (keys) = 4*(lane >> 4) + r
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int j = jt + 4 * lk + r;
-                const int tlim = visible_keys(p.st, li, N);
-                S[li * TP + j] = (j < tlim) ? acc[r] : -INFINITY;
+            for (int c = 0; c < 4; c++) {
+                const int j = jb + c;
+                if (j < t_cap)
+                    *reinterpret_cast<float4 *>(S + (size_t)j * G + 4 * qg) =
+                        make_float4(j < Tq[0] ? (float)acc[0][c] : -INFINITY, j < Tq[1] ? (float)acc[1][c] : -INFINITY,
+                                    j < Tq[2] ? (float)acc[2][c] : -INFINITY, j < Tq[3] ? (float)acc[3][c] : -INFINITY);
             }
         }
     }
     __syncthreads();
 
-    // ---- softmax: wave w owns query row w (ggml_soft_max: fp16-table exp, double row sum) ----
+    // ---- softmax (ggml_soft_max: fp16-table exp, double row sum, p = fl(e * (float)(1/sum))) ----
     {
-        float *Sr = S + wave * TP;
+        const int q = tid & 15, slot = tid >> 4;
+        const int Tw = (i0 + q < N) ? visible_keys(p.st, i0 + q, N) : 0;
         float mx = -INFINITY;
-        for (int j = lane; j < T16; j += 64) mx = fmaxf(mx, Sr[j]);
-        mx = wave_max_f32(mx);
+        for (int j = slot; j < Tw; j += 16) mx = fmaxf(mx, S[(size_t)j * G + q]);
+        s_mx[slot * G + q] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) mx = fmaxf(mx, s_mx[s2 * G + q]);
         double sum = 0.0;
-        for (int j0 = lane; j0 < T16; j0 += 256) {      // 4 table lookups in flight per lane
-            float val[4];
+        for (int j = slot; j < Tw; j += 64) {            // 4 table lookups in flight per thread
+            float e[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = j0 + 64 * u;
-                val[u] = (j < T16) ? h2f(p.exp_tab[f2h(__fsub_rn(Sr[j], mx))]) : 0.0f;   // exp(-inf) = 0 for masked / padded keys
+                const int jj = j + 16 * u;
+                e[u] = (jj < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(S[(size_t)jj * G + q], mx))]) : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = j0 + 64 * u;
-                if (j < T16) { Sr[j] = val[u]; sum += (double)val[u]; }
+                const int jj = j + 16 * u;
+                if (jj < Tw) { S[(size_t)jj * G + q] = e[u]; sum += (double)e[u]; }
             }
         }
-        sum = wave_sum_f64(sum);
-        const float inv = inv_sum_f32(sum);
-        for (int j = lane; j < T16; j += 64) Sr[j] = __fmul_rn(Sr[j], inv);
+        s_sum[slot * G + q] = sum;
+        __syncthreads();
+        if (slot == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; s2++) t += s_sum[s2 * G + q];
+            s_inv[q] = (Tw > 0) ? inv_sum_f32(t) : 0.0f;
+        }
+        __syncthreads();
+        const float inv = s_inv[q];
+        for (int j = slot; j < Tmax; j += 16) S[(size_t)j * G + q] = (j < Tw) ? __fmul_rn(S[(size_t)j * G + q], inv) : 0.0f;
     }
     __syncthreads();
 
-    // ---- PV: 4-key steps round-robin over the 16 waves, 4 steps per trip (all loads first) ----
-    f32x4 o[4];
+    // ---- PV: wave = key slice (j mod 4), lane = (4 queries, 4 dims) ----
+    double acc[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave * 4; j0 < T16; j0 += 4 * NW * 4) {
-        float a[4];
-        float4 b[4];
+    for (int qi = 0; qi < 4; qi++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + NW * 4 * u;
-            const bool ok = j < T16;
-            a[u] = ok ? S[li * TP + j + lk] : 0.0f;                                                    // A[query li][key j + lk]
-            b[u] = ok ? *reinterpret_cast<const float4 *>(vbase + (size_t)(j + lk) * DK + 4 * li)      // B[key][d = 4*li + c]
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, o[1], 0, 0, 0);
-            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, o[2], 0, 0, 0);
-            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, o[3], 0, 0, 0);
-        }
-    }
-    // C layout: column n = lane & 15 -> d = 4n + c ; rows (queries) = 4*(lane >> 4) + r
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) R[(wave * 16 + 4 * lk + r) * DK + 4 * li + c] = o[c][r];
-    __syncthreads();
-
-    // ---- combine the 16 waves: thread -> one output (query qi, dim dd); waves summed in order ----
+        for (int c = 0; c < 4; c++) acc[qi][c] = 0.0;
     {
-        const int qi = tid >> 6, dd = tid & 63;
-        float v = 0.0f;
+        const int qg = lane >> 4, dg = lane & 15;
+        const float4 *vbase = reinterpret_cast<const float4 *>(p.vcache + (size_t)h * p.P * DK) + dg;
+        for (int j = wave; j < Tmax; j += 16) {          // 4 keys of this slice per trip: all loads first
+            float4 v[4], pr[4];
 #pragma unroll
-        for (int w = 0; w < NW; w++) v += R[(w * 16 + qi) * DK + dd];
-        const bool live = qi < N;
-        if (live) p.out[(size_t)qi * D + (size_t)h * DK + dd] = v;
-        if (p.oq_q != nullptr) {
-            // wave qi holds the query's 64 outputs of this head = two Q8 blocks (quantize_row_q8_0 / q8_1)
-            float amax = fabsf(v);
-            amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_QUAD_XOR2>(amax));
-            amax = fmaxf(amax, dpp_f<DPP_ROW_HALF_MIRROR>(amax)); amax = fmaxf(amax, dpp_f<DPP_ROW_MIRROR>(amax));
-            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-            const float dq = amax / 127.0f;
-            const float id = (dq != 0.0f) ? 1.0f / dq : 0.0f;
-            const int q = (int)roundf(__fmul_rn(v, id));
-            int isum = q;
-            isum += dpp_i<DPP_QUAD_XOR1>(isum); isum += dpp_i<DPP_QUAD_XOR2>(isum);
-            isum += dpp_i<DPP_ROW_HALF_MIRROR>(isum); isum += dpp_i<DPP_ROW_MIRROR>(isum);
-            isum += __shfl_xor(isum, 16, 64);
-            if (live) {
-                const size_t blk = (size_t)qi * (D / 32) + h * 2 + (dd >> 5);
-                p.oq_q[blk * 32 + (dd & 31)] = (int8_t)q;
-                if ((dd & 31) == 0) {
-                    if (p.q81) { p.oq_d[blk] = dq; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, dq)); }
-                    else { p.oq_d[blk] = h2f(f2h(dq)); p.oq_s[blk] = (uint32_t)isum; }
+            for (int u = 0; u < 4; u++) {
+                const int jj = j + 4 * u;
+                v[u] = vbase[(size_t)min(jj, t_cap - 1) * (DK / 4)];
+                pr[u] = (jj < Tmax) ? *reinterpret_cast<const float4 *>(S + (size_t)jj * G + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j + 4 * u < Tmax) {                   // a hidden key has p = 0 and adds +-0: the accumulator is unchanged
+                    const float pq[4] = {pr[u].x, pr[u].y, pr[u].z, pr[u].w};
+#pragma unroll
+                    for (int qi = 0; qi < 4; qi++) {
+                        acc[qi][0] += (double)__fmul_rn(v[u].x, pq[qi]); acc[qi][1] += (double)__fmul_rn(v[u].y, pq[qi]);
+                        acc[qi][2] += (double)__fmul_rn(v[u].z, pq[qi]); acc[qi][3] += (double)__fmul_rn(v[u].w, pq[qi]);
+                    }
                 }
             }
         }
     }
+    __syncthreads();                                      // every read of S is done: the area becomes pvp
+    {
+        const int qg = lane >> 4, dg = lane & 15;
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) pvp[((size_t)wave * G + 4 * qg + qi) * DK + 4 * dg + c] = acc[qi][c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                         // wave w finishes queries w, w+4, w+8, w+12: 64 outputs each = two Q8 blocks
+        const int q = wave + 4 * r;
+        if (i0 + q < N) {
+            const double t0 = pvp[((size_t)0 * G + q) * DK + lane] + pvp[((size_t)1 * G + q) * DK + lane];
+            const double t1 = pvp[((size_t)2 * G + q) * DK + lane] + pvp[((size_t)3 * G + q) * DK + lane];
+            store_head_output(p, i0 + q, h, lane, (float)(t0 + t1), p.oq_q != nullptr);
+        }
+    }
 }
 
-__host__ __device__ inline size_t attn_mfma_smem_bytes(int P) { return ((size_t)16 * (P + 2) + 16 * 16 * 64) * 4 + 64; }
+// (A matrix-core version of this contraction -- v_mfma_f32_16x16x4_f32 for QK^T and PV -- was built in round 1 and removed in
+// round 2: f32 MFMA is an f32 fma chain, the reference sums the f32-rounded products in double, and the ~1e-7 difference flips
+// int8 codes of the next Q8 activation block often enough that its logits only held 5e-2, 50x outside the contract; it was also
+// slower than the VALU kernel at 8-16 query rows.  The matrix cores are used where the reference's arithmetic is integer and
+// therefore exact: the int8 block dots of the projections, kernels_mfma.hip.h.  DESIGN.md section 4.5.)
 
 }  // namespace bgk

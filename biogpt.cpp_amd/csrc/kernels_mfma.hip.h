@@ -125,91 +125,114 @@ __device__ __forceinline__ long mfma_a_operand(const MfmaBatch<WT> &t, int j, in
     return (long)(((unsigned long)hi << 32) | lo);
 }
 
-__host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool gelu_q8) {
-    const int kp = K > 2048 ? 2048 : K;                                        // staged K phase
-    const size_t act = (size_t)16 * (kp + 16) + 2 * (size_t)16 * (kp / QK + 1) * 4;
-    const size_t tail = gelu_q8 ? (size_t)16 * 64 * 4 : 0;
+// NT = 16-column tiles per wave.  NT = 2: the weight-side work of a block (operand unpack, the four fp16 row scales) feeds
+// two MFMAs and two sets of per-output terms, and the two tiles' dependency chains interleave.
+__host__ __device__ inline int matmul_mfma_kp(int K, int nt) { const int cap = nt == 1 ? 2048 : 1024; return K > cap ? cap : K; }
+__host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool gelu_q8, int nt = 1) {
+    const int kp = matmul_mfma_kp(K, nt), nc = 16 * nt;                        // staged K phase, columns per workgroup
+    const size_t act = (size_t)nc * (kp + 16) + 2 * (size_t)nc * (kp / QK + 1) * 4;
+    const size_t tail = gelu_q8 ? (size_t)nc * 64 * 4 : 0;
     return (act > tail ? act : tail) + 64;    // the GELU_Q8 exchange reuses the activation area after the last block
 }
 
-template <int WT, int EPI, int K>
+template <int WT, int EPI, int K, int NT = 1>
 __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
-    // KP: columns of K staged in LDS at a time (K = 4096 goes in two phases: 41 KB instead of 82 KB, so three workgroups
+    static_assert(NT == 1 || NT == 2, "column tiles per wave");
+    // KP: columns of K staged in LDS at a time (K = 4096 goes in phases: 41 KB instead of 82 KB, so three workgroups
     // fit a compute unit instead of one; the accumulators simply carry over, block order is unchanged)
-    constexpr int KP = K > 2048 ? 2048 : K, NPH = K / KP, BPP = KP / QK;
+    constexpr int KP = (NT == 1) ? (K > 2048 ? 2048 : K) : (K > 1024 ? 1024 : K), NPH = K / KP, BPP = KP / QK, NC = 16 * NT;
     constexpr int CH = MfmaBatch<WT>::CH, BPR = K / QK, NB = BPP / CH, PITCH = KP + 16, SP = BPP + 1;   // SP: per-column pitch of the scale arrays (bank skew)
     static_assert(NB % 2 == 0, "K must be a multiple of 512");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint8_t *const s_q = smem_raw;                                              // [16 columns][PITCH] int8
-    float *const s_d = reinterpret_cast<float *>(smem_raw + 16 * PITCH);        // [16][SP] activation block scales
-    uint32_t *const s_s = reinterpret_cast<uint32_t *>(s_d + 16 * SP);          // [16][SP] block sums (Q8_0: int, Q8_1: d*sum)
-    float *const s_tail = reinterpret_cast<float *>(smem_raw);                  // GELU_Q8: [16 columns][64 rows], after the loop
+    uint8_t *const s_q = smem_raw;                                              // [NC columns][PITCH] int8
+    float *const s_d = reinterpret_cast<float *>(smem_raw + NC * PITCH);        // [NC][SP] activation block scales
+    uint32_t *const s_s = reinterpret_cast<uint32_t *>(s_d + NC * SP);          // [NC][SP] block sums (Q8_0: int, Q8_1: d*sum)
+    float *const s_tail = reinterpret_cast<float *>(smem_raw);                  // GELU_Q8: [NC columns][64 rows], after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int M = p.W.M;
     const int tile = blockIdx.x * 4 + wave;                                     // 16-row tile of this wave
-    const int row0 = tile * 16, col0 = blockIdx.y * 16;
+    const int row0 = tile * 16, col0 = blockIdx.y * NC;
     const bool tile_ok = row0 < M;
     const int tile_c = tile_ok ? tile : 0;                                      // waves past the last row keep the barriers company
     const int64_t base = (int64_t)tile_c * BPR * 16;
-    const int col = col0 + li;
-    const bool col_ok = col < p.N;
-    const int colc = min(col, p.N - 1);
-    const int orow = row0 + 4 * g;                                              // outputs: rows 4g .. 4g+3, column lane & 15
+    const int orow = row0 + 4 * g;                                              // outputs: rows 4g .. 4g+3, columns col0 + 16t + (lane & 15)
 
     const MfmaLanePtrs<WT> lp = mfma_lane_ptrs<WT>(img, base, li, g);
     MfmaBatch<WT> t0, t1;
     mfma_load_batch<WT>(t0, lp, 0);
     // epilogue inputs (independent loads); M is a multiple of 4 everywhere
     const int orc = min(orow, M - 4);
-    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res = e_bias;
+    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res[NT];
     if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc);
-    if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc * p.ldr + orc);
-    int e_npast = 0, e_seq = 0;
-    if (EPI == EPI_QKV) {
-        e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
-        e_seq = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
+    int e_npast[NT], e_seq[NT], colv[NT];
+    bool col_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        colv[t] = col0 + 16 * t + li;
+        col_ok[t] = colv[t] < p.N;
+        const int colc = min(colv[t], p.N - 1);
+        e_res[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_RESID) e_res[t] = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc * p.ldr + orc);
+        e_npast[t] = 0; e_seq[t] = 0;
+        if (EPI == EPI_QKV) {
+            e_npast[t] = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
+            e_seq[t] = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
+        }
     }
 
-    const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15, k-group g
+    const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15 (+ 16 t), k-group g
     const float *bd = s_d + li * SP;
     const uint32_t *bs = s_s + li * SP;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto consume = [&](const MfmaBatch<WT> &t, int b0) {                        // b0: block index inside the staged phase
+    float acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[t][r] = 0.0f;
+    auto consume = [&](const MfmaBatch<WT> &tb, int b0) {                       // b0: block index inside the staged phase
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             const int b = b0 + j;
-            const long bop = *reinterpret_cast<const long *>(bq + b * QK);
-            const float xd = bd[b];
-            const uint32_t xs = bs[b];
-            const i32x4 zero = {0, 0, 0, 0};
-            const i32x4 c = __builtin_amdgcn_mfma_i32_16x16x32_i8(mfma_a_operand<WT>(t, j, g), bop, zero, 0, 0, 0);
+            const long aop = mfma_a_operand<WT>(tb, j, g);
+            uint32_t scr[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t sc = TI::q81 ? t.sc[j][r] : ((t.sc[j][r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
-                acc[r] = __fadd_rn(acc[r], mfma_block_term<WT>(c[r], sc, xd, xs));
+            for (int r = 0; r < 4; r++) scr[r] = TI::q81 ? tb.sc[j][r] : ((tb.sc[j][r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+            i32x4 c[NT];
+            float xd[NT];
+            uint32_t xs[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const long bop = *reinterpret_cast<const long *>(bq + t * 16 * PITCH + b * QK);
+                xd[t] = bd[t * 16 * SP + b];
+                xs[t] = bs[t * 16 * SP + b];
+                const i32x4 zero = {0, 0, 0, 0};
+                c[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop, zero, 0, 0, 0);
             }
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t][r] = __fadd_rn(acc[t][r], mfma_block_term<WT>(c[t][r], scr[r], xd[t], xs[t]));
         }
     };
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ph++) {
-        // ---- stage this phase of the 16 activation columns in LDS (coalesced 16-byte pieces) ----
+        // ---- stage this phase of the NC activation columns in LDS (coalesced 16-byte pieces) ----
         if (ph > 0) __syncthreads();                                            // the previous phase has been consumed
         {
             constexpr int PPC = KP / 16;                                        // 16-byte pieces per column
 #pragma unroll
-            for (int i = 0; i < 16 * PPC / 256; i++) {
+            for (int i = 0; i < NC * PPC / 256; i++) {
                 const int pc = tid + 256 * i, c = pc / PPC, o = (pc - c * PPC) * 16;
                 const int cc = min(col0 + c, p.N - 1);                          // idle columns re-read the last one
                 *reinterpret_cast<uint4 *>(s_q + c * PITCH + o) = *reinterpret_cast<const uint4 *>(p.aq_q + (size_t)cc * K + ph * KP + o);
             }
 #pragma unroll
-            for (int i = 0; i < (16 * BPP + 255) / 256; i++) {
+            for (int i = 0; i < (NC * BPP + 255) / 256; i++) {
                 const int e = tid + 256 * i;
-                if (e < 16 * BPP) {
+                if (e < NC * BPP) {
                     const int c = e / BPP, b = e - c * BPP;
                     const int cc = min(col0 + c, p.N - 1);
                     s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
@@ -228,17 +251,19 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
         }
     }
 
-    const bool ok = col_ok && tile_ok;
     if (EPI == EPI_GELU_Q8) {
         __syncthreads();                                                        // everyone is done reading the activation area
-        float4 v;
-        v.x = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.x, acc[0]))]); v.y = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.y, acc[1]))]);
-        v.z = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.z, acc[2]))]); v.w = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.w, acc[3]))]);
-        *reinterpret_cast<float4 *>(s_tail + li * 64 + wave * 16 + 4 * g) = v;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float4 v;
+            v.x = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.x, acc[t][0]))]); v.y = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.y, acc[t][1]))]);
+            v.z = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.z, acc[t][2]))]); v.w = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.w, acc[t][3]))]);
+            *reinterpret_cast<float4 *>(s_tail + (16 * t + li) * 64 + wave * 16 + 4 * g) = v;
+        }
         __syncthreads();
         // the workgroup's 64 rows are two Q8 blocks of fc2's activation row per column: quantize_row_q8_0 / _q8_1,
         // a half-wave per (column, block)
-        for (int u = wave * 2 + (lane >> 5); u < 32; u += 8) {
+        for (int u = wave * 2 + (lane >> 5); u < 2 * NC; u += 8) {
             const int c = u >> 1, half = u & 1;
             if (col0 + c >= p.N) continue;
             const float v1 = s_tail[c * 64 + half * 32 + (lane & 31)];
@@ -260,26 +285,31 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
                 else { p.oq_d[blk] = h2f(f2h(d)); p.oq_s[blk] = (uint32_t)isum; }
             }
         }
-    } else if (ok) {
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (!(col_ok[t] && tile_ok)) continue;
+        const int col = colv[t];
         if (EPI == EPI_QKV) {
             float4 v;
-            v.x = __fadd_rn(e_bias.x, acc[0]); v.y = __fadd_rn(e_bias.y, acc[1]); v.z = __fadd_rn(e_bias.z, acc[2]); v.w = __fadd_rn(e_bias.w, acc[3]);
+            v.x = __fadd_rn(e_bias.x, acc[t][0]); v.y = __fadd_rn(e_bias.y, acc[t][1]); v.z = __fadd_rn(e_bias.z, acc[t][2]); v.w = __fadd_rn(e_bias.w, acc[t][3]);
             const int which = orow / K, rr = orow - which * K;             // d_model == K for the q/k/v projection
             if (which == 0) {
                 v.x = __fmul_rn(v.x, p.q_scale); v.y = __fmul_rn(v.y, p.q_scale); v.z = __fmul_rn(v.z, p.q_scale); v.w = __fmul_rn(v.w, p.q_scale);
                 *reinterpret_cast<float4 *>(p.q_out + (size_t)col * K + rr) = v;
             } else {
-                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq * p.kv_seq_stride : 0);
+                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq[t] * p.kv_seq_stride : 0);
                 const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);       // head-major cache: [H][P][dk]; 4 | dk
-                *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast) << p.dk_log2) + dd) = v;
+                *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast[t]) << p.dk_log2) + dd) = v;
             }
         } else if (EPI == EPI_RESID) {
             float4 v;
-            v.x = __fadd_rn(__fadd_rn(acc[0], e_bias.x), e_res.x); v.y = __fadd_rn(__fadd_rn(acc[1], e_bias.y), e_res.y);
-            v.z = __fadd_rn(__fadd_rn(acc[2], e_bias.z), e_res.z); v.w = __fadd_rn(__fadd_rn(acc[3], e_bias.w), e_res.w);
+            v.x = __fadd_rn(__fadd_rn(acc[t][0], e_bias.x), e_res[t].x); v.y = __fadd_rn(__fadd_rn(acc[t][1], e_bias.y), e_res[t].y);
+            v.z = __fadd_rn(__fadd_rn(acc[t][2], e_bias.z), e_res[t].z); v.w = __fadd_rn(__fadd_rn(acc[t][3], e_bias.w), e_res[t].w);
             *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = v;
         } else {
-            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
         }
     }
 }
