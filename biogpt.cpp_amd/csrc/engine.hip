@@ -740,7 +740,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                         HIP_TRY(false, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgk::attn_tile_smem_bytes<16>(P)));
                         c->lds_attr_done.insert(fn);
                     }
-                    hipLaunchKernelGGL((bgk::attn_tile_kernel<16>), dim3(H, (N + 15) / 16), dim3(256), smb, st, a);
+                    hipLaunchKernelGGL((bgk::attn_tile_kernel<16>), dim3(H, (N + 15) / 16), dim3(512), smb, st, a);
                 } else {
                     hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
                 }

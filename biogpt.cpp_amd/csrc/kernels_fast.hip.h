@@ -827,40 +827,47 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
 // Visibility per query as everywhere (visible_keys: the end of its own reference chunk, F1).
 template <int G>
 __host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
-    const size_t sc = (size_t)t_cap * G * 4, po = (size_t)4 * G * 64 * 8;
-    return (sc > po ? sc : po) + (size_t)G * 64 * 4 + 16 * G * 4 + 16 * G * 8 + G * 4 + 64;
+    const size_t sc = (size_t)t_cap * G * 4, po = (size_t)8 * G * 64 * 8;
+    return (sc > po ? sc : po) + (size_t)G * 64 * 4 + 32 * G * 4 + 32 * G * 8 + G * 4 + 64;
 }
 
+// 512 threads = 8 waves: the critical path of the pass is its longest tile (512 keys), whose per-thread work this halves
+// against a 256-thread version; two workgroups per compute unit = 4 waves per SIMD, hence the 128-register bound.
+// Measured per layer at 512 columns (profiles/prefill_attention_r2.txt): grouped kernel above 51 us; this tiling with 256
+// threads 48 us whatever the inner-loop order; + K staged through LDS 57 us; 512 threads 41 us (shipped); two tiles (longest +
+// shortest) per workgroup for perfect balance 55 us (half the waves per SIMD); register double-buffering of the operands under
+// the 128-register bound spills (262 us).  The instruction stream itself (v_pk_mul_f32 + 2 v_cvt_f64_f32 + 2 v_add_f64 per two
+// products) costs 8.5-9.2 SIMD cycles per wave-MAC in isolation (tools/microbench10): ~17 us for this layer if nothing waited.
 template <int G>
-__global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
-    constexpr int DK = 64;
-    static_assert(G == 16, "thread maps assume 16 queries: 4 query groups x 64 key groups, 16 queries x 16 key slots, 4 x 16 x 4 for PV");
+__global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
+    constexpr int DK = 64, NW = 8;
+    static_assert(G == 16, "thread maps assume 16 queries: 4 query groups x 128 key groups, 16 queries x 32 key slots, 8 x (4 x 16) for PV");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t_cap = p.t_cap;
-    const size_t main_bytes = ((size_t)t_cap * G * 4 > (size_t)4 * G * DK * 8) ? (size_t)t_cap * G * 4 : (size_t)4 * G * DK * 8;
+    const size_t main_bytes = ((size_t)t_cap * G * 4 > (size_t)NW * G * DK * 8) ? (size_t)t_cap * G * 4 : (size_t)NW * G * DK * 8;
     float *const S = reinterpret_cast<float *>(smem_raw);                       // [key][G]: scores, then e, then probabilities
-    double *const pvp = reinterpret_cast<double *>(smem_raw);                   // [4 slices][G][DK] partial outputs (after the PV loop)
+    double *const pvp = reinterpret_cast<double *>(smem_raw);                   // [8 slices][G][DK] partial outputs (after the PV loop)
     float *const Qs = reinterpret_cast<float *>(smem_raw + main_bytes);         // [G][DK]
-    float *const s_mx = Qs + G * DK;                                            // [16 slots][G]
-    double *const s_sum = reinterpret_cast<double *>(s_mx + 16 * G);            // [16 slots][G]
-    float *const s_inv = reinterpret_cast<float *>(s_sum + 16 * G);             // [G]
+    float *const s_mx = Qs + G * DK;                                            // [32 slots][G]
+    double *const s_sum = reinterpret_cast<double *>(s_mx + 32 * G);            // [32 slots][G]
+    float *const s_inv = reinterpret_cast<float *>(s_sum + 32 * G);             // [G]
     const int h = blockIdx.x;
-    // dispatch order: the long-context half of the tiles first (largest first), then the short half in ASCENDING order -- the
-    // second wave of workgroups then lands a short tile next to each long one and every compute unit gets the same work
-    const int ny = (int)gridDim.y, yb = (int)blockIdx.y, nhalf = (ny + 1) / 2;
-    const int i0 = ((yb < nhalf) ? ny - 1 - yb : yb - nhalf) * G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, D = p.D;
+    // dispatch order: the long-context half of the tiles first (largest first), then the short half in ASCENDING order -- the
+    // second round of workgroups then lands a short tile next to each long one (44.9 -> 41.2 us against plain longest-first)
+    const int ny = (int)gridDim.y, yb = (int)blockIdx.y, nhalf = (ny + 1) / 2;
+    const int i0 = ((yb < nhalf) ? ny - 1 - yb : yb - nhalf) * G;
 
-    // queries of this tile -> LDS (row-major), 4 floats per thread
-    {
+    // queries of this tile -> LDS (row-major), 4 floats per thread of the first four waves
+    if (tid < 256) {
         const int q = tid >> 4, d4 = tid & 15;
         reinterpret_cast<float4 *>(Qs)[tid] = *reinterpret_cast<const float4 *>(p.q + (size_t)min(i0 + q, N - 1) * D + (size_t)h * DK + 4 * d4);
     }
     const int Tmax = visible_keys(p.st, min(i0 + G - 1, N - 1), N);              // visibility grows with the column index
     __syncthreads();
 
-    // ---- scores ----
+    // ---- scores: a thread owns 4 queries x 4 keys and walks the 64 dims in order ----
     {
         const int kg = tid >> 2, qg = tid & 3;
         int Tq[4];
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
         for (int qi = 0; qi < 4; qi++) Tq[qi] = (i0 + 4 * qg + qi < N) ? visible_keys(p.st, i0 + 4 * qg + qi, N) : 0;
         const float4 *kbase = reinterpret_cast<const float4 *>(p.kcache + (size_t)h * p.P * DK);
         const float4 *qbase = reinterpret_cast<const float4 *>(Qs + 4 * qg * DK);
-        for (int j0 = 0; j0 < Tmax; j0 += 256) {
+        for (int j0 = 0; j0 < Tmax; j0 += 512) {
             if (j0 + 64 * wave >= Tmax) break;                                   // this wave's 64 keys are past every query's context
             const int jb = j0 + 4 * kg;
             const float4 *krow[4];
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
             for (int qi = 0; qi < 4; qi++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) acc[qi][c] = 0.0;
-#pragma unroll 4
+#pragma unroll 2
             for (int m = 0; m < DK / 4; m++) {
                 float4 kv[4], qv[4];
 #pragma unroll
@@ -889,12 +896,19 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
 #pragma unroll
                 for (int qi = 0; qi < 4; qi++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        acc[qi][c] += (double)__fmul_rn(kv[c].x, qv[qi].x);
-                        acc[qi][c] += (double)__fmul_rn(kv[c].y, qv[qi].y);
-                        acc[qi][c] += (double)__fmul_rn(kv[c].z, qv[qi].z);
-                        acc[qi][c] += (double)__fmul_rn(kv[c].w, qv[qi].w);
-                    }
+                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].x, qv[qi].x);
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].y, qv[qi].y);
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].z, qv[qi].z);
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].w, qv[qi].w);
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -910,25 +924,25 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
 
     // ---- softmax (ggml_soft_max: fp16-table exp, double row sum, p = fl(e * (float)(1/sum))) ----
     {
-        const int q = tid & 15, slot = tid >> 4;
+        const int q = tid & 15, slot = tid >> 4;           // 32 key slots
         const int Tw = (i0 + q < N) ? visible_keys(p.st, i0 + q, N) : 0;
         float mx = -INFINITY;
-        for (int j = slot; j < Tw; j += 16) mx = fmaxf(mx, S[(size_t)j * G + q]);
+        for (int j = slot; j < Tw; j += 32) mx = fmaxf(mx, S[(size_t)j * G + q]);
         s_mx[slot * G + q] = mx;
         __syncthreads();
 #pragma unroll
-        for (int s2 = 0; s2 < 16; s2++) mx = fmaxf(mx, s_mx[s2 * G + q]);
+        for (int s2 = 0; s2 < 32; s2++) mx = fmaxf(mx, s_mx[s2 * G + q]);
         double sum = 0.0;
-        for (int j = slot; j < Tw; j += 64) {            // 4 table lookups in flight per thread
+        for (int j = slot; j < Tw; j += 128) {           // 4 table lookups in flight per thread
             float e[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int jj = j + 16 * u;
+                const int jj = j + 32 * u;
                 e[u] = (jj < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(S[(size_t)jj * G + q], mx))]) : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int jj = j + 16 * u;
+                const int jj = j + 32 * u;
                 if (jj < Tw) { S[(size_t)jj * G + q] = e[u]; sum += (double)e[u]; }
             }
         }
@@ -937,16 +951,16 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
         if (slot == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; s2++) t += s_sum[s2 * G + q];
+            for (int s2 = 0; s2 < 32; s2++) t += s_sum[s2 * G + q];
             s_inv[q] = (Tw > 0) ? inv_sum_f32(t) : 0.0f;
         }
         __syncthreads();
         const float inv = s_inv[q];
-        for (int j = slot; j < Tmax; j += 16) S[(size_t)j * G + q] = (j < Tw) ? __fmul_rn(S[(size_t)j * G + q], inv) : 0.0f;
+        for (int j = slot; j < Tmax; j += 32) S[(size_t)j * G + q] = (j < Tw) ? __fmul_rn(S[(size_t)j * G + q], inv) : 0.0f;
     }
     __syncthreads();
 
-    // ---- PV: wave = key slice (j mod 4), lane = (4 queries, 4 dims) ----
+    // ---- PV: wave = key slice (j mod 8), lane = (4 queries, 4 dims) ----
     double acc[4][4];
 #pragma unroll
     for (int qi = 0; qi < 4; qi++)
@@ -955,17 +969,17 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
     {
         const int qg = lane >> 4, dg = lane & 15;
         const float4 *vbase = reinterpret_cast<const float4 *>(p.vcache + (size_t)h * p.P * DK) + dg;
-        for (int j = wave; j < Tmax; j += 16) {          // 4 keys of this slice per trip: all loads first
+        for (int j = wave; j < Tmax; j += 4 * NW) {      // 4 keys of this slice per trip: all loads first
             float4 v[4], pr[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int jj = j + 4 * u;
+                const int jj = j + NW * u;
                 v[u] = vbase[(size_t)min(jj, t_cap - 1) * (DK / 4)];
                 pr[u] = (jj < Tmax) ? *reinterpret_cast<const float4 *>(S + (size_t)jj * G + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (j + 4 * u < Tmax) {                   // a hidden key has p = 0 and adds +-0: the accumulator is unchanged
+                if (j + NW * u < Tmax) {                  // a hidden key has p = 0 and adds +-0: the accumulator is unchanged
                     const float pq[4] = {pr[u].x, pr[u].y, pr[u].z, pr[u].w};
 #pragma unroll
                     for (int qi = 0; qi < 4; qi++) {
@@ -986,11 +1000,15 @@ __global__ __launch_bounds__(256) void attn_tile_kernel(const AttnParams p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) {                         // wave w finishes queries w, w+4, w+8, w+12: 64 outputs each = two Q8 blocks
-        const int q = wave + 4 * r;
+    for (int r = 0; r < 2; r++) {                         // wave w finishes queries w and w + 8: 64 outputs each = two Q8 blocks
+        const int q = wave + NW * r;
         if (i0 + q < N) {
-            const double t0 = pvp[((size_t)0 * G + q) * DK + lane] + pvp[((size_t)1 * G + q) * DK + lane];
-            const double t1 = pvp[((size_t)2 * G + q) * DK + lane] + pvp[((size_t)3 * G + q) * DK + lane];
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < NW; s2 += 2) {
+                t0 += pvp[((size_t)s2 * G + q) * DK + lane];
+                t1 += pvp[((size_t)(s2 + 1) * G + q) * DK + lane];
+            }
             store_head_output(p, i0 + q, h, lane, (float)(t0 + t1), p.oq_q != nullptr);
         }
     }
