@@ -1604,16 +1604,20 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
     const size_t L = (size_t)ctx->hp.n_layer, P = (size_t)ctx->hp.n_positions, D = (size_t)ctx->hp.d_model, H = (size_t)ctx->hp.n_head;
     const size_t dk = D / H, total = L * P * D;
     if (offset + count > total) BG_FAIL(-1, "KV range out of bounds");
+    if (count == 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-    // the device cache is head-major [layer][head][pos][dk]; present the reference's flat
-    // [layer][pos][d_model] view (biogpt.cpp:331-335) to the caller
-    std::vector<float> dev(total);
-    HIP_TRY(-2, hipMemcpy(dev.data(), which ? ctx->memory_v : ctx->memory_k, total * 4, hipMemcpyDeviceToHost));
-    for (size_t e = offset; e < offset + count; e++) {
-        const size_t l = e / (P * D), pos = (e / D) % P, dm = e % D, h = dm / dk, dd = dm % dk;
-        out[e - offset] = dev[((l * H + h) * P + pos) * dk + dd];
-    }
+    // the device cache is head-major [layer][head][pos][dk]; the caller sees the reference's flat [layer][pos][d_model]
+    // view (biogpt.cpp:331-335).  Only the requested range is gathered on the device and copied.
+    float *stage = nullptr;
+    HIP_TRY(-2, hipMalloc(&stage, count * 4));
+    const float *cache = which ? ctx->memory_v : ctx->memory_k;
+    hipLaunchKernelGGL(bgk::kv_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, cache, stage, (unsigned long long)offset,
+                       (unsigned long long)count, (int)P, (int)D, (int)H, (int)dk);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, stage, count * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(stage);
+    HIP_TRY(-2, e);
     return 0;
 }
 

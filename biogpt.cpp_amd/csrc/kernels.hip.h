@@ -769,6 +769,16 @@ __host__ __device__ inline size_t attn_smem_bytes(int P, int dk, int nthreads) {
     return (((size_t)P * 4 + 15) & ~(size_t)15) + 16 * 8 + (size_t)nthreads * 8 + 64;
 }
 
+// flat reference view [layer][pos][d_model] of a range of the head-major cache [layer][head][pos][dk] (biogpt_hip_read_kv)
+__global__ __launch_bounds__(256) void kv_gather_kernel(const float *cache, float *out, unsigned long long offset, unsigned long long count,
+                                                        int P, int D, int H, int dk) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long e = offset + i;
+    const unsigned long long l = e / ((unsigned long long)P * D), pos = (e / D) % P, dm = e % D, h = dm / dk, dd = dm % dk;
+    out[i] = cache[((l * H + h) * P + pos) * dk + dd];
+}
+
 // ---- greedy sampler + token feedback (main.cpp:109-128 with top_k = 1) ----------------------------
 // Finishes the arg-max over the per-block partials of the lm_head kernel, appends the id to
 // gen_ids, makes it the next input token and advances n_past by n_eval (the tokens just evaluated).

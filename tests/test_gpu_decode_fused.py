@@ -1,6 +1,7 @@
-"""The fused single-token decode step (csrc/kernels_decode.hip.h: 3 launches per layer, sampler folded into the next
-step's first kernel) against (a) the oracle and (b) the unfused five-launch chain it replaces, at BioGPT-base widths;
-the full 24-layer BioGPT-base configuration (biogpt.h:25-35); and bench.py's RCCL replica path on one GPU."""
+"""The single-token decode step of csrc/kernels_decode.hip.h (five short-chain launches per layer, embedding and sampler
+folded into the first kernel of the next step) against (a) the oracle and (b) the first chain of kernels_fast.hip.h it
+replaces (BIOGPT_HIP_NO_FUSED_DECODE=1), at BioGPT-base widths; the full 24-layer BioGPT-base configuration
+(biogpt.h:25-35); device-side top-k; the C-ABI replicas; and bench.py's RCCL replica path on one GPU."""
 import json
 import os
 import subprocess
@@ -210,3 +211,28 @@ def test_device_top_k_equals_sorted_logits(pkg, files, k):
     with pytest.raises(pkg.BiogptError):
         g.eval_topk([2], 0, 65)
     g.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q8_0"])
+def test_opt_in_causal_mask(pkg, oracle, files, monkeypatch, name):
+    """BIOGPT_HIP_CAUSAL=1 (the opt-in fix of the reference's missing intra-chunk mask, F1): prompt chunks, a pass of several
+    chunks and single tokens against the oracle in causal mode."""
+    monkeypatch.setenv("BIOGPT_HIP_CAUSAL", "1")
+    g = pkg.BiogptModel.load(files[name])
+    monkeypatch.delenv("BIOGPT_HIP_CAUSAL")
+    o = oracle.OracleModel(files[name], n_threads=16)
+    o.set_mode("ggml", n_threads=16, causal=1)
+    rng = np.random.default_rng(41)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 30)]
+    worst, n_past = 0.0, 0
+    for n in (8, 5, 1, 1, 16):
+        lg, lo = g.eval(toks[n_past:n_past + n], n_past), o.eval(toks[n_past:n_past + n], n_past)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        assert int(lg.argmax()) == int(lo.argmax())
+        n_past += n
+    # and it is NOT the default behaviour: the same chunk without the mask differs
+    g2 = pkg.BiogptModel.load(files[name])
+    assert np.abs(g2.eval(toks[:8], 0) - o.eval(toks[:8], 0)).max() > 1e-4
+    print("%s causal: worst |diff| %.2e" % (name, worst))
+    assert worst <= ATOL
+    g.close(); g2.close()

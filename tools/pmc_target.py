@@ -1,9 +1,17 @@
-"""Small eager (no hipGraph) workload for rocprofv3 --pmc passes: the mat-vec kernels back to back."""
+"""Small workload for rocprofv3 --pmc passes: every kernel of the decode step back to back (graph replays of one sweep
+over the layers), plus the lm_head and -- with `prefill` as second argument -- one 512-column prompt pass."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import _pkg
 m = _pkg.load()
 g = m.BiogptModel.load(sys.argv[1])
-for which in (0, 1, 2, 3, 4):
-    s, b = g.bench_matvec(which, 0, 48)
-    print(which, round(s * 1e6, 2), "us", b, "bytes", flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "prefill":
+    rng = np.random.default_rng(7000)
+    toks = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 511)]
+    g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
+    g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
+else:
+    for which in (6, 7, 8, 9, 10, 4):
+        s, b = g.bench_matvec(which, 0, 48)
+        print(which, round(s * 1e6, 2), "us", b, "bytes", flush=True)
