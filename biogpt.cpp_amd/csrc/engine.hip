@@ -165,7 +165,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -190,6 +190,7 @@ struct EngineOptions {
         oproj_waves = get("BIOGPT_HIP_OPROJ_WAVES", 16);
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
         mfma_nt2_min = get("BIOGPT_HIP_MFMA_NT2_MIN", 64);
+        eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
 };
@@ -250,7 +251,9 @@ struct biogpt_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
-    hipGraphExec_t graph_eval[4] = {};     // single-token biogpt_hip_eval*: the five-launch decode step with the token taken from the state
+    hipGraphExec_t graph_eval[2][4][4] = {};   // [form][bucket][segment] single-token biogpt_hip_eval*: the decode step with the token taken
+                                               // from the state; form 0 = one graph, form 1 = a short first segment + the rest
+    int graph_eval_segs[2] = {0, 0};
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
     int32_t *mbox_host = nullptr;          // pinned ring of 64 x {n_past, causal, token}: inputs of the graph-replayed single-token evals
     uint32_t *mbox_ctr = nullptr;          // device: replays consumed
@@ -644,7 +647,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         }
         HIP_TRY(false, e);
     }
-    if (only >= 0) return true;
+    if (only >= 0 || l1 < hp.n_layer) return true;   // one kernel (bench) or a leading segment of the step: no lm_head
     {  // final LayerNorm + lm_head (last row only, F8) + per-workgroup arg-max partials; block 0 advances the position
         const MatSlot &m = c->plan.lm_head;
         const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
@@ -1024,7 +1027,7 @@ void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
-    for (auto &g : c->graph_eval) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &f : c->graph_eval) for (auto &row : f) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->mbox_host) (void)hipHostFree(c->mbox_host);
@@ -1191,7 +1194,7 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     ctx->opt.load();
     // captured graphs bake launch shapes chosen from the options
     for (auto &row : ctx->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    for (auto &g : ctx->graph_eval) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &f : ctx->graph_eval) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     ctx->graph_batch_n = 0;
     return 0;
@@ -1218,7 +1221,8 @@ int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes
     return 0;
 }
 
-int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) {
+// form 0: the step; form 1: the step + a last node that writes the logits row into pinned host memory (biogpt_hip_eval)
+static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int form) {
     clear_error();
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
@@ -1231,17 +1235,27 @@ int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
             HIP_TRY(-2, hipMalloc(&ctx->mbox_ctr, 16));
             HIP_TRY(-2, hipMemset(ctx->mbox_ctr, 0, 16));
         }
-        if (!ctx->graph_eval[b]) {
-            hipGraph_t g = nullptr;
+        if (!ctx->graph_eval[form][b][0]) {
+            const int L = ctx->hp.n_layer;
+            const int nseg = 1;
+            const int bounds[3] = {0, L, L};
+            const size_t V = (size_t)ctx->hp.n_vocab;
+            if (form == 1 && !ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), V * 4, hipHostMallocDefault));
             HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
-            const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0);
-            const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-            if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
-            HIP_TRY(-2, e);
-            HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[b], g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
+            for (int sgi = 0; sgi < nseg; sgi++) {
+                hipGraph_t g = nullptr;
+                HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                if (sgi == 0) hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
+                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1]);
+                if (ok && form == 1 && sgi == nseg - 1)
+                    hipLaunchKernelGGL(bgk::logits_to_host_kernel, dim3((unsigned)((V + 1023) / 1024)), dim3(256), 0, ctx->stream, ctx->logits, ctx->logits_host, (int)V);
+                const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+                if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
+                HIP_TRY(-2, e);
+                HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[form][b][sgi], g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+            }
+            ctx->graph_eval_segs[form] = nseg;
         }
         if (ctx->mbox_sent - ctx->mbox_synced >= 64) {   // never overwrite a slot a queued replay has not read yet
             HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
@@ -1250,13 +1264,15 @@ int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
         int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
         slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
         ctx->mbox_sent++;
-        HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[b], ctx->stream));
+        for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[form][b][sgi], ctx->stream));
         return 0;
     }
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
     if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
     return 0;
 }
+
+int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) { return eval_device_impl(ctx, tokens, n, n_past, 0); }
 
 int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int32_t k, float *vals_out, int32_t *ids_out) {
     if (!vals_out || !ids_out) BG_FAIL(-1, "null output buffer");
@@ -1303,7 +1319,7 @@ int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, 
 int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_predict, int32_t mode, int32_t *out_ids,
                               double *seconds_out) {
     clear_error();
-    if (!ctx || !prompt || n_prompt < 1 || n_predict < 1 || (mode != 0 && mode != 1)) BG_FAIL(-1, "bad argument");
+    if (!ctx || !prompt || n_prompt < 1 || n_predict < 1 || mode < 0 || mode > 2) BG_FAIL(-1, "bad argument");
     if (!check_eval_args(ctx, prompt, n_prompt, 0)) return -1;
     n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);
     const size_t V = (size_t)ctx->hp.n_vocab;
@@ -1318,9 +1334,14 @@ int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_
         if (mode == 0) {
             if (biogpt_hip_eval(ctx, in, n_in, n_past, logits.data()) != 0) return -2;
             tok = (int32_t)(std::max_element(logits.begin(), logits.end()) - logits.begin());
-        } else {
+        } else if (mode == 1) {
             if (biogpt_hip_eval_topk(ctx, in, n_in, n_past, 40, logits.data(), ids) < 0) return -2;
             tok = ids[0];
+        } else {   // mode 2 (diagnostic): the eval and a stream synchronise only -- no output leaves the device; token fixed
+            if (biogpt_hip_eval_device(ctx, in, n_in, n_past) != 0) return -2;
+            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+            ctx->mbox_synced = ctx->mbox_sent;
+            tok = 2;
         }
         n_past += n_in;
         if (out_ids) out_ids[k] = tok;
@@ -1339,13 +1360,20 @@ int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
 
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
     if (!logits_out) BG_FAIL(-1, "null logits buffer");
-    const int rc = biogpt_hip_eval_device(ctx, tokens, n, n_past);
+    const int rc = eval_device_impl(ctx, tokens, n, n_past, 1);
     if (rc) return rc;
-    // device -> pinned staging -> caller's (pageable) buffer: one DMA instead of the runtime's chunked staging
     const size_t bytes = (size_t)ctx->hp.n_vocab * 4;
-    if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), bytes, hipHostMallocDefault));
-    HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    const bool in_graph = n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, n_past + 1);   // the replayed graph already wrote the pinned row
+    if (!in_graph) {   // device -> pinned staging -> caller's (pageable) buffer: one DMA instead of the runtime's chunked staging
+        if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), bytes, hipHostMallocDefault));
+        HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (;;) {   // poll: the caller is blocked on this token anyway
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(-2, q);
+    }
+    ctx->mbox_synced = ctx->mbox_sent;
     std::memcpy(logits_out, ctx->logits_host, bytes);
     return 0;
 }

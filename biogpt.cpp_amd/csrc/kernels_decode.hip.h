@@ -626,8 +626,8 @@ __global__ __launch_bounds__(NW * 64) void dec_fc2_kernel(const DecFc2Params p) 
 
 // ---- device-side top-k of the logits row (the sampler needs k <= 64 candidates, not 170 KB over PCIe) ----
 // Exact selection of the k largest logits, best first (equal logits: lower id first), one 1024-thread workgroup:
-//   1. the k-th largest of the lm_head kernel's per-workgroup maxima is a lower bound T0 of the k-th largest logit (k
-//      workgroups each hold a logit >= it), so every member of the top k is >= T0;
+//   1. the lm_head kernel left one maximum per workgroup; the k-th largest of (groups of 8 of) them is a lower bound T0 of the
+//      k-th largest logit (k workgroups each hold a logit >= it), so every member of the top k is >= T0;
 //   2. one sweep over the row collects the logits >= T0 (a few dozen) in LDS;
 //   3. every candidate counts the candidates that beat it: its rank; ranks < k are the answer, already ordered.
 // out_n[0] = k, or -1 if more than TOPK_CAP logits reach T0 (degenerate rows: the caller falls back to the full row).
@@ -635,37 +635,49 @@ __global__ __launch_bounds__(NW * 64) void dec_fc2_kernel(const DecFc2Params p) 
 constexpr int TOPK_CAP = 4096;
 __global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, int k, const float *pmax_val, int nparts, float *out_val,
                                                     int32_t *out_idx, int32_t *out_n) {
-    __shared__ float s_pm[1024];
+    __shared__ float s_gm[128];
     __shared__ float s_cv[TOPK_CAP];
     __shared__ int s_ci[TOPK_CAP];
     __shared__ float s_t0;
     __shared__ int s_n;
     const int tid = threadIdx.x;
     if (tid == 0) { s_t0 = -INFINITY; s_n = 0; }
+    // 1. threshold: the partial maxima in 128 groups of 8; the k-th largest GROUP maximum is still the maximum of some
+    //    workgroup, so at least k logits reach it -- a lower bound of the k-th largest logit, found with 128 x 128 compares
     const int np = min(nparts, 1024);
-    const float mine = (tid < np) ? pmax_val[tid] : -INFINITY;
-    s_pm[tid] = mine;
+    float gm = (tid < np) ? pmax_val[tid] : -INFINITY;
+    gm = group8_max(gm);
+    if ((tid & 7) == 0) s_gm[tid >> 3] = gm;
     __syncthreads();
-    if (k <= np && tid < np) {                      // rank of this partial maximum among the partials (ties: by index)
+    const int ngroups = (np + 7) >> 3;
+    if (k <= ngroups && nparts <= 1024 && tid < 128) {
+        const float mine = s_gm[tid];
         int beat = 0;
-        for (int j = 0; j < np; j++) {
-            const float o = s_pm[j];
+        for (int j = 0; j < 128; j++) {
+            const float o = s_gm[j];
             beat += (o > mine || (o == mine && j < tid)) ? 1 : 0;
         }
         if (beat == k - 1) s_t0 = mine;
     }
     __syncthreads();
-    const float t0 = (nparts <= 1024) ? s_t0 : -INFINITY;
-    for (int i = tid; i < V; i += 1024) {
-        const float x = logits[i];
-        if (x >= t0) {
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot < TOPK_CAP) { s_cv[slot] = x; s_ci[slot] = i; }
+    const float t0 = s_t0;
+    // 2. one sweep over the row, 8 loads in flight per thread
+    for (int i0 = tid; i0 < V; i0 += 8 * 1024) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = (i0 + 1024 * u < V) ? logits[i0 + 1024 * u] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i0 + 1024 * u < V && x[u] >= t0) {
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < TOPK_CAP) { s_cv[slot] = x[u]; s_ci[slot] = i0 + 1024 * u; }
+            }
         }
     }
     __syncthreads();
     const int n = s_n;
     if (n > TOPK_CAP || n < k) { if (tid == 0) out_n[0] = -1; return; }   // n < k only if the row holds NaNs
+    // 3. rank of every candidate among the candidates (equal logits: lower id first); ranks < k are the answer, in order
     for (int c = tid; c < n; c += 1024) {
         const float x = s_cv[c];
         const int ix = s_ci[c];
@@ -677,6 +689,14 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, 
         if (beat < k) { out_val[beat] = x; out_idx[beat] = ix; }
     }
     if (tid == 0) out_n[0] = k;
+}
+
+// biogpt_hip_eval's logits row: written by the device straight into pinned host memory as the last node of the replayed
+// graph (a device-to-host copy command behind the graph costs 60-120 us of extra latency per token on this runtime)
+__global__ __launch_bounds__(256) void logits_to_host_kernel(const float *src, float *dst_pinned, int n) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<float4 *>(dst_pinned + i) = *reinterpret_cast<const float4 *>(src + i);
+    else for (int j = i; j < n; j++) dst_pinned[j] = src[j];
 }
 
 // Single-token evals through the C API: the host drops {n_past, causal, token} into a ring of pinned slots and replays the
