@@ -251,7 +251,7 @@ struct biogpt_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
-    hipGraphExec_t graph_eval[2][4][4] = {};   // [form][bucket][segment] single-token biogpt_hip_eval*: the decode step with the token taken
+    hipGraphExec_t graph_eval[2][6][4] = {};   // [form][bucket][segment] single-token biogpt_hip_eval*: the decode step with the token taken
                                                // from the state; form 0 = one graph, form 1 = a short first segment + the rest
     int graph_eval_segs[2] = {0, 0};
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
@@ -548,7 +548,7 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
 // advance: the lm_head kernel moves the device-side position on by one when the step is done.
 bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max) {
     const auto &hp = c->hp;
-    return is_quantized(ftype_to_type(hp.ftype)) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 && t_max <= 256 &&
+    return is_quantized(ftype_to_type(hp.ftype)) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 && t_max <= 1024 &&
            hp.n_positions >= 64 && !c->opt.no_fast && !c->opt.no_chain && !c->opt.no_fused_decode;
 }
 
@@ -558,7 +558,19 @@ hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, co
                                const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2, int only = -1) {
     hipStream_t st = c->stream;
     if (only < 0 || only == 0) hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
-    if (only < 0 || only == 1) {
+    if ((only < 0 || only == 1) && at.t_cap > 256) {
+        // beyond 256 keys one workgroup per head would pull up to 512 KB of K / V through one compute unit: the keys of a head
+        // are spread over H x T/64 workgroups in three dependent launches (attn_split_*_kernel, kernels_fast.hip.h)
+        bgk::AttnParams sa{};
+        sa.q = at.q; sa.kcache = at.kcache; sa.vcache = at.vcache; sa.out = c->att; sa.st = at.st; sa.exp_tab = at.exp_tab;
+        sa.N = 1; sa.D = c->hp.d_model; sa.dk = 64; sa.P = at.P; sa.t_cap = at.t_cap;
+        sa.oq_q = at.oq_q; sa.oq_d = at.oq_d; sa.oq_s = at.oq_s; sa.q81 = at.q81;
+        sa.sp_scores = c->sp_scores; sa.sp_max = c->sp_max; sa.sp_pv = c->sp_pv;
+        sa.n_split = (sa.t_cap + bgk::SPLIT_KEYS - 1) / bgk::SPLIT_KEYS;
+        hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(16, sa.n_split), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(16, sa.n_split), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(16), dim3(64), 0, st, sa);
+    } else if (only < 0 || only == 1) {
         if (at.t_cap <= 64) hipLaunchKernelGGL(bgk::dec_attn_kernel<16>, dim3(16), dim3(1024), 0, st, at);
         else if (at.t_cap <= 128) hipLaunchKernelGGL(bgk::dec_attn_kernel<8>, dim3(16), dim3(1024), 0, st, at);
         else hipLaunchKernelGGL(bgk::dec_attn_kernel<4>, dim3(16), dim3(1024), 0, st, at);

@@ -316,7 +316,9 @@ struct DecAttnParams {
     int32_t wall_slot;
 };
 
-// grid = 16 heads, 1024 threads.  Scores: LPK lanes per key (16 / 8 / 4 for contexts up to 64 / 128 / 256 keys), every
+// grid = 16 heads, 1024 threads.  Scores: LPK lanes per key (16 / 8 / 4 for contexts up to 64 / 128 / 256 keys; 2 lanes per key
+// for 512 keys was measured: 256 KB of K / V through one compute unit, 633-649 us per token against 599 with the key-split
+// launches of kernels_fast.hip.h), every
 // lane 64 / LPK dims, double partial sums reduced with DPP inside the key's lane group -- all 1024 threads work whatever
 // the context.  PV: 16 key slices x 64 dims.  The query row goes through LDS once (16 lanes load it) instead of being
 // fetched by every quad (1024 x 64 B through one texture addresser).
