@@ -165,7 +165,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -186,8 +186,11 @@ struct EngineOptions {
         causal = get("BIOGPT_HIP_CAUSAL", 0);
         no_fused_decode = get("BIOGPT_HIP_NO_FUSED_DECODE", 0);
         fc1_blocks = get("BIOGPT_HIP_FC1_BLOCKS", 1);
-        fc2_waves = get("BIOGPT_HIP_FC2_WAVES", 16);
-        oproj_waves = get("BIOGPT_HIP_OPROJ_WAVES", 16);
+        fc2_waves = get("BIOGPT_HIP_FC2_WAVES", 8);      // same-process sweeps (profiles/decode_shapes_r2.txt): 8 waves beat 16 and 4
+        oproj_waves = get("BIOGPT_HIP_OPROJ_WAVES", 8);
+        qkv_waves = get("BIOGPT_HIP_QKV_WAVES", 8);
+        fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
+        attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
         mfma_nt2_min = get("BIOGPT_HIP_MFMA_NT2_MIN", 64);
         eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
@@ -557,7 +560,11 @@ template <int WT>
 hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, const bgk::DecAttnParams &at, const bgk::DecOprojParams &op,
                                const bgk::DecFc1Params &f1, const bgk::DecFc2Params &f2, int only = -1) {
     hipStream_t st = c->stream;
-    if (only < 0 || only == 0) hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
+    if (only < 0 || only == 0) {
+        if (c->opt.qkv_waves == 8) hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT, 8>), dim3(192), dim3(512), bgk::dec_qkv_smem_bytes(), st, a);
+        else if (c->opt.qkv_waves == 4) hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT, 4>), dim3(384), dim3(256), bgk::dec_qkv_smem_bytes(), st, a);
+        else hipLaunchKernelGGL((bgk::dec_qkv_kernel<WT, 16>), dim3(96), dim3(1024), bgk::dec_qkv_smem_bytes(), st, a);
+    }
     if ((only < 0 || only == 1) && at.t_cap > 256) {
         // beyond 256 keys one workgroup per head would pull up to 512 KB of K / V through one compute unit: the keys of a head
         // are spread over H x T/64 workgroups in three dependent launches (attn_split_*_kernel, kernels_fast.hip.h)
@@ -571,9 +578,11 @@ hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, co
         hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(16, sa.n_split), dim3(256), 0, st, sa);
         hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(16), dim3(64), 0, st, sa);
     } else if (only < 0 || only == 1) {
-        if (at.t_cap <= 64) hipLaunchKernelGGL(bgk::dec_attn_kernel<16>, dim3(16), dim3(1024), 0, st, at);
-        else if (at.t_cap <= 128) hipLaunchKernelGGL(bgk::dec_attn_kernel<8>, dim3(16), dim3(1024), 0, st, at);
-        else hipLaunchKernelGGL(bgk::dec_attn_kernel<4>, dim3(16), dim3(1024), 0, st, at);
+        if (c->opt.attn_waves == 8 && at.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_attn_kernel<8, 8>), dim3(16), dim3(512), 0, st, at);
+        else if (c->opt.attn_waves == 8 && at.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_attn_kernel<4, 8>), dim3(16), dim3(512), 0, st, at);
+        else if (at.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_attn_kernel<16, 16>), dim3(16), dim3(1024), 0, st, at);
+        else if (at.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_attn_kernel<8, 16>), dim3(16), dim3(1024), 0, st, at);
+        else hipLaunchKernelGGL((bgk::dec_attn_kernel<4, 16>), dim3(16), dim3(1024), 0, st, at);
     }
     if (only < 0 || only == 2) {
         if (c->opt.oproj_waves == 4) hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 4>), dim3(128), dim3(256), bgk::dec_oproj_smem_bytes(4), st, op);
@@ -581,8 +590,10 @@ hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, co
         else hipLaunchKernelGGL((bgk::dec_oproj_kernel<WT, 16>), dim3(32), dim3(1024), bgk::dec_oproj_smem_bytes(16), st, op);
     }
     if (only < 0 || only == 3) {
-        if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
-        else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
+        if (c->opt.fc1_blocks == 2) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 2, 16>), dim3(64), dim3(1024), bgk::dec_fc1_smem_bytes<2>(), st, f1);
+        else if (c->opt.fc1_waves == 8) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1, 8>), dim3(128), dim3(512), bgk::dec_fc1_smem_bytes<1>(), st, f1);
+        else if (c->opt.fc1_waves == 4) hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1, 4>), dim3(128), dim3(256), bgk::dec_fc1_smem_bytes<1>(), st, f1);
+        else hipLaunchKernelGGL((bgk::dec_fc1_kernel<WT, 1, 16>), dim3(128), dim3(1024), bgk::dec_fc1_smem_bytes<1>(), st, f1);
     }
     if (only < 0 || only == 4) {
         if (c->opt.fc2_waves == 4) hipLaunchKernelGGL((bgk::dec_fc2_kernel<WT, 4>), dim3(256), dim3(256), bgk::dec_fc2_smem_bytes(4), st, f2);
@@ -1886,7 +1897,7 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
         const int nk = 5 * ctx->hp.n_layer;
         std::vector<unsigned long long> w((size_t)nk * 2048);
         HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp + 128, w.size() * 8, hipMemcpyDeviceToHost));
-        const int grids[5] = {96, 16, ctx->opt.oproj_waves == 4 ? 128 : ctx->opt.oproj_waves == 8 ? 64 : 32, ctx->opt.fc1_blocks == 2 ? 64 : 128,
+        const int grids[5] = {ctx->opt.qkv_waves == 8 ? 192 : ctx->opt.qkv_waves == 4 ? 384 : 96, 16, ctx->opt.oproj_waves == 4 ? 128 : ctx->opt.oproj_waves == 8 ? 64 : 32, ctx->opt.fc1_blocks == 2 ? 64 : 128,
                               ctx->opt.fc2_waves == 4 ? 256 : ctx->opt.fc2_waves == 8 ? 128 : 64};
         const char *kn[5] = {"dec_qkv  ", "dec_attn ", "dec_oproj", "dec_fc1  ", "dec_fc2  "};
         double acc[5][5] = {};

@@ -194,9 +194,10 @@ struct DecQkvParams {
 constexpr int DEC_PS = 36;     // floats between two rows of block terms in LDS (32 + 4: float4 aligned, skewed)
 __host__ __device__ inline size_t dec_qkv_smem_bytes() { return 1536 + 128 + 128 + (size_t)16 * 2 * DEC_PS * 4; }
 
-// grid = 3072 / 32 = 96 workgroups of 1024 threads: wave w owns rows 32*b + 2*w, +1 (lane = block of the row)
-template <int WT>
-__global__ __launch_bounds__(1024) void dec_qkv_kernel(const DecQkvParams p) {
+// NW waves per workgroup (>= 4: the LayerNorm workers), 2 rows per wave: grid = 3072 / (2 NW); wave w owns rows 2 NW b + 2 w, +1
+template <int WT, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_qkv_kernel(const DecQkvParams p) {
+    static_assert(NW >= 4 && NW <= 16, "waves per workgroup");
     using TI = TypeInfo<WT>;
     constexpr int D = 1024, DK = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -221,10 +222,10 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const DecQkvParams p) {
         lnw = reinterpret_cast<const float4 *>(p.ln_w)[tid];
         lnb = reinterpret_cast<const float4 *>(p.ln_b)[tid];
     }
-    const int row = blockIdx.x * 32 + wave * 2 + rsub;                    // row of the stacked [q; k; v] matrix
+    const int row = blockIdx.x * 2 * NW + wave * 2 + rsub;                // row of the stacked [q; k; v] matrix
     Unit<WT> wq;
     load_unit<WT>(wq, p.Wqkv, (int64_t)row * 32 + sub);
-    const int frow = blockIdx.x * 32 + wave * 2 + (lane & 1);             // finisher lanes 0, 1
+    const int frow = blockIdx.x * 2 * NW + wave * 2 + (lane & 1);         // finisher lanes 0, 1
     float e_bias = 0.0f;
     if (lane < 2) e_bias = p.bqkv[frow];
     if (p.tok_src != 0) {
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const DecQkvParams p) {
             // kernel's per-workgroup partials (lowest id wins ties); workgroup 0 records it
             float bv = -INFINITY;
             int bi = 0x7fffffff;
-            for (int k = tid; k < p.nparts; k += 1024) {
+            for (int k = tid; k < p.nparts; k += NW * 64) {
                 const float v = p.pmax_val[k];
                 const int ix = p.pmax_idx[k];
                 if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const DecQkvParams p) {
             __syncthreads();
             bv = s_amv[0]; bi = s_ami[0];
 #pragma unroll
-            for (int w = 1; w < 16; w++)
+            for (int w = 1; w < NW; w++)
                 if (s_amv[w] > bv || (s_amv[w] == bv && s_ami[w] < bi)) { bv = s_amv[w]; bi = s_ami[w]; }
             tok = bi;
             if (tok < 0 || tok >= p.n_vocab) tok = 0;      // partials never written (first replay of a fresh context)
@@ -316,21 +317,21 @@ struct DecAttnParams {
     int32_t wall_slot;
 };
 
-// grid = 16 heads, 1024 threads.  Scores: LPK lanes per key (16 / 8 / 4 for contexts up to 64 / 128 / 256 keys; 2 lanes per key
+// grid = 16 heads, NW waves.  Scores: LPK lanes per key (16 / 8 / 4 for contexts up to 64 / 128 / 256 keys; 2 lanes per key
 // for 512 keys was measured: 256 KB of K / V through one compute unit, 633-649 us per token against 599 with the key-split
 // launches of kernels_fast.hip.h), every
 // lane 64 / LPK dims, double partial sums reduced with DPP inside the key's lane group -- all 1024 threads work whatever
 // the context.  PV: 16 key slices x 64 dims.  The query row goes through LDS once (16 lanes load it) instead of being
 // fetched by every quad (1024 x 64 B through one texture addresser).
-template <int LPK>
-__global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
+template <int LPK, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const DecAttnParams p) {
     constexpr int DK = 64, NF4 = 16 / LPK;          // float4 per lane of a key row
     static_assert(LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     __shared__ __attribute__((aligned(16))) float s_q[DK];
-    __shared__ float s_S[1024 / LPK];
-    __shared__ float s_redf[16];
-    __shared__ double s_redd[16];
-    __shared__ double s_pv[1024];
+    __shared__ float s_S[NW * 64 / LPK];          // contexts up to NW * 64 / LPK keys
+    __shared__ float s_redf[NW];
+    __shared__ double s_redd[NW];
+    __shared__ double s_pv[NW * 64];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksub = tid & (LPK - 1), kidx = tid / LPK;
     const int dd = tid & (DK - 1), sl = tid >> 6;
@@ -346,13 +347,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
 #pragma unroll
         for (int m = 0; m < NF4; m++) kr[m] = kbase[LPK * m];       // float4 #(LPK*m + ksub): one load of a lane group covers 16*LPK contiguous bytes
     }
-    constexpr int NV = 64 / LPK;                     // keys per slice: t_cap <= 16 * NV
+    constexpr int NV = 64 / LPK;                     // keys per slice: t_cap <= NW * NV
     float vr[NV];
     {
         const float *vbase = p.vcache + (size_t)h * p.P * DK + dd;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            const int j = sl + 16 * k;
+            const int j = sl + NW * k;
             if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
         }
     }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
     __syncthreads();
     mx = s_redf[0];
 #pragma unroll
-    for (int w = 1; w < 16; w++) mx = fmaxf(mx, s_redf[w]);
+    for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
     DEC_STAMP(2);
     double sum = 0.0;
     if (kidx < T && ksub == 0) {
@@ -394,14 +395,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
     __syncthreads();
     sum = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) sum += s_redd[w];
+    for (int w = 0; w < NW; w++) sum += s_redd[w];
     const float inv = inv_sum_f32(sum);
     DEC_STAMP(3);
     {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int k = 0; k < NV; k += 2) {
-            const int j0 = sl + 16 * k, j1 = j0 + 16;
+            const int j0 = sl + NW * k, j1 = j0 + NW;
             if (j0 < T) a0 += (double)__fmul_rn(vr[k], __fmul_rn(s_S[j0], inv));
             if (j1 < T) a1 += (double)__fmul_rn(vr[k + 1], __fmul_rn(s_S[j1], inv));
         }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const DecAttnParams p) {
     if (tid < DK) {
         double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-        for (int s2 = 0; s2 < 16; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
+        for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
         const float o = (float)(t0 + t1);
         if (p.att_out) p.att_out[h * DK + tid] = o;
         int8_t q8; float d8; uint32_t s8;
@@ -487,13 +488,15 @@ struct DecFc1Params {
     int32_t wall_slot;
 };
 
-template <int NB> __host__ __device__ inline size_t dec_fc1_smem_bytes() { return 1536 + 256 + (size_t)16 * 2 * NB * DEC_PS * 4; }
+template <int NB> __host__ __device__ inline size_t dec_fc1_smem_bytes() { return 1536 + 256 + (size_t)32 * NB * DEC_PS * 4; }
 
-// NB = Q8 output blocks (of 32 rows) per workgroup: grid = 4096 / (32 * NB)
-template <int WT, int NB>
-__global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
+// NB = Q8 output blocks (of 32 rows) per workgroup: grid = 4096 / (32 * NB); NW waves, each 2 rows per step, 16 NB / NW steps
+template <int WT, int NB, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_fc1_kernel(const DecFc1Params p) {
     using TI = TypeInfo<WT>;
     static_assert(NB == 1 || NB == 2, "one wave quantizes the workgroup's output blocks");
+    static_assert(NW >= 4 && (16 * NB) % NW == 0, "waves per workgroup");
+    constexpr int STEPS = 16 * NB / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem);
     float *const s_xd = reinterpret_cast<float *>(smem + 1024);
@@ -513,11 +516,11 @@ __global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
         lnw = reinterpret_cast<const float4 *>(p.ln_w)[tid];
         lnb = reinterpret_cast<const float4 *>(p.ln_b)[tid];
     }
-    Unit<WT> wq[NB];
+    Unit<WT> wq[STEPS];
 #pragma unroll
-    for (int s = 0; s < NB; s++) load_unit<WT>(wq[s], p.W1, (int64_t)(row0 + s * 32 + wave * 2 + rsub) * 32 + sub);
+    for (int s = 0; s < STEPS; s++) load_unit<WT>(wq[s], p.W1, (int64_t)(row0 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
     float e_bias = 0.0f;
-    if (lane < 2 * NB) e_bias = p.b1[row0 + (lane >> 1) * 32 + wave * 2 + (lane & 1)];
+    if (lane < 2 * STEPS) e_bias = p.b1[row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1)];
     DEC_STAMP(1);
 
     if (TI::q81) ln4_q8_1024<true>(x1, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs, p.tstamp);
@@ -530,16 +533,16 @@ __global__ __launch_bounds__(1024) void dec_fc1_kernel(const DecFc1Params p) {
         ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
         const float axd = s_xd[sub];
         const uint32_t axs = s_xs[sub];
-        float *const part = s_part + wave * 2 * NB * DEC_PS;
+        float *const part = s_part + wave * 2 * STEPS * DEC_PS;
 #pragma unroll
-        for (int s = 0; s < NB; s++)
+        for (int s = 0; s < STEPS; s++)
             part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wq[s], ax, axd, __uint_as_float(axs), (int)axs);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 2 * NB) {
+        if (lane < 2 * STEPS) {
             const float v = __fadd_rn(e_bias, sum32_in_order(part + lane * DEC_PS));
-            s_g[(lane >> 1) * 32 + wave * 2 + (lane & 1)] = h2f(p.gelu_tab[f2h(v)]);   // ggml_gelu: fp16 table
+            s_g[(lane >> 1) * 2 * NW + wave * 2 + (lane & 1)] = h2f(p.gelu_tab[f2h(v)]);   // ggml_gelu: fp16 table
         }
     }
     __syncthreads();
