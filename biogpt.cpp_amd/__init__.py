@@ -68,6 +68,7 @@ SYMBOLS = [
     ("biogpt_hip_arena_bytes", C.c_size_t, [_P]),
     ("biogpt_hip_free", None, [_P]),
     ("biogpt_hip_refresh_options", C.c_int, [_P]),
+    ("biogpt_hip_xpipe_state", C.c_int, [_P]),
     ("biogpt_hip_share_vocab", C.c_int, [_P, _P]),
     ("biogpt_hip_replicas_load", _P, [C.c_char_p, _P, C.c_int, C.c_int]),
     ("biogpt_hip_replicas_count", C.c_int, [_P]),
@@ -381,6 +382,11 @@ class BiogptModel:
         if got < 0:
             raise BiogptError(_err())
         return out[:got], secs.value
+
+    def xpipe_state(self):
+        """1: single-token decode steps of this context run as the XCD-pipelined persistent launch; 0: off / path held by
+        another context of the device; -1: unavailable or abandoned after a disturbed launch."""
+        return int(lib().biogpt_hip_xpipe_state(self._h))
 
     def refresh_options(self):
         """Re-read the BIOGPT_HIP_* switches (they are cached at load time) and drop the captured graphs."""

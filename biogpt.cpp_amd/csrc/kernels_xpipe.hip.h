@@ -1,0 +1,598 @@
+// Single-token decode step as ONE launch, pipelined over the MI355X's 8 XCDs (accelerator dies: 32 compute units and one
+// 4 MB L2 each).  biogpt.cpp:664-795 for all layers; the arithmetic per element is that of kernels_decode.hip.h.
+//
+// Why: the five-launch layer of kernels_decode.hip.h spends 7.5 of its 20 us in launch boundaries (1.3-1.6 us each:
+// every boundary is a device-wide all-to-all), and each kernel then starts cold (0.7-1.5 us until its first weights
+// arrive).  What a layer needs between its five stages is an all-to-all among the workgroups THAT COMPUTE THE LAYER --
+// and on this chip 32 compute units behind one L2 can do that in ~1 us with tagged 8-byte granules
+// (tools/microbench11.hip: all six hand-offs of a layer, model-sized, 6.9 us per layer end to end).
+//
+// Shape: grid = 256 workgroups x 1024 threads, one per compute unit; workgroup b runs on XCD b % 8 (checked against
+// HW_REG_XCC_ID in every launch, rank inside the XCD from a ticket; the host probes the device once).  Layer l is computed
+// by the 32 workgroups of XCD l % 8.  While the other XCDs compute their layers, an XCD loads the weights of ITS next
+// layer into registers (7.08 MB of Q4_0 per layer = 221 KB per compute unit = 12 block units per lane, 60 VGPRs), so a
+// layer's stages never wait for weights: stage latency = hand-off + arithmetic.
+//
+//   stage A  x (granules from the previous layer's XCD, or the embedding) -> LayerNorm -> Q8 -> 96 q/k/v rows per
+//            workgroup; KV append; workgroups 16-31 hand their rows (second half of K, V of head slot - 16) to 0-15
+//   stage B  workgroups 0-15: attention of head `slot` (old keys from the cache, the new key/value from stage A)
+//   stage C  out_proj rows (32 per workgroup) + bias + residual
+//   stage D  LayerNorm -> Q8 -> fc1 rows (128 per workgroup = 4 Q8 blocks) -> GELU table -> Q8
+//   stage E  fc2 rows (32 per workgroup) + bias + residual -> x for the next layer's XCD
+//
+// Hand-offs: "R2" granules of MI355X_MICROARCH.md -- one naturally aligned 8-byte {value, tag} written by ONE relaxed
+// agent-scope atomic store and polled with relaxed agent-scope atomic loads; tag = the context's launch counter
+// (ctl[0], bumped by the last layer's first workgroup once every workgroup has provably read it), buffers are per
+// layer, so a tag can only match data of THIS launch.  No fences, no flags.  EVERY spin is bounded: after XP_SPIN_MAX
+// passes a poller raises ctl[1] (and the pinned host word), every other poller sees it within 1024 passes, the launch
+// drains in milliseconds with garbage outputs, and the host reports the failure and leaves this path for good.
+#pragma once
+
+#include "kernels_decode.hip.h"
+
+namespace bgk {
+
+typedef unsigned long long xp_u64;
+#define XP_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr uint32_t XP_SPIN_MAX = 400000u;      // ~0.3 s of polling: far beyond any kernel another stream could hold the compute units with
+
+struct XpLayer {               // one layer's constants (device memory, read with scalar loads)
+    const float *ln0_w, *ln0_b, *ln1_w, *ln1_b;
+    const float *bqkv, *bo, *b1, *b2;
+    DevMatrix Wqkv, Wo, W1, W2;
+    float *kcache, *vcache;    // layer slice, head-major [H][P][64]
+};
+
+// granules of one layer
+constexpr int XP_G_QKV = 0;                    // [3072] stacked q (scaled) / k / v rows; only the rows of workgroups 16-31 are published
+constexpr int XP_G_ATT = 3072;                 // [256] 4 x int8, [32] block scale, [32] block sum
+constexpr int XP_G_X1 = XP_G_ATT + 320;        // [1024]
+constexpr int XP_G_H = XP_G_X1 + 1024;         // [1024] 4 x int8, [128] scale, [128] sum
+constexpr int XP_G_X = XP_G_H + 1280;          // [1024] the layer's OUTPUT
+constexpr int XP_G_LAYER = XP_G_X + 1024;
+
+struct XpParams {
+    const XpLayer *layers;
+    int32_t n_layer;
+    xp_u64 *gran;              // [n_layer][XP_G_LAYER], zeroed once at allocation
+    uint32_t *ctl;             // [0] launch counter (starts at 1), [1] error word, [8..15] per-XCD arrival tickets
+    uint32_t *err_host;        // pinned mirror of the error word
+    DevState *st;
+    DevMatrix tok_emb, pos_emb;
+    float embed_scale;
+    int32_t tok_src;           // 1: token in the state; 2: arg-max of the previous step's lm_head partials
+    const float *pmax_val; const int32_t *pmax_idx; int32_t nparts;
+    int32_t n_positions, n_vocab;
+    float eps, q_scale;
+    int32_t P, t_cap;
+    const uint16_t *exp_tab, *gelu_tab;
+    float *x_final;            // [1024] input of the final LayerNorm + lm_head launch
+    unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
+};
+
+#ifdef BIOGPT_HIP_PROFILE_HOOKS
+#define XP_WALL(k) do { if (p.wall && tid == 0) { const unsigned long long t_ = wall_clock64(); if ((slot & 15) == 0) p.wall[L * 16 + (k)] = t_; \
+        if (L == p.n_layer - 1) p.wall[(p.n_layer + slot) * 16 + (k)] = t_; } } while (0)
+#else
+#define XP_WALL(k) do {} while (0)
+#endif
+
+// to ANOTHER XCD (the layer output): write-through (sc1) store, visible at the memory side
+__device__ __forceinline__ void xp_put(xp_u64 *g, uint32_t epoch, uint32_t v) { __hip_atomic_store(g, ((xp_u64)epoch << 32) | v, XP_RLX); }
+// inside the XCD (every other hand-off): a plain 8-byte store keeps the line in the XCD's L2, where the pollers' sc1 loads
+// (L1 bypassed, L2 served) find it -- tools/microbench11.hip: 4.7 us per layer for the six hand-offs against 7.0 with
+// write-through stores, which drop the line and send every poll of 32 workgroups across the fabric.  Valid only because
+// producer and consumers share ONE L2: that is what the XCC_ID check at the top of the kernel establishes.
+__device__ __forceinline__ void xp_put_local(xp_u64 *g, uint32_t epoch, uint32_t v) {
+    __hip_atomic_store(g, ((xp_u64)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// x / x1 columns are stored so that LayerNorm worker t (elements 4t .. 4t+3) polls granules t, t + 256, t + 512, t + 768:
+// every poll instruction of a wave covers 512 contiguous bytes
+__device__ __forceinline__ int xp_col_slot(int row) { return (row & 3) * 256 + (row >> 2); }
+
+__device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
+    __hip_atomic_store(p.ctl + 1, code, XP_RLX);
+    __hip_atomic_store(p.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
+template <int N, int S = 1>
+__device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p) {
+    for (uint32_t spins = 0;; spins++) {
+        bool ok = true;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                v[k] = (uint32_t)a;
+                ok &= (uint32_t)(a >> 32) == epoch;
+            }
+        }
+        if (__all(ok)) return;
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
+        if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// a lane's 4 x int8 and the three lanes above it packed into one word (valid in lanes with lane % 4 == 0)
+__device__ __forceinline__ uint32_t xp_pack4(int8_t q) {
+    const int b = (int)(uint8_t)q;
+    const int b1 = __builtin_amdgcn_update_dpp(0, b, 0x101, 0xf, 0xf, true);   // row_shl:1
+    const int b2 = __builtin_amdgcn_update_dpp(0, b, 0x102, 0xf, 0xf, true);
+    const int b3 = __builtin_amdgcn_update_dpp(0, b, 0x103, 0xf, 0xf, true);
+    return (uint32_t)b | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
+}
+
+// LDS carve (bytes)
+constexpr int XP_S_X = 0;                        // [1024] f32 layer input (residual of out_proj)
+constexpr int XP_S_X1 = XP_S_X + 4096;           // [1024] f32 (residual of fc2)
+constexpr int XP_S_XQ = XP_S_X1 + 4096;          // [256] u32 Q8 activation of qkv / out_proj / fc1
+constexpr int XP_S_XD = XP_S_XQ + 1024;          // [32]
+constexpr int XP_S_XS = XP_S_XD + 128;           // [32]
+constexpr int XP_S_RED = XP_S_XS + 128;          // [8] double
+constexpr int XP_S_HQ = XP_S_RED + 64;           // [1024] u32 fc1 output as Q8
+constexpr int XP_S_HD = XP_S_HQ + 4096;          // [128]
+constexpr int XP_S_HS = XP_S_HD + 512;           // [128]
+constexpr int XP_S_PART = XP_S_HS + 512;         // [192 rows][DEC_PS] f32 block terms of the q/k/v rows (fc1: 128 rows; fc2: [32][DEC_PS2])
+constexpr int XP_S_G = XP_S_PART + 192 * DEC_PS * 4;   // [128] GELU outputs
+constexpr int XP_S_LN = XP_S_G + 512;            // [4][1024] f32 ln0_w, ln0_b, ln1_w, ln1_b
+constexpr int XP_S_BIAS = XP_S_LN + 16384;       // [192 + 32 + 128 + 32] f32: q/k/v rows of the head, out_proj / fc1 / fc2 rows of the workgroup
+constexpr int XP_S_CUR = XP_S_BIAS + 1536;       // [192] f32 q, k, v of this token (head = slot)
+constexpr int XP_S_S = XP_S_CUR + 768;           // [256] softmax numerators
+constexpr int XP_S_REDF = XP_S_S + 1024;         // [16] f32 + [16] int
+constexpr int XP_S_REDD = XP_S_REDF + 128;       // [16] double
+constexpr int XP_S_PV = XP_S_REDD + 128;         // [1024] double
+constexpr int XP_S_TOTAL = XP_S_PV + 8192;
+static_assert(32 * DEC_PS2 <= 192 * DEC_PS, "fc2 block terms fit the shared region");
+__host__ __device__ inline size_t xpipe_smem_bytes() { return XP_S_TOTAL; }
+
+// stacked [q; k; v] row computed by lane group j (0..95) of workgroup `slot`: workgroups h and h + 16 share head h
+__device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
+__device__ __forceinline__ int xp_qkv_row(int slot, int j) { const int jj = xp_qkv_local(slot, j); return (jj >> 6) * 1024 + (slot & 15) * 64 + (jj & 63); }
+
+template <int WT, int LPK, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
+    using TI = TypeInfo<WT>;
+    static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
+    static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
+    static_assert(NW == 8 || NW == 16, "waves per workgroup");
+    constexpr int D = 1024, DK = 64, NT = NW * 64;
+    constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
+    constexpr int NF4 = 16 / LPK, NV = 64 / LPK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
+    float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
+    uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
+    float *const s_xd = reinterpret_cast<float *>(smem + XP_S_XD);
+    uint32_t *const s_xs = reinterpret_cast<uint32_t *>(smem + XP_S_XS);
+    double *const s_red = reinterpret_cast<double *>(smem + XP_S_RED);
+    uint32_t *const s_hq = reinterpret_cast<uint32_t *>(smem + XP_S_HQ);
+    float *const s_hd = reinterpret_cast<float *>(smem + XP_S_HD);
+    uint32_t *const s_hs = reinterpret_cast<uint32_t *>(smem + XP_S_HS);
+    float *const s_part = reinterpret_cast<float *>(smem + XP_S_PART);
+    float *const s_g = reinterpret_cast<float *>(smem + XP_S_G);
+    float *const s_ln = reinterpret_cast<float *>(smem + XP_S_LN);
+    float *const s_bias = reinterpret_cast<float *>(smem + XP_S_BIAS);
+    float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
+    float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
+    float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 64);
+    double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
+    double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
+
+    // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
+    // launches: launch e hands out 32 (e - 1) .. 32 e - 1) says which.  The dispatcher deals workgroups round-robin over the
+    // XCDs, so a launch that has the device to itself gets exactly 32 per XCD whatever the starting point; a launch interleaved
+    // with another stream's workgroups may not -- then a 33rd arrival raises the error word and the launch drains.
+    const uint32_t epoch = __hip_atomic_load(p.ctl, XP_RLX);
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;     // HW_REG_XCC_ID, bits 0..3
+        const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
+        s_redi[0] = (int)xcc;
+        s_redi[1] = (int)(t - 32u * (epoch - 1u));
+    }
+    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
+    __syncthreads();
+    if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
+    const int n_past = p.st->n_past;
+    const int T = n_past + 1;
+    const int t_cap = p.t_cap;
+
+    for (int L = xcd; L < p.n_layer; L += 8) {
+        // the thread index goes through an empty asm in every iteration: without it the compiler hoists a few hundred
+        // per-thread addresses (LDS carve, granule slots, weight rows) out of the layer loop and spills them (120 VGPRs
+        // of "folded spills" measured); recomputing them costs a handful of integer instructions per stage
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int sub = lane & 31, rsub = lane >> 5;
+        const bool worker = tid < 256;
+        if (L == xcd && L >= 2) {      // start this XCD's first weight load when layer L - 1 starts, not all eight at once
+            if (tid == 0) {
+                const xp_u64 *g = p.gran + (size_t)(L - 2) * XP_G_LAYER + XP_G_X;
+                for (uint32_t spins = 0;; spins++) {
+                    if ((uint32_t)(__hip_atomic_load(g, XP_RLX) >> 32) == epoch) break;
+                    if (spins >= XP_SPIN_MAX) { xp_fail(p, 3u); break; }
+                    if ((spins & 255u) == 255u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            __syncthreads();
+        }
+        const XpLayer &Y = p.layers[L];
+        xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+        // ---- this layer's weights into registers, its small vectors into LDS: issued as soon as the previous layer of this
+        //      XCD is done, i.e. seven layers ahead of their use.  Workgroups 0-15 are the layer's attention heads and hold the
+        //      head's old keys / values instead of q/k/v weights; workgroup 16 + h computes all 192 q/k/v rows of head h.
+        const bool attn_wg = slot < 16;
+        const int head = slot & 15;
+        Unit<WT> wo[OS], w1[FS], w2[F2R][2];
+        {
+            float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0;
+            if (worker) {
+                l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid];
+                l2 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l3 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid];
+            }
+            float bv = 0.0f;
+            if (tid < 192) bv = Y.bqkv[(tid >> 6) * 1024 + head * 64 + (tid & 63)];
+            else if (tid < 224) bv = Y.bo[slot * 32 + tid - 192];
+            else if (tid < 352) bv = Y.b1[slot * 128 + tid - 224];
+            else if (tid < 384) bv = Y.b2[slot * 32 + tid - 352];
+#pragma unroll
+            for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+#pragma unroll
+            for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+#pragma unroll
+            for (int r = 0; r < F2R; r++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+            if (worker) {
+                reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1;
+                reinterpret_cast<float4 *>(s_ln + 2048)[tid] = l2; reinterpret_cast<float4 *>(s_ln + 3072)[tid] = l3;
+            }
+            if (tid < 384) s_bias[tid] = bv;
+        }
+        // the layer input, 4 elements per LayerNorm worker (waves 0-3): the embedding (layer 0) or the previous layer's granules
+        auto layer_input = [&]() -> float4 {
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (L == 0) {
+                int tok;
+                if (p.tok_src == 2) {
+                    // greedy sampler of the PREVIOUS token (main.cpp:109-128, top_k = 1): arg-max over the lm_head kernel's
+                    // per-workgroup partials, lowest id wins ties; workgroup 0 records it
+                    float bv = -INFINITY;
+                    int bi = 0x7fffffff;
+                    for (int k = tid; k < p.nparts; k += NT) {
+                        const float v = p.pmax_val[k];
+                        const int ix = p.pmax_idx[k];
+                        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+                    }
+    #pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const float ov = __shfl_xor(bv, off, 64);
+                        const int oi = __shfl_xor(bi, off, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    if (lane == 0) { s_redf[wave] = bv; s_redi[wave] = bi; }
+                    __syncthreads();
+                    bv = s_redf[0]; bi = s_redi[0];
+    #pragma unroll
+                    for (int w = 1; w < NW; w++)
+                        if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
+                    tok = bi;
+                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                    if (slot == 0 && tid == 0) {
+                        int32_t *tokens = state_tokens(p.st);
+                        const int g = p.st->n_gen;
+                        if (g < p.n_positions) tokens[p.n_positions + g] = tok;
+                        tokens[0] = tok;
+                    }
+                } else {
+                    tok = state_tokens(p.st)[0];
+                }
+                if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
+                    float e[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                    xv = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            } else if (wave < 4) {
+                uint32_t v[4];
+                xp_sweep<4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+            return xv;
+        };
+        asm volatile("; XPMARK stage_A" ::: "memory");
+        if (!attn_wg) {
+            // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
+            Unit<WT> wqkv[QS];
+#pragma unroll
+            for (int s = 0; s < QS; s++) {
+                const int jj = s * 2 * NW + wave * 2 + rsub;
+                load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+            }
+            const float4 xv = layer_input();
+            XP_WALL(0);
+            float4 lnw = xv, lnb = xv;
+            if (worker) {
+                reinterpret_cast<float4 *>(s_x)[tid] = xv;
+                lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
+            }
+            ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            XP_WALL(6);
+            uint32_t ax[8];
+            const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+            const float axd = s_xd[sub];
+            const uint32_t axs = s_xs[sub];
+            float *const part = s_part + wave * 2 * QS * DEC_PS;
+#pragma unroll
+            for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 2 * QS) {
+                const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
+                const int which = jj >> 6, d = jj & 63;
+                if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, epoch, __float_as_uint(v));
+                if (which != 0) {                                               // KV append (biogpt.cpp:721-727), head-major cache
+                    float *cache = (which == 1) ? Y.kcache : Y.vcache;
+                    cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                }
+            }
+            XP_WALL(1);
+        } else {
+            // ================= stage B (workgroups 0-15): attention of head `head` (biogpt.cpp:729-764) =================
+            // the old keys / values of this head: in flight since the previous layer of this XCD finished
+            float4 kr[NF4];
+            float vr[NV];
+            const int ksub = tid & (LPK - 1), kidx = tid / LPK;
+            const int dd = tid & (DK - 1), sl = tid >> 6;
+            if (kidx < t_cap) {
+                const float4 *kbase = reinterpret_cast<const float4 *>(Y.kcache + (size_t)head * p.P * DK) + (size_t)kidx * (DK / 4) + ksub;
+#pragma unroll
+                for (int m = 0; m < NF4; m++) kr[m] = kbase[LPK * m];
+            }
+            {
+                const float *vbase = Y.vcache + (size_t)head * p.P * DK + dd;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const int j = sl + NW * k;
+                    if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
+                }
+            }
+            {   // the layer input is the residual of stage C; it arrives about 2 us before the q / k / v rows
+                const float4 xv = layer_input();
+                if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;
+            }
+            XP_WALL(0);
+            if (wave < 3) {
+                uint32_t v[1];
+                xp_sweep<1>(G + XP_G_QKV + wave * 1024 + head * 64 + lane, true, epoch, v, p);
+                s_cur[tid] = __uint_as_float(v[0]);
+            }
+            __syncthreads();
+            XP_WALL(7);
+            float sc = -INFINITY;
+            if ((tid & ~63) < LPK * T) {
+                if (kidx == n_past) {
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                }
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int m = 0; m < NF4; m++) {
+                    const float4 qm = *reinterpret_cast<const float4 *>(s_cur + 4 * (LPK * m + ksub));
+                    a0 += (double)__fmul_rn(kr[m].x, qm.x); a1 += (double)__fmul_rn(kr[m].y, qm.y);
+                    a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
+                }
+                double acc = (a0 + a1) + (a2 + a3);
+                acc += dpp_d<DPP_QUAD_XOR1>(acc);
+                if (LPK >= 4) acc += dpp_d<DPP_QUAD_XOR2>(acc);
+                if (LPK >= 8) acc += dpp_d<DPP_ROW_HALF_MIRROR>(acc);
+                if (LPK >= 16) acc += dpp_d<DPP_ROW_MIRROR>(acc);
+                if (kidx < T) sc = (float)acc;
+            }
+            float mx = wave_max_f32(sc);
+            if (lane == 0) s_redf[wave] = mx;
+            __syncthreads();
+            mx = s_redf[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
+            double sum = 0.0;
+            if (kidx < T && ksub == 0) {
+                const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);
+                s_S[kidx] = val;
+                sum = (double)val;
+            }
+            sum = wave_sum_f64(sum);
+            if (lane == 0) s_redd[wave] = sum;
+            __syncthreads();
+            sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) sum += s_redd[w];
+            const float inv = inv_sum_f32(sum);
+            {
+                const float vcur = s_cur[128 + dd];
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < NV; k += 2) {
+                    const int j0 = sl + NW * k, j1 = j0 + NW;
+                    if (j0 < T) a0 += (double)__fmul_rn(j0 == n_past ? vcur : vr[k], __fmul_rn(s_S[j0], inv));
+                    if (j1 < T) a1 += (double)__fmul_rn(j1 == n_past ? vcur : vr[k + 1], __fmul_rn(s_S[j1], inv));
+                }
+                s_pv[tid] = a0 + a1;
+            }
+            __syncthreads();
+            if (tid < DK) {
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
+                const float o = (float)(t0 + t1);
+                int8_t q8; float d8; uint32_t s8;
+                q8_block32(o, TI::q81, q8, d8, s8);
+                const uint32_t packed = xp_pack4(q8);
+                const int blk = head * 2 + (tid >> 5);
+                if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
+                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_ATT + 288 + blk, epoch, s8); }
+            }
+        }
+        XP_WALL(2);
+        asm volatile("; XPMARK stage_C" ::: "memory");
+        // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
+        if (wave < 5) {
+            uint32_t v[1];
+            xp_sweep<1>(G + XP_G_ATT + tid, true, epoch, v, p);
+            if (tid < 256) s_xq[tid] = v[0];
+            else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
+            else s_xs[tid - 288] = v[0];
+        }
+        __syncthreads();
+        XP_WALL(8);
+        {
+            uint32_t ax[8];
+            const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+            const float axd = s_xd[sub];
+            const uint32_t axs = s_xs[sub];
+            float *const part = s_part + wave * 2 * OS * DEC_PS;
+#pragma unroll
+            for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 2 * OS) {
+                const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
+                const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
+                xp_put_local(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));
+            }
+        }
+        XP_WALL(3);
+        asm volatile("; XPMARK stage_D" ::: "memory");
+        // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
+        float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
+        if (wave < 4) {
+            uint32_t v[4];
+            xp_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
+            x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
+            XP_WALL(9);
+            lnw = reinterpret_cast<const float4 *>(s_ln + 2048)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 3072)[tid];
+        }
+        ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+        XP_WALL(10);
+        {
+            uint32_t ax[8];
+            const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+            const float axd = s_xd[sub];
+            const uint32_t axs = s_xs[sub];
+            float *const part = s_part + wave * 2 * FS * DEC_PS;
+#pragma unroll
+            for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 2 * FS) {
+                const int jr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                const float v = __fadd_rn(s_bias[224 + jr], sum32_in_order(part + lane * DEC_PS));
+                s_g[jr] = h2f(p.gelu_tab[f2h(v)]);                            // ggml_gelu: fp16 table
+            }
+        }
+        __syncthreads();
+        XP_WALL(11);
+        if (tid < 128) {
+            int8_t q8; float d8; uint32_t s8;
+            q8_block32(s_g[tid], TI::q81, q8, d8, s8);
+            const uint32_t packed = xp_pack4(q8);
+            const int blk = slot * 4 + (tid >> 5);
+            if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), epoch, packed);
+            if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
+        }
+        XP_WALL(4);
+        asm volatile("; XPMARK stage_E" ::: "memory");
+        // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
+        {   // 1024 + 128 + 128 granules in ONE poll loop: every pass has all of a lane's loads in flight together
+            constexpr int NQ = 1024 / NT;
+            uint32_t v[NQ + 1];
+            const xp_u64 *g = G + XP_G_H + tid;
+            const bool tail = tid < 256;
+            for (uint32_t spins = 0;; spins++) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NQ; k++) {
+                    const xp_u64 a = __hip_atomic_load(g + k * NT, XP_RLX);
+                    v[k] = (uint32_t)a;
+                    ok &= (uint32_t)(a >> 32) == epoch;
+                }
+                if (tail) {
+                    const xp_u64 a = __hip_atomic_load(g + 1024, XP_RLX);
+                    v[NQ] = (uint32_t)a;
+                    ok &= (uint32_t)(a >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); break; }
+                if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];
+            if (tid < 128) s_hd[tid] = __uint_as_float(v[NQ]);
+            else if (tid < 256) s_hs[tid - 128] = v[NQ];
+        }
+        __syncthreads();
+        XP_WALL(12);
+        {
+            float *const part = s_part + wave * F2R * DEC_PS2;
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int u = lane + 64 * it;
+                uint32_t ax[8];
+                const uint4 a = *reinterpret_cast<const uint4 *>(s_hq + u * 8), b = *reinterpret_cast<const uint4 *>(s_hq + u * 8 + 4);
+                ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                const float axd = s_hd[u];
+                const uint32_t axs = s_hs[u];
+#pragma unroll
+                for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = unit_dot_quant<WT>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < F2R) {
+                const float4 *p4 = reinterpret_cast<const float4 *>(part + lane * DEC_PS2);
+                float sumf = 0.0f;
+#pragma unroll
+                for (int b0 = 0; b0 < 32; b0 += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) t[j] = p4[b0 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        sumf = __fadd_rn(sumf, t[j].x); sumf = __fadd_rn(sumf, t[j].y);
+                        sumf = __fadd_rn(sumf, t[j].z); sumf = __fadd_rn(sumf, t[j].w);
+                    }
+                }
+                const int lr = wave * F2R + lane, row = slot * 32 + lr;
+                const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
+                xp_put(G + XP_G_X + xp_col_slot(row), epoch, __float_as_uint(v));
+                if (L == p.n_layer - 1) p.x_final[row] = v;
+            }
+        }
+        XP_WALL(5);
+        __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next layer of this XCD
+        if (L == p.n_layer - 1 && slot == 0 && tid == 0) __hip_atomic_store(p.ctl, epoch + 1u, XP_RLX);   // every workgroup read it long ago
+    }
+}
+
+// where workgroup b of a 256-workgroup launch runs: the host checks b % 8 once per device before it trusts the pipeline
+__global__ void xp_probe_kernel(uint32_t *out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;
+}
+
+}  // namespace bgk

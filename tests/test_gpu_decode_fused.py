@@ -236,3 +236,115 @@ def test_opt_in_causal_mask(pkg, oracle, files, monkeypatch, name):
     print("%s causal: worst |diff| %.2e" % (name, worst))
     assert worst <= ATOL
     g.close(); g2.close()
+
+
+# ---- XCD-pipelined decode step (csrc/kernels_xpipe.hip.h): ONE persistent launch for all layers -----------------------------
+
+XPIPE_TYPES = ["q4_0", "q4_1", "q5_0", "q5_1"]
+
+
+def _with_xpipe(g, monkeypatch, on):
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE", "1" if on else "0")
+    g.refresh_options()
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE")
+
+
+@pytest.mark.parametrize("name", XPIPE_TYPES)
+def test_xpipe_step_is_bit_identical_to_the_five_launch_layer_and_the_oracle(pkg, oracle, files, monkeypatch, name):
+    """The same context, the same positions, with the pipeline on and off (options re-read in between): logits identical bit for
+    bit around every context bucket of the pipeline (64 / 128 / 256 keys: 8 / 4 / 2 lanes per key) and within the contract of
+    the oracle; the K / V rows the pipeline appended are the oracle's."""
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device (xpipe_state %d)" % g.xpipe_state())
+    o = oracle.OracleModel(files[name], n_threads=16)
+    rng = np.random.default_rng(29)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 256)]
+    checked = [0, 1, 31, 62, 63, 64, 65, 100, 127, 128, 129, 200, 254, 255]
+    n_past, worst = 0, 0.0
+    while n_past <= checked[-1]:
+        if n_past in checked:
+            _with_xpipe(g, monkeypatch, True)
+            assert g.xpipe_state() == 1
+            lp = g.eval([toks[n_past]], n_past)
+            kp = g.read_kv(0, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"])
+            _with_xpipe(g, monkeypatch, False)
+            assert g.xpipe_state() == 0
+            lf = g.eval([toks[n_past]], n_past)
+            kf = g.read_kv(0, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"])
+            lo = o.eval([toks[n_past]], n_past)
+            assert (lp == lf).all(), "%s: pipeline != five-launch layer at n_past %d (max diff %g)" % (name, n_past, np.abs(lp - lf).max())
+            assert (kp == kf).all()
+            worst = max(worst, float(np.abs(lp - lo).max()))
+            assert int(lp.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            g.eval_device(chunk, n_past); g.synchronize(); o.eval(chunk, n_past)
+            n_past += m
+    assert worst <= ATOL
+    K = o.kv(0)
+    for pos in (0, 64, 255):
+        got = g.read_kv(0, ((KW["n_layer"] - 1) * KW["n_positions"] + pos) * KW["d_model"], KW["d_model"])
+        assert np.abs(got - K[KW["n_layer"] - 1, pos]).max() <= ATOL
+    assert g.xpipe_state() == 0          # switched off above, not abandoned
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+def test_xpipe_generation_equals_the_oracle(pkg, oracle, files, monkeypatch, name):
+    """Greedy generation (device-resident sampler folded into the pipeline's first stage) through all three pipeline buckets
+    and across the hand-over to the five-launch graphs at 257 keys: the oracle's ids, and the ids with the pipeline off."""
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    rng = np.random.default_rng(31)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 40)]
+    n_predict = 230                          # contexts 41 .. 270 keys
+    ids_p, _ = g.generate_greedy(prompt, n_predict=n_predict, n_batch=8)
+    assert g.xpipe_state() == 1
+    _with_xpipe(g, monkeypatch, False)
+    ids_f, _ = g.generate_greedy(prompt, n_predict=n_predict, n_batch=8)
+    assert list(ids_p) == list(ids_f)
+    o = oracle.OracleModel(files[name], n_threads=16)
+    ids_o, _ = o.generate_greedy(prompt, n_predict=40, n_batch=8)
+    assert list(ids_p[:40]) == list(ids_o)
+    g.close()
+
+
+def test_xpipe_disturbed_launch_is_repeated_on_the_five_launch_layer(pkg, files, monkeypatch, capfd):
+    """BIOGPT_HIP_XPIPE_FAULT=1 pre-loads one arrival ticket of XCD 0, so the first pipelined launch finds a 33rd workgroup
+    there -- what a launch interleaved with another stream's workgroups looks like.  The launch must drain (bounded spins),
+    the call must be repeated transparently and give the undisturbed results, and the context must stay off the pipeline."""
+    ref = pkg.BiogptModel.load(files["q4_0"])
+    if ref.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 100, 200, 300]
+    want, _ = ref.generate_greedy(prompt, n_predict=24, n_batch=8)
+    want_logits = ref.eval([7], 30)
+    ref.close()
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    assert g.xpipe_state() == 1
+    got, _ = g.generate_greedy(prompt, n_predict=24, n_batch=8)
+    assert list(got) == list(want)
+    assert g.xpipe_state() == -1
+    assert "five-launch layer" in capfd.readouterr().err
+    assert (g.eval([7], 30) == want_logits).all()
+    g.close()
+    # and through the single-token API
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    g.eval_device(prompt, 0); g.synchronize()
+    l0 = g.eval([7], 4)
+    assert g.xpipe_state() == -1
+    g.close()
+    ref = pkg.BiogptModel.load(files["q4_0"])
+    ref.eval_device(prompt, 0); ref.synchronize()
+    assert (ref.eval([7], 4) == l0).all()
+    ref.close()

@@ -1,0 +1,232 @@
+// Round-2 calibration, part 8: skeleton of an XCD-pipelined persistent decode step.
+//
+// Question: what do the six dependency edges of a BioGPT layer cost when the whole layer runs on the 32 CUs of ONE XCD
+// (layer l on XCD l % 8, weights stationary in registers) and the edges are 8-byte {value, tag} granules instead of
+// kernel boundaries?  The skeleton moves exactly the model's hand-off data (x 1024 f32, q/k/v 3072 f32, attention output
+// 256 + 32 words, x1 1024 f32, fc1 activations 1024 + 128 words) with trivial bodies (one workgroup-wide xor per phase, so
+// that every output depends on every input and a stale granule shows up in the final checksum).
+//
+// Hand-off form: MI355X_MICROARCH.md "R2" granules (relaxed agent-scope 8-byte atomic stores and loads, tag = epoch).
+// Every spin is bounded (SPIN_MAX passes, error word set, every later poll returns at once).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef unsigned long long u64;
+typedef unsigned int u32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int NL = 24, NX = 8, WPX = 32, D = 1024;
+constexpr u32 SPIN_MAX = 400000;
+
+struct P {
+    u64 *x;      // [NL + 1][1024]
+    u64 *qkv;    // [NL][3072]
+    u64 *att;    // [NL][288]
+    u64 *x1;     // [NL][1024]
+    u64 *h;      // [NL][1152]
+    u32 *epoch;  // [0] epoch, [1] error
+    u64 *stamps; // [NL][8] wall clock of slot 0
+    int sleep_far;
+    int poll_mode;
+};
+
+__device__ __forceinline__ void put(u64 *g, u32 epoch, u32 v) { __hip_atomic_store(g, ((u64)epoch << 32) | v, RLX_AGENT); }
+// same-XCD hand-off: a plain (workgroup-scope) 8-byte store keeps the line in the XCD's L2, where the pollers' sc1 loads find it
+__device__ __forceinline__ void put_local(u64 *g, u32 epoch, u32 v, int plain) {
+    if (plain) __hip_atomic_store(g, ((u64)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(g, ((u64)epoch << 32) | v, RLX_AGENT);
+}
+// the real kernel's LayerNorm input sweep: waves 0-3, 4 granules per lane; layout 0: lane t reads 4t..4t+3, layout 1: t + 256 k
+__device__ __forceinline__ u32 sweep4(const u64 *g, u32 epoch, u32 *err, int layout) {
+    const int t = threadIdx.x;
+    u32 acc = 0;
+    if (t < 256) {
+        for (u32 spins = 0;; spins++) {
+            bool ok = true; acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 a = __hip_atomic_load(g + (layout ? t + 256 * k : 4 * t + k), RLX_AGENT);
+                ok &= (u32)(a >> 32) == epoch; acc ^= (u32)a;
+            }
+            if (__all(ok)) break;
+            if (spins > SPIN_MAX || ((spins & 1023) == 1023 && __hip_atomic_load(err, RLX_AGENT) != 0)) { if ((t & 63) == 0) __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    return acc;
+}
+
+// every thread with i < n polls granule g[i] (and g[i + 1024] when i + 1024 < n) until all tags match; returns false on timeout
+__device__ __forceinline__ bool sweep(const u64 *g, int n, u32 epoch, u32 &v0, u32 &v1, u32 *err, int *s_flag) {
+    const int i = threadIdx.x;
+    bool ok0 = i >= n, ok1 = i + 1024 >= n;
+    v0 = 0; v1 = 0;
+    for (u32 spins = 0;; spins++) {
+        if (!ok0) { const u64 a = __hip_atomic_load(g + i, RLX_AGENT); if ((u32)(a >> 32) == epoch) { ok0 = true; v0 = (u32)a; } }
+        if (!ok1) { const u64 a = __hip_atomic_load(g + i + 1024, RLX_AGENT); if ((u32)(a >> 32) == epoch) { ok1 = true; v1 = (u32)a; } }
+        if (__all(ok0 && ok1)) break;
+        if (spins > SPIN_MAX || ((spins & 1023) == 1023 && __hip_atomic_load(err, RLX_AGENT) != 0)) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, RLX_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ u32 wg_xor(u32 v, u32 *s_red) {
+    for (int o = 32; o; o >>= 1) v ^= __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = 0;
+    for (int w = 0; w < 16; w++) r ^= s_red[w];
+    return r;
+}
+
+__device__ __forceinline__ u32 mix(u32 a, u32 b) { a ^= b * 0x9E3779B1u; a = (a << 13) | (a >> 19); return a * 0x85EBCA6Bu + 1u; }
+
+extern __shared__ char smem[];
+__global__ __launch_bounds__(1024) void xpipe_skel(const P p) {
+    __shared__ u32 s_red[16];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    const u32 xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID = 20, bits 0..3
+    const int slot = blockIdx.x / NX;
+    u32 *err = p.epoch + 1;
+    if (xcc != (u32)(blockIdx.x % NX)) { if (tid == 0) __hip_atomic_store(err, 2u, RLX_AGENT); }
+    const u32 epoch = __hip_atomic_load(p.epoch, RLX_AGENT);
+    if (smem[tid] == 77 && epoch == 0xFFFFFFFFu) p.stamps[0] = 1;   // keep the dynamic LDS request alive
+    const int xcd = blockIdx.x % NX;
+    for (int L = xcd; L < NL; L += NX) {
+        u32 v0, v1;
+        // far from my turn: ONE lane watches the input of the previous layer with long sleeps
+        if (p.sleep_far && L >= 1) {
+            if (tid == 0) {
+                for (u32 spins = 0; spins < SPIN_MAX; spins++) {
+                    const u64 a = __hip_atomic_load(p.x + (size_t)(L - 1) * D, RLX_AGENT);
+                    if (L - 1 == 0 || (u32)(a >> 32) == epoch) break;
+                    for (int k = 0; k < p.sleep_far; k++) __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
+        // A: x -> qkv
+        if (L == 0) { v0 = tid * 2654435761u; v1 = 0; __syncthreads(); }
+        else if (p.poll_mode & 1) { v0 = sweep4(p.x + (size_t)L * D, epoch, err, p.poll_mode & 4); v1 = 0; }
+        else sweep(p.x + (size_t)L * D, D, epoch, v0, v1, err, &s_flag);
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 0] = wall_clock64();
+        u32 r = wg_xor(v0, s_red);
+        if (tid < 96) put_local(p.qkv + (size_t)L * 3072 + slot * 96 + tid, epoch, mix(r, slot * 96 + tid), p.poll_mode & 2);
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 1] = wall_clock64();
+        // B: qkv -> attention output (16 head workgroups)
+        if (slot < 16) {
+            const int src = (tid >> 6) * 1024 + slot * 64 + (tid & 63);     // q, k, v of head `slot`
+            u32 w = 0;
+            {   // 192 granules
+                bool ok = tid >= 192;
+                for (u32 spins = 0;; spins++) {
+                    if (!ok) { const u64 a = __hip_atomic_load(p.qkv + (size_t)L * 3072 + src, RLX_AGENT); if ((u32)(a >> 32) == epoch) { ok = true; w = (u32)a; } }
+                    if (__all(ok)) break;
+                    if (spins > SPIN_MAX || ((spins & 1023) == 1023 && __hip_atomic_load(err, RLX_AGENT) != 0)) { if ((tid & 63) == 0) __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            r = wg_xor(w, s_red);
+            if (tid < 18) put_local(p.att + (size_t)L * 288 + slot * 18 + tid, epoch, mix(r, slot * 18 + tid), p.poll_mode & 2);
+        }
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 2] = wall_clock64();
+        // C: attention output -> x1
+        sweep(p.att + (size_t)L * 288, 288, epoch, v0, v1, err, &s_flag);
+        r = wg_xor(v0, s_red);
+        if (tid < 32) put_local(p.x1 + (size_t)L * D + slot * 32 + tid, epoch, mix(r, slot * 32 + tid), p.poll_mode & 2);
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 3] = wall_clock64();
+        // D: x1 -> fc1 activations
+        if (p.poll_mode & 1) { v0 = sweep4(p.x1 + (size_t)L * D, epoch, err, p.poll_mode & 4); v1 = 0; }
+        else sweep(p.x1 + (size_t)L * D, D, epoch, v0, v1, err, &s_flag);
+        r = wg_xor(v0, s_red);
+        if (tid < 36) put_local(p.h + (size_t)L * 1152 + slot * 36 + tid, epoch, mix(r, slot * 36 + tid), p.poll_mode & 2);
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 4] = wall_clock64();
+        // E: fc1 activations -> x of the next layer (another XCD)
+        sweep(p.h + (size_t)L * 1152, 1152, epoch, v0, v1, err, &s_flag);
+        r = wg_xor(v0 ^ v1, s_red);
+        if (tid < 32) put(p.x + (size_t)(L + 1) * D + slot * 32 + tid, epoch, mix(r, slot * 32 + tid));
+        if (slot == 0 && tid == 0) p.stamps[L * 8 + 5] = wall_clock64();
+    }
+}
+
+__global__ void bump(u32 *epoch) { if (threadIdx.x == 0) epoch[0] += 1; }
+
+// host model of the same data flow
+static u32 hmix(u32 a, u32 b) { a ^= b * 0x9E3779B1u; a = (a << 13) | (a >> 19); return a * 0x85EBCA6Bu + 1u; }
+static u32 expected_checksum() {
+    std::vector<u32> x(D), q(3072), at(288), x1(D), h(1152);
+    for (int i = 0; i < D; i++) x[i] = i * 2654435761u;
+    for (int L = 0; L < NL; L++) {
+        u32 r = 0; for (u32 v : x) r ^= v;
+        for (int i = 0; i < 3072; i++) q[i] = hmix(r, i);
+        for (int hd = 0; hd < 16; hd++) {
+            u32 rr = 0;
+            for (int s = 0; s < 3; s++) for (int d = 0; d < 64; d++) rr ^= q[s * 1024 + hd * 64 + d];
+            for (int t = 0; t < 18; t++) at[hd * 18 + t] = hmix(rr, hd * 18 + t);
+        }
+        r = 0; for (u32 v : at) r ^= v;
+        for (int i = 0; i < D; i++) x1[i] = hmix(r, i);
+        r = 0; for (u32 v : x1) r ^= v;
+        for (int i = 0; i < 1152; i++) h[i] = hmix(r, i);
+        r = 0; for (u32 v : h) r ^= v;
+        for (int i = 0; i < D; i++) x[i] = hmix(r, i);
+    }
+    u32 r = 0; for (u32 v : x) r ^= v;
+    return r;
+}
+
+int main(int argc, char **argv) {
+    P p;
+    const size_t nx = (size_t)(NL + 1) * D, nq = (size_t)NL * 3072, na = (size_t)NL * 288, n1 = (size_t)NL * D, nh = (size_t)NL * 1152;
+    CK(hipMalloc(&p.x, nx * 8)); CK(hipMalloc(&p.qkv, nq * 8)); CK(hipMalloc(&p.att, na * 8)); CK(hipMalloc(&p.x1, n1 * 8)); CK(hipMalloc(&p.h, nh * 8));
+    CK(hipMalloc(&p.epoch, 64)); CK(hipMalloc(&p.stamps, NL * 8 * 8));
+    CK(hipMemset(p.x, 0, nx * 8)); CK(hipMemset(p.qkv, 0, nq * 8)); CK(hipMemset(p.att, 0, na * 8)); CK(hipMemset(p.x1, 0, n1 * 8)); CK(hipMemset(p.h, 0, nh * 8));
+    CK(hipMemset(p.stamps, 0, NL * 64));
+    u32 e0[2] = {1, 0};
+    CK(hipMemcpy(p.epoch, e0, 8, hipMemcpyHostToDevice));
+    const size_t lds = 96 * 1024;      // one workgroup per CU
+    CK(hipFuncSetAttribute((const void *)xpipe_skel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const u32 want = expected_checksum();
+    for (int mode : {0, 1, 5, 2, 3, 7}) {
+        const int sleep_far = 0;
+        p.sleep_far = sleep_far; p.poll_mode = mode;
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        const int reps = 200;
+        for (int pass = 0; pass < 2; pass++) {
+            CK(hipEventRecord(a, st));
+            for (int i = 0; i < reps; i++) {
+                hipLaunchKernelGGL(xpipe_skel, dim3(NX * WPX), dim3(1024), lds, st, p);
+                hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, st, p.epoch);
+            }
+            CK(hipEventRecord(b, st));
+            CK(hipStreamSynchronize(st));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        u32 ew[2]; CK(hipMemcpy(ew, p.epoch, 8, hipMemcpyDeviceToHost));
+        std::vector<u64> x(D); CK(hipMemcpy(x.data(), p.x + (size_t)NL * D, D * 8, hipMemcpyDeviceToHost));
+        u32 r = 0; bool tags = true;
+        for (int i = 0; i < D; i++) { r ^= (u32)x[i]; tags &= (u32)(x[i] >> 32) == ew[0] - 1; }
+        std::vector<u64> s(NL * 8); CK(hipMemcpy(s.data(), p.stamps, NL * 64, hipMemcpyDeviceToHost));
+        printf("mode %d (1: 4-granule LayerNorm sweeps by 4 waves, 2: plain same-XCD stores, 4: lane-contiguous layout): %.2f us per step (24 layers + bump launch) = %.2f us per layer; error word %u; checksum %s, tags %s\n", mode, ms * 1e3 / reps,
+               ms * 1e3 / reps / NL, ew[1], r == want ? "ok" : "WRONG", tags ? "ok" : "WRONG");
+        double seg[5] = {0, 0, 0, 0, 0}, hop = 0;
+        for (int L = 1; L < NL; L++) {
+            for (int k = 0; k < 5; k++) seg[k] += (double)(s[L * 8 + k + 1] - s[L * 8 + k]) * 0.01;
+            hop += (double)(s[L * 8] - s[(L - 1) * 8 + 5]) * 0.01;
+        }
+        printf("   slot-0 wall clock, mean over layers 1..23 (us): x arrived -> qkv published %.2f | -> attention published %.2f | -> x1 published %.2f | -> fc1 act published %.2f | -> next x published %.2f | cross-XCD hop %.2f | layer %.2f\n",
+               seg[0] / 23, seg[1] / 23, seg[2] / 23, seg[3] / 23, seg[4] / 23, hop / 23, (double)(s[23 * 8 + 5] - s[5]) * 0.01 / 23);
+        if (ew[1]) break;
+    }
+    return 0;
+}
