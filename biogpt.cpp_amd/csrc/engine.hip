@@ -167,7 +167,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -193,6 +193,7 @@ struct EngineOptions {
         qkv_waves = get("BIOGPT_HIP_QKV_WAVES", 8);
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
+        xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // fp16 table slices kept in LDS by the pipeline: 1 GELU, 2 exp (3: both if they fit)
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
@@ -267,6 +268,8 @@ struct biogpt_hip_ctx {
     uint32_t *xp_ctl = nullptr;
     uint32_t *xp_err_host = nullptr;
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
+    int xp_exp_n = 0;                      // entries of the exp table's negative half the attention workgroups keep in LDS
+    int xp_gelu_p = 0, xp_gelu_n = 0, xp_gelu_z = 0;   // the GELU table's slices every workgroup keeps in LDS (kernels_xpipe.hip.h)
     int xp_state = 0;                      // 0 not probed, 1 usable, -1 unusable on this device / model / after a failure
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
     int32_t *mbox_host = nullptr;          // pinned ring of 64 x {n_past, causal, token}: inputs of the graph-replayed single-token evals
@@ -583,6 +586,27 @@ bool xpipe_model_ok(const biogpt_hip_ctx *c) {
            hp.n_positions >= 64 && hp.n_layer >= 1;
 }
 
+template <int WT>
+bool xpipe_set_lds_t(size_t sm) {
+    const void *fns[3] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8>)};
+    for (const void *fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return false;
+    return true;
+}
+// > 64 KB of dynamic LDS needs the opt-in attribute (per device); set outside any stream capture
+bool xpipe_set_lds(biogpt_hip_ctx *c) {
+    const size_t sm = bgk::xpipe_smem_bytes(c->xp_exp_n, c->xp_gelu_p + c->xp_gelu_n);
+    if (sm <= 64 * 1024) return true;
+    switch (ftype_to_type(c->hp.ftype)) {
+        case T_Q4_0: return xpipe_set_lds_t<bgk::W_Q4_0>(sm);
+        case T_Q4_1: return xpipe_set_lds_t<bgk::W_Q4_1>(sm);
+        case T_Q5_0: return xpipe_set_lds_t<bgk::W_Q5_0>(sm);
+        case T_Q5_1: return xpipe_set_lds_t<bgk::W_Q5_1>(sm);
+        default: return false;
+    }
+}
+
 // once per context, outside any stream capture: is this an 8-XCD x 32-CU device that places workgroup b on XCD b % 8 ?
 // then the layer table, the granules and the control words.  Leaves xp_state = 1 or -1; never fails the caller.
 void xpipe_prepare(biogpt_hip_ctx *c) {
@@ -627,6 +651,28 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         const uint32_t one = 1u;
         (void)hipMemcpy(c->xp_ctl + 8, &one, 4, hipMemcpyHostToDevice);
     }
+    {   // the exp table (built by upload_weights exactly like this) is 0 from some negative argument down to -inf: keep the rest in LDS
+        int n = 0;
+        for (uint32_t k = 0; k <= 0x7C00u; k++)
+            if (f32_to_f16(expf(f16_to_f32((uint16_t)(0x8000u + k)))) != 0) n = (int)k + 1;
+        n = (n + 7) & ~7;
+        // the GELU table (same construction): identity from some positive argument up to +inf, one constant from some negative
+        // argument down to the most negative finite value
+        std::vector<uint16_t> tg(65536);
+        for (uint32_t i = 0; i < 65536; i++) tg[i] = f32_to_f16(gelu_tanh_f32(f16_to_f32((uint16_t)i)));
+        int P = 0x7C01;
+        while (P > 0 && tg[(size_t)P - 1] == (uint16_t)(P - 1)) P--;
+        const uint16_t Z = tg[0xFBFF];
+        int N = 0x7C00;
+        while (N > 0 && tg[0x8000 + (size_t)N - 1] == Z) N--;
+        P = (P + 7) & ~7; N = (N + 7) & ~7;
+        const size_t lds_max = 160 * 1024;
+        if (c->opt.xpipe_tables & 1) {
+            if (P <= 0x7C00 && N <= 0x7C00 && bgk::xpipe_smem_bytes(0, P + N) <= lds_max) { c->xp_gelu_p = P; c->xp_gelu_n = N; c->xp_gelu_z = Z; }
+        }
+        if ((c->opt.xpipe_tables & 2) && bgk::xpipe_smem_bytes(n, c->xp_gelu_p + c->xp_gelu_n) <= lds_max) c->xp_exp_n = n;
+    }
+    if (!xpipe_set_lds(c)) { (void)hipGetLastError(); xpipe_release(c); return; }
     *c->xp_err_host = 0u;
     c->xp_state = 1;
 }
@@ -655,7 +701,7 @@ bool xpipe_check(biogpt_hip_ctx *c) {
 
 template <int WT>
 hipError_t launch_xpipe(biogpt_hip_ctx *c, const bgk::XpParams &xp) {
-    const size_t sm = bgk::xpipe_smem_bytes();
+    const size_t sm = bgk::xpipe_smem_bytes(xp.exp_n, xp.gelu_p + xp.gelu_n);
     // 8 waves per workgroup: 24 weight units per lane (120 VGPRs) + the head's old keys / values fit the 256-register budget
     if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8>), dim3(256), dim3(512), sm, c->stream, xp);
     else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8>), dim3(256), dim3(512), sm, c->stream, xp);
@@ -755,6 +801,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.P = P; xp.t_cap = std::min(P, (t_max + 63) & ~63);
         xp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
         xp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+        xp.exp_n = c->xp_exp_n; xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z;
         xp.x_final = c->x;
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
         hipError_t e = hipErrorInvalidValue;
@@ -2086,27 +2133,27 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
         std::vector<unsigned long long> w((size_t)nl * 16);
         HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp, w.size() * 8, hipMemcpyDeviceToHost));
         // stamp order inside a layer
-        const int order[13] = {0, 6, 1, 7, 2, 8, 3, 9, 10, 11, 4, 12, 5};
-        const char *names[13] = {"x arrived", "LayerNorm + Q8 done", "q/k/v rows stored / handed over", "partner's rows arrived", "attention output published",
-                                 "attention output arrived", "out_proj rows published", "x1 arrived", "LayerNorm + Q8 done", "fc1 rows + GELU done",
-                                 "fc1 activations published", "fc1 activations arrived", "layer output published"};
-        double seg[13] = {}, hop = 0.0;
+        const int order[16] = {0, 6, 1, 7, 13, 14, 15, 2, 8, 3, 9, 10, 11, 4, 12, 5};
+        const char *names[16] = {"x arrived", "LayerNorm + Q8 done", "q/k/v rows stored / handed over", "q/k/v rows arrived", "scores + max", "exp + sum",
+                                 "PV + slice sums in LDS", "attention output published", "attention output arrived", "out_proj rows published", "x1 arrived",
+                                 "LayerNorm + Q8 done", "fc1 rows + GELU done", "fc1 activations published", "fc1 activations arrived", "layer output published"};
+        double seg[16] = {}, hop = 0.0;
         for (int l = 1; l < nl; l++) {
-            for (int k = 1; k < 13; k++) seg[k] += (double)(long long)(w[(size_t)l * 16 + order[k]] - w[(size_t)l * 16 + order[k - 1]]) * 0.01;
+            for (int k = 1; k < 16; k++) seg[k] += (double)(long long)(w[(size_t)l * 16 + order[k]] - w[(size_t)l * 16 + order[k - 1]]) * 0.01;
             hop += (double)(long long)(w[(size_t)l * 16] - w[(size_t)(l - 1) * 16 + 5]) * 0.01;
         }
         const double n = nl > 1 ? nl - 1 : 1;
         fprintf(stderr, "XCD pipeline: wall clock of workgroup 0 of the layer's XCD, mean over layers 1.. (us since the previous line)\n");
         fprintf(stderr, "   %-36s %6.2f   (previous layer's output published -> seen on the next XCD)\n", names[0], hop / n);
-        for (int k = 1; k < 13; k++) fprintf(stderr, "   %-36s %6.2f\n", names[k], seg[k] / n);
+        for (int k = 1; k < 16; k++) fprintf(stderr, "   %-36s %6.2f\n", names[k], seg[k] / n);
         fprintf(stderr, "   one layer = %.2f us\n", nl > 1 ? (double)(long long)(w[(size_t)(nl - 1) * 16 + 5] - w[5]) * 0.01 / n : 0.0);
         // the last layer, every workgroup of its XCD: us since workgroup 0 saw the layer input
         std::vector<unsigned long long> ws((size_t)32 * 16);
         HIP_TRY(-2, hipMemcpy(ws.data(), ctx->tstamp + (size_t)nl * 16, ws.size() * 8, hipMemcpyDeviceToHost));
-        fprintf(stderr, "   last layer, per workgroup (columns: the 13 events above):\n");
+        fprintf(stderr, "   last layer, per workgroup (columns: the 16 events above):\n");
         for (int sl = 0; sl < 32; sl++) {
             fprintf(stderr, "   wg %2d:", sl);
-            for (int k = 0; k < 13; k++) {
+            for (int k = 0; k < 16; k++) {
                 const unsigned long long t = ws[(size_t)sl * 16 + order[k]];
                 if (t == 0) fprintf(stderr, "      -"); else fprintf(stderr, " %6.2f", (double)(long long)(t - ws[0]) * 0.01);
             }

@@ -66,6 +66,9 @@ struct XpParams {
     float eps, q_scale;
     int32_t P, t_cap;
     const uint16_t *exp_tab, *gelu_tab;
+    int32_t exp_n;             // the attention workgroups keep exp_tab[0x8000 .. 0x8000 + exp_n) in LDS; every later entry up to -inf is 0 (host-checked)
+    int32_t gelu_p, gelu_n, gelu_z;   // every workgroup keeps gelu_tab[0 .. gelu_p) and [0x8000 .. 0x8000 + gelu_n) in LDS; above: identity up to
+                               //   +inf, below: the constant gelu_z down to the most negative finite value (host-checked); 0 / 0: no slice
     float *x_final;            // [1024] input of the final LayerNorm + lm_head launch
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
 };
@@ -145,7 +148,7 @@ constexpr int XP_S_REDD = XP_S_REDF + 128;       // [16] double
 constexpr int XP_S_PV = XP_S_REDD + 128;         // [1024] double
 constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 192 * DEC_PS, "fc2 block terms fit the shared region");
-__host__ __device__ inline size_t xpipe_smem_bytes() { return XP_S_TOTAL; }
+__host__ __device__ inline size_t xpipe_smem_bytes(int exp_n, int gelu_entries) { return XP_S_TOTAL + (size_t)exp_n * 2 + (size_t)gelu_entries * 2; }
 
 // stacked [q; k; v] row computed by lane group j (0..95) of workgroup `slot`: workgroups h and h + 16 share head h
 __device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
@@ -180,6 +183,8 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 64);
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
+    uint16_t *const s_exp = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+    uint16_t *const s_gelu = s_exp + p.exp_n;
 
     // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
     // launches: launch e hands out 32 (e - 1) .. 32 e - 1) says which.  The dispatcher deals workgroups round-robin over the
@@ -200,6 +205,22 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     const int T = n_past + 1;
     const int t_cap = p.t_cap;
 
+    // softmax numerators: exp(score - max) through ggml's fp16 table (biogpt.cpp:748 -> ggml_soft_max).  score - max <= 0, and
+    // exp underflows to fp16 zero below -17.4: the attention workgroups keep that slice of the table (39 KB) in LDS for the
+    // whole launch instead of gathering from L2 in every layer
+    const uint16_t exp_of_zero = p.exp_tab[0];
+    if (slot < 16) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
+        for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_exp)[i] = src[i];
+    }
+    // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
+    // in fp16) nor -0 (x <= -5.42): kept in LDS for the whole launch, fc1's 128 rows per workgroup look it up there
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
+        const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
+        for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
+        for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
+    }
     for (int L = xcd; L < p.n_layer; L += 8) {
         // the thread index goes through an empty asm in every iteration: without it the compiler hoists a few hundred
         // per-thread addresses (LDS carve, granule slots, weight rows) out of the layer loop and spills them (120 VGPRs
@@ -405,9 +426,17 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             mx = s_redf[0];
 #pragma unroll
             for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
+            XP_WALL(13);
             double sum = 0.0;
             if (kidx < T && ksub == 0) {
-                const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);
+                const uint32_t ix = f2h(__fsub_rn(sc, mx));
+                const uint32_t off = ix - 0x8000u;
+                uint16_t e16;
+                if (ix == 0u) e16 = exp_of_zero;
+                else if (off < (uint32_t)p.exp_n) e16 = s_exp[off];
+                else if (off <= 0x7C00u) e16 = 0;                       // ... down to -inf: all zero in the table (checked by the host)
+                else e16 = p.exp_tab[ix];                               // NaN (or a positive difference: impossible for finite scores)
+                const float val = h2f(e16);
                 s_S[kidx] = val;
                 sum = (double)val;
             }
@@ -418,18 +447,30 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
 #pragma unroll
             for (int w = 0; w < NW; w++) sum += s_redd[w];
             const float inv = inv_sum_f32(sum);
+            XP_WALL(14);
             {
+                // all LDS reads first, no branches in the loop: a key past the context adds +0.0 (exact), never its stale weight
                 const float vcur = s_cur[128 + dd];
+                constexpr int CH = NV < 16 ? NV : 16;      // softmax weights fetched 16 at a time (register budget at 256 keys)
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < NV; k += 2) {
-                    const int j0 = sl + NW * k, j1 = j0 + NW;
-                    if (j0 < T) a0 += (double)__fmul_rn(j0 == n_past ? vcur : vr[k], __fmul_rn(s_S[j0], inv));
-                    if (j1 < T) a1 += (double)__fmul_rn(j1 == n_past ? vcur : vr[k + 1], __fmul_rn(s_S[j1], inv));
+                for (int k0 = 0; k0 < NV; k0 += CH) {
+                    float pj[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; k++) pj[k] = s_S[sl + NW * (k0 + k)];
+#pragma unroll
+                    for (int k = 0; k < CH; k += 2) {
+                        const int j0 = sl + NW * (k0 + k), j1 = j0 + NW;
+                        const double c0 = (double)__fmul_rn(j0 == n_past ? vcur : vr[k0 + k], __fmul_rn(pj[k], inv));
+                        const double c1 = (double)__fmul_rn(j1 == n_past ? vcur : vr[k0 + k + 1], __fmul_rn(pj[k + 1], inv));
+                        a0 += (j0 < T) ? c0 : 0.0;
+                        a1 += (j1 < T) ? c1 : 0.0;
+                    }
                 }
                 s_pv[tid] = a0 + a1;
             }
             __syncthreads();
+            XP_WALL(15);
             if (tid < DK) {
                 double t0 = 0.0, t1 = 0.0;
 #pragma unroll
@@ -502,7 +543,14 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             if (lane < 2 * FS) {
                 const int jr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
                 const float v = __fadd_rn(s_bias[224 + jr], sum32_in_order(part + lane * DEC_PS));
-                s_g[jr] = h2f(p.gelu_tab[f2h(v)]);                            // ggml_gelu: fp16 table
+                const uint32_t ix = f2h(v), neg = ix - 0x8000u;               // ggml_gelu: fp16 table
+                uint16_t g16;
+                if (ix < (uint32_t)p.gelu_p) g16 = s_gelu[ix];
+                else if (ix <= 0x7C00u) g16 = (p.gelu_p > 0) ? (uint16_t)ix : p.gelu_tab[ix];
+                else if (neg < (uint32_t)p.gelu_n) g16 = s_gelu[p.gelu_p + neg];
+                else if (neg < 0x7C00u && p.gelu_n > 0) g16 = (uint16_t)p.gelu_z;
+                else g16 = p.gelu_tab[ix];                                     // -inf, NaN (or no slice in LDS)
+                s_g[jr] = h2f(g16);
             }
         }
         __syncthreads();
