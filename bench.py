@@ -249,6 +249,20 @@ def main():
                     per[name] = {"GBps": round(bk / sk / 1e9, 1), "us": round(sk * 1e6, 3), "bytes": bk, "frac": round(bk / sk / 1e9 / HBM_PEAK_GBS, 4)}
                 secs, nbytes = per["fc1"]["us"] * 1e-6, per["fc1"]["bytes"]
                 kname = "dec_fc1_kernel<%s> (fc1 %dx%d: LayerNorm + W*A8 mat-vec + GELU + Q8 output, 24 launches/token)" % (args.ftype.upper(), hp.d_ff, hp.d_model)
+                method = None
+                if model.xpipe_state() == 1:
+                    # the decode step of this run is ONE persistent launch for all layers (csrc/kernels_xpipe.hip.h) + the lm_head launch:
+                    # that launch is the dominant kernel; the five-launch layer above stays as the fallback's figures
+                    sx, bx = model.bench_matvec(11, layer=0, reps=40)
+                    per["five_launch_layer_fc1"] = per.pop("fc1")
+                    per = {("five_launch_layer_" + k if not k.startswith("five_") else k): v for k, v in per.items()}
+                    secs, nbytes = sx, bx
+                    kname = ("dec_xpipe_kernel<%s> (all %d layers of one token at 104 keys in ONE persistent launch, layer l on the 32 compute units of XCD l %% 8, "
+                             "weights stationary in registers, hand-offs through the XCD's L2; 1 launch/token)" % (args.ftype.upper(), hp.n_layer))
+                    method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel (hipGraph, as the decode step is replayed), real arena weights; "
+                              "algorithmic bytes = the four matrices of every layer at file density + K / V rows of 104 keys + the new K / V rows + x in / out; "
+                              "the launch is LATENCY-bound by design: a layer is %.1f us of dependent stages (profiles/xpipe_timeline_r2.txt) on 1/8 of the chip while the "
+                              "other XCDs prefetch -- 8 TB/s would move a layer's 7.1 MB in 0.9 us" % (sx * 1e6 / hp.n_layer))
             else:
                 secs, nbytes = model.bench_matvec(0, layer=0, reps=reps)        # fc1: LN + mat-vec + GELU (generic kernels)
                 secs2, nbytes2 = model.bench_matvec(1, layer=0, reps=reps)
@@ -264,9 +278,10 @@ def main():
                 # passes are committed under profiles/ (pmc_*_r2.txt); the line itself carries no borrowed constant
                 "traffic": None,
                 "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
-                "method": "HIP events on the engine stream around %d back-to-back launches of this ONE kernel (hipGraph replays of one sweep over the layers, as the decode step is replayed) cycling through the 24 layers' own "
-                          "arena weights (no L2 reuse between launches; the 211 MB arena fits the 256 MB Infinity Cache); model shapes only -- "
-                          "a launch moves %.1f MB, which 8 TB/s would move in %.2f us, against a measured ~1.3-1.6 us launch boundary" % (reps, nbytes / 1e6, nbytes / 8e6),
+                "method": (method if quant and method else
+                           "HIP events on the engine stream around %d back-to-back launches of this ONE kernel (hipGraph replays of one sweep over the layers, as the decode step is replayed) cycling through the 24 layers' own "
+                           "arena weights (no L2 reuse between launches; the 211 MB arena fits the 256 MB Infinity Cache); model shapes only -- "
+                           "a launch moves %.1f MB, which 8 TB/s would move in %.2f us, against a measured ~1.3-1.6 us launch boundary" % (reps, nbytes / 1e6, nbytes / 8e6)),
                 "other_kernels": per,
             }
             if args.ftype == "q4_0":
@@ -284,6 +299,7 @@ def main():
                                    "GBps": round(b / s / 1e9, 1), "frac_of_peak": round(b / s / 1e9 / HBM_PEAK_GBS, 4),
                                    "bytes_per_token": int(b)}
             out["token_roofline"] = tok
+            out["decode_path"] = "xcd-pipeline (1 persistent launch per token + lm_head)" if model.xpipe_state() == 1 else "five launches per layer + lm_head"
             # batched multi-sequence decode on this one GPU (biogpt_hip_generate_greedy_batch): S independent
             # 200-token continuations decoded together, weights read once per step for all S -- NOT the headline
             # (configs[1] is single-stream), reported because it is what the HBM-bound regime of this chip looks like

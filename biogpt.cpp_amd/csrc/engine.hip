@@ -788,6 +788,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     unsigned long long *const wall = (c->opt.dbg & 64) ? c->tstamp + 128 : nullptr;
     if (l1 < 0) l1 = hp.n_layer;
     const bool pipelined = only < 0 && l0 == 0 && l1 == hp.n_layer && tok_src != 0 && xpipe_usable(c, t_max);
+    if (only == -2 && !pipelined) BG_FAIL(false, "the XCD-pipelined decode step is not available for this context");
     if (pipelined) {
         bgk::XpParams xp{};
         xp.layers = c->xp_layers; xp.n_layer = hp.n_layer; xp.gran = c->xp_gran; xp.ctl = c->xp_ctl; xp.err_host = c->xp_err_host;
@@ -860,7 +861,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         }
         HIP_TRY(false, e);
     }
-    if (only >= 0 || l1 < hp.n_layer) return true;   // one kernel (bench) or a leading segment of the step: no lm_head
+    if (only >= 0 || only == -2 || l1 < hp.n_layer) return true;   // one kernel (bench) or a leading segment of the step: no lm_head
     {  // final LayerNorm + lm_head (last row only, F8) + per-workgroup arg-max partials; block 0 advances the position
         const MatSlot &m = c->plan.lm_head;
         const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
@@ -1909,7 +1910,7 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 10) BG_FAIL(-1, "bad argument");
+    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 11) BG_FAIL(-1, "bad argument");
     if (which >= 6 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     t_ctx = ctx;
@@ -1923,6 +1924,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
                        !opt().no_fast && !opt().no_chain;
     auto launch = [&](int l) -> bool {
         ctx->launch_parity ^= 1;
+        if (which == 11) return enqueue_decode_fused(ctx, 104, 1, 0, 0, -1, -2);   // the XCD-pipelined launch alone: all layers of one token at 104 keys, no lm_head
         if (which >= 6 && which <= 10) {   // one kernel of the five-launch decode layer (kernels_decode.hip.h), layer l mod L, `layer` = n_past for attention
             const int ll = l % hp.n_layer;
             return enqueue_decode_fused(ctx, 104, 0, 0, ll, ll + 1, which - 6);
@@ -1994,7 +1996,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     if (which >= 6) {
         // the decode-layer kernels finish faster than the host can launch them one by one (~3.3 us per eager launch):
         // capture one sweep over the layers and time graph replays, as the decode step itself is replayed
-        const int per = std::max(1, hp.n_layer);
+        const int per = which == 11 ? 4 : std::max(1, hp.n_layer);
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -2047,6 +2049,13 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     }
     if (bytes_out) {
         if (which == 5) { *bytes_out = 2.0 * (layer + 1) * D * 4; return 0; }  // K and V rows of one layer
+        if (which == 11) {   // every layer's four matrices + K / V rows at 104 keys + the new K / V rows + one x column in and out
+            double b = 0.0;
+            for (const auto &L : ctx->plan.layers)
+                for (const MatSlot *m : {&L.qkv, &L.o, &L.fc1, &L.fc2}) b += (double)file_row_bytes(m->type, m->K) * (double)m->M;
+            *bytes_out = b + hp.n_layer * (2.0 * 104 * D * 4 + 2.0 * D * 4) + 8.0 * D;
+            return 0;
+        }
         if (which == 7) { *bytes_out = 2.0 * 104 * D * 4 + 4.0 * D + 1.0 * D + 8.0 * (D / 32); return 0; }   // K, V rows at 104 keys + q + Q8 output
         if (which >= 6) {   // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
             const MatSlot *m6 = which == 6 ? &ctx->plan.layers[0].qkv : which == 8 ? &ctx->plan.layers[0].o : which == 9 ? &ctx->plan.layers[0].fc1 : &ctx->plan.layers[0].fc2;

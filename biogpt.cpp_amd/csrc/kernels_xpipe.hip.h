@@ -434,8 +434,8 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
                 uint16_t e16;
                 if (ix == 0u) e16 = exp_of_zero;
                 else if (off < (uint32_t)p.exp_n) e16 = s_exp[off];
-                else if (off <= 0x7C00u) e16 = 0;                       // ... down to -inf: all zero in the table (checked by the host)
-                else e16 = p.exp_tab[ix];                               // NaN (or a positive difference: impossible for finite scores)
+                else if (off <= 0x7C00u && p.exp_n > 0) e16 = 0;        // ... down to -inf: all zero in the table (checked by the host)
+                else e16 = p.exp_tab[ix];                               // no slice in LDS; NaN (a positive difference is impossible)
                 const float val = h2f(e16);
                 s_S[kidx] = val;
                 sum = (double)val;

@@ -22,5 +22,7 @@ for t in q5_1 q8_0 q4_1 q5_0 f16; do python bench.py --ftype $t --steps 3 --warm
 python bench.py --ftype f32 --steps 2 --warmup 1 --cpu-seconds 12 > $OUT/bench_r2_f32.json 2>/dev/null
 python bench.py --workload prefill --no-cpu-baseline > $OUT/bench_r2_prefill_q4_0.json 2>/dev/null
 BIOGPT_BENCH_CHUNK_CALLS=1 python bench.py --workload prefill --no-cpu-baseline > $OUT/bench_r2_prefill_q4_0_per_eval.json 2>/dev/null
-BIOGPT_HIP_DBG=96 BIOGPT_HIP_LIB=$PWD/biogpt.cpp_amd/libbiogpt_hip_prof.so python tools/decode_timeline.py $M 103 > $OUT/decode_timeline_r2.txt 2>&1
+BIOGPT_HIP_XPIPE=0 BIOGPT_HIP_DBG=96 BIOGPT_HIP_LIB=$PWD/biogpt.cpp_amd/libbiogpt_hip_prof.so python tools/decode_timeline.py $M 103 > $OUT/decode_timeline_r2.txt 2>&1
+for n in 40 103 200; do BIOGPT_HIP_DBG=128 BIOGPT_HIP_LIB=$PWD/biogpt.cpp_amd/libbiogpt_hip_prof.so python tools/decode_timeline.py $M $n; done > $OUT/xpipe_timeline_r2.txt 2>&1
+[ -x tools/microbench11 ] && timeout 120 tools/microbench11 > $OUT/microbench11_xcd_pipeline_r2.txt 2>&1
 ls -la $OUT
