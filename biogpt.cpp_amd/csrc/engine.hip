@@ -167,7 +167,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -193,7 +193,8 @@ struct EngineOptions {
         qkv_waves = get("BIOGPT_HIP_QKV_WAVES", 8);
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
-        xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // fp16 table slices kept in LDS by the pipeline: 1 GELU, 2 exp (3: both if they fit)
+        xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
+        xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
@@ -268,7 +269,6 @@ struct biogpt_hip_ctx {
     uint32_t *xp_ctl = nullptr;
     uint32_t *xp_err_host = nullptr;
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
-    int xp_exp_n = 0;                      // entries of the exp table's negative half the attention workgroups keep in LDS
     int xp_gelu_p = 0, xp_gelu_n = 0, xp_gelu_z = 0;   // the GELU table's slices every workgroup keeps in LDS (kernels_xpipe.hip.h)
     int xp_state = 0;                      // 0 not probed, 1 usable, -1 unusable on this device / model / after a failure
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
@@ -596,7 +596,7 @@ bool xpipe_set_lds_t(size_t sm) {
 }
 // > 64 KB of dynamic LDS needs the opt-in attribute (per device); set outside any stream capture
 bool xpipe_set_lds(biogpt_hip_ctx *c) {
-    const size_t sm = bgk::xpipe_smem_bytes(c->xp_exp_n, c->xp_gelu_p + c->xp_gelu_n);
+    const size_t sm = bgk::xpipe_smem_bytes(c->xp_gelu_p + c->xp_gelu_n);
     if (sm <= 64 * 1024) return true;
     switch (ftype_to_type(c->hp.ftype)) {
         case T_Q4_0: return xpipe_set_lds_t<bgk::W_Q4_0>(sm);
@@ -651,12 +651,8 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         const uint32_t one = 1u;
         (void)hipMemcpy(c->xp_ctl + 8, &one, 4, hipMemcpyHostToDevice);
     }
-    {   // the exp table (built by upload_weights exactly like this) is 0 from some negative argument down to -inf: keep the rest in LDS
-        int n = 0;
-        for (uint32_t k = 0; k <= 0x7C00u; k++)
-            if (f32_to_f16(expf(f16_to_f32((uint16_t)(0x8000u + k)))) != 0) n = (int)k + 1;
-        n = (n + 7) & ~7;
-        // the GELU table (same construction): identity from some positive argument up to +inf, one constant from some negative
+    {
+        // the GELU table, rebuilt exactly as upload_weights builds it: identity from some positive argument up to +inf, one constant from some negative
         // argument down to the most negative finite value
         std::vector<uint16_t> tg(65536);
         for (uint32_t i = 0; i < 65536; i++) tg[i] = f32_to_f16(gelu_tanh_f32(f16_to_f32((uint16_t)i)));
@@ -668,9 +664,8 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         P = (P + 7) & ~7; N = (N + 7) & ~7;
         const size_t lds_max = 160 * 1024;
         if (c->opt.xpipe_tables & 1) {
-            if (P <= 0x7C00 && N <= 0x7C00 && bgk::xpipe_smem_bytes(0, P + N) <= lds_max) { c->xp_gelu_p = P; c->xp_gelu_n = N; c->xp_gelu_z = Z; }
+            if (P <= 0x7C00 && N <= 0x7C00 && bgk::xpipe_smem_bytes(P + N) <= lds_max) { c->xp_gelu_p = P; c->xp_gelu_n = N; c->xp_gelu_z = Z; }
         }
-        if ((c->opt.xpipe_tables & 2) && bgk::xpipe_smem_bytes(n, c->xp_gelu_p + c->xp_gelu_n) <= lds_max) c->xp_exp_n = n;
     }
     if (!xpipe_set_lds(c)) { (void)hipGetLastError(); xpipe_release(c); return; }
     *c->xp_err_host = 0u;
@@ -701,7 +696,7 @@ bool xpipe_check(biogpt_hip_ctx *c) {
 
 template <int WT>
 hipError_t launch_xpipe(biogpt_hip_ctx *c, const bgk::XpParams &xp) {
-    const size_t sm = bgk::xpipe_smem_bytes(xp.exp_n, xp.gelu_p + xp.gelu_n);
+    const size_t sm = bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n);
     // 8 waves per workgroup: 24 weight units per lane (120 VGPRs) + the head's old keys / values fit the 256-register budget
     if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8>), dim3(256), dim3(512), sm, c->stream, xp);
     else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8>), dim3(256), dim3(512), sm, c->stream, xp);
@@ -788,6 +783,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     unsigned long long *const wall = (c->opt.dbg & 64) ? c->tstamp + 128 : nullptr;
     if (l1 < 0) l1 = hp.n_layer;
     const bool pipelined = only < 0 && l0 == 0 && l1 == hp.n_layer && tok_src != 0 && xpipe_usable(c, t_max);
+    bool lm_in_kernel = false;
     if (only == -2 && !pipelined) BG_FAIL(false, "the XCD-pipelined decode step is not available for this context");
     if (pipelined) {
         bgk::XpParams xp{};
@@ -802,8 +798,18 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.P = P; xp.t_cap = std::min(P, (t_max + 63) & ~63);
         xp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
         xp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
-        xp.exp_n = c->xp_exp_n; xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z;
+        xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z;
         xp.x_final = c->x;
+        {   // lm_head inside the launch: its 64-row blocks (= the stand-alone launch's workgroups) three per workgroup of 7 XCDs
+            const MatSlot &m = c->plan.lm_head;
+            const bool fold = c->opt.xpipe_lm && m.type == wt && m.K == 1024 && m.M == V && lm_parts == (V + 63) / 64 && lm_parts <= 3 * 224;
+            xp.lm = fold ? 1 : 0;
+            xp.lm_blocks = lm_parts; xp.adv = advance;
+            xp.Wlm = dev_matrix(c, m);
+            xp.lm_ln_w = dev_vec(c, c->plan.ln_w); xp.lm_ln_b = dev_vec(c, c->plan.ln_b);
+            xp.logits = c->logits; xp.pmax_out_val = c->pmax_val; xp.pmax_out_idx = c->pmax_idx;
+            lm_in_kernel = fold;
+        }
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
         hipError_t e = hipErrorInvalidValue;
         switch (wt) {
@@ -861,6 +867,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         }
         HIP_TRY(false, e);
     }
+    if (lm_in_kernel) { c->lm_blocks = lm_parts; return true; }   // the pipelined launch wrote the logits, the partials and moved the position
     if (only >= 0 || only == -2 || l1 < hp.n_layer) return true;   // one kernel (bench) or a leading segment of the step: no lm_head
     {  // final LayerNorm + lm_head (last row only, F8) + per-workgroup arg-max partials; block 0 advances the position
         const MatSlot &m = c->plan.lm_head;
@@ -2053,7 +2060,9 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             double b = 0.0;
             for (const auto &L : ctx->plan.layers)
                 for (const MatSlot *m : {&L.qkv, &L.o, &L.fc1, &L.fc2}) b += (double)file_row_bytes(m->type, m->K) * (double)m->M;
-            *bytes_out = b + hp.n_layer * (2.0 * 104 * D * 4 + 2.0 * D * 4) + 8.0 * D;
+            b += hp.n_layer * (2.0 * 104 * D * 4 + 2.0 * D * 4) + 8.0 * D;
+            if (ctx->opt.xpipe_lm) b += (double)file_row_bytes(ctx->plan.lm_head.type, ctx->plan.lm_head.K) * (double)ctx->plan.lm_head.M + 4.0 * V;   // + the output projection and the logits row
+            *bytes_out = b;
             return 0;
         }
         if (which == 7) { *bytes_out = 2.0 * 104 * D * 4 + 4.0 * D + 1.0 * D + 8.0 * (D / 32); return 0; }   // K, V rows at 104 keys + q + Q8 output

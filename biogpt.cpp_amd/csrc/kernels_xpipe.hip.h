@@ -66,10 +66,17 @@ struct XpParams {
     float eps, q_scale;
     int32_t P, t_cap;
     const uint16_t *exp_tab, *gelu_tab;
-    int32_t exp_n;             // the attention workgroups keep exp_tab[0x8000 .. 0x8000 + exp_n) in LDS; every later entry up to -inf is 0 (host-checked)
     int32_t gelu_p, gelu_n, gelu_z;   // every workgroup keeps gelu_tab[0 .. gelu_p) and [0x8000 .. 0x8000 + gelu_n) in LDS; above: identity up to
                                //   +inf, below: the constant gelu_z down to the most negative finite value (host-checked); 0 / 0: no slice
-    float *x_final;            // [1024] input of the final LayerNorm + lm_head launch
+    float *x_final;            // [1024] input of the final LayerNorm + lm_head launch (written also when the lm_head runs in here)
+    // final LayerNorm + lm_head inside this launch (lm != 0): the workgroups of the XCDs that do NOT compute the last layer take
+    // three 64-row blocks of the output projection each -- the blocks, and the per-block arg-max partials, of the stand-alone
+    // lm_head launch (matvec_fast_kernel<EPI_LOGITS>, 64 rows per workgroup), so every consumer of the partials is unchanged
+    int32_t lm, lm_blocks, adv;
+    DevMatrix Wlm;
+    const float *lm_ln_w, *lm_ln_b;
+    float *logits;
+    float *pmax_out_val; int32_t *pmax_out_idx;
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
 };
 
@@ -143,12 +150,12 @@ constexpr int XP_S_LN = XP_S_G + 512;            // [4][1024] f32 ln0_w, ln0_b, 
 constexpr int XP_S_BIAS = XP_S_LN + 16384;       // [192 + 32 + 128 + 32] f32: q/k/v rows of the head, out_proj / fc1 / fc2 rows of the workgroup
 constexpr int XP_S_CUR = XP_S_BIAS + 1536;       // [192] f32 q, k, v of this token (head = slot)
 constexpr int XP_S_S = XP_S_CUR + 768;           // [256] softmax numerators
-constexpr int XP_S_REDF = XP_S_S + 1024;         // [16] f32 + [16] int
-constexpr int XP_S_REDD = XP_S_REDF + 128;       // [16] double
+constexpr int XP_S_REDF = XP_S_S + 1024;         // [48] f32 + [48] int
+constexpr int XP_S_REDD = XP_S_REDF + 384;       // [16] double
 constexpr int XP_S_PV = XP_S_REDD + 128;         // [1024] double
 constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 192 * DEC_PS, "fc2 block terms fit the shared region");
-__host__ __device__ inline size_t xpipe_smem_bytes(int exp_n, int gelu_entries) { return XP_S_TOTAL + (size_t)exp_n * 2 + (size_t)gelu_entries * 2; }
+__host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP_S_TOTAL + (size_t)gelu_entries * 2; }
 
 // stacked [q; k; v] row computed by lane group j (0..95) of workgroup `slot`: workgroups h and h + 16 share head h
 __device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
@@ -180,11 +187,10 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
     float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
     float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
-    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 64);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 192);
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
-    uint16_t *const s_exp = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
-    uint16_t *const s_gelu = s_exp + p.exp_n;
+    uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
 
     // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
     // launches: launch e hands out 32 (e - 1) .. 32 e - 1) says which.  The dispatcher deals workgroups round-robin over the
@@ -205,14 +211,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     const int T = n_past + 1;
     const int t_cap = p.t_cap;
 
-    // softmax numerators: exp(score - max) through ggml's fp16 table (biogpt.cpp:748 -> ggml_soft_max).  score - max <= 0, and
-    // exp underflows to fp16 zero below -17.4: the attention workgroups keep that slice of the table (39 KB) in LDS for the
-    // whole launch instead of gathering from L2 in every layer
-    const uint16_t exp_of_zero = p.exp_tab[0];
-    if (slot < 16) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
-        for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_exp)[i] = src[i];
-    }
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
     // in fp16) nor -0 (x <= -5.42): kept in LDS for the whole launch, fc1's 128 rows per workgroup look it up there
     {
@@ -429,14 +427,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             XP_WALL(13);
             double sum = 0.0;
             if (kidx < T && ksub == 0) {
-                const uint32_t ix = f2h(__fsub_rn(sc, mx));
-                const uint32_t off = ix - 0x8000u;
-                uint16_t e16;
-                if (ix == 0u) e16 = exp_of_zero;
-                else if (off < (uint32_t)p.exp_n) e16 = s_exp[off];
-                else if (off <= 0x7C00u && p.exp_n > 0) e16 = 0;        // ... down to -inf: all zero in the table (checked by the host)
-                else e16 = p.exp_tab[ix];                               // no slice in LDS; NaN (a positive difference is impossible)
-                const float val = h2f(e16);
+                const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);   // ggml_soft_max: fp16 exp table
                 s_S[kidx] = val;
                 sum = (double)val;
             }
@@ -635,6 +626,84 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         XP_WALL(5);
         __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next layer of this XCD
         if (L == p.n_layer - 1 && slot == 0 && tid == 0) __hip_atomic_store(p.ctl, epoch + 1u, XP_RLX);   // every workgroup read it long ago
+    }
+    // ================= final LayerNorm + lm_head (biogpt.cpp:799-811): the XCDs that are done with their layers =================
+    // Their weights (three 64-row blocks = 12 units per lane) are loaded as soon as the workgroup's last layer is finished --
+    // 1 .. 7 layers before the last layer's output exists -- so the logits cost one hop + LayerNorm + 12 block dots instead of
+    // a launch boundary plus a 24.6 MB stream.
+    const int last_xcd = (p.n_layer - 1) & 7;
+    if (p.lm != 0 && xcd != last_xcd) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int sub = lane & 31, rsub = lane >> 5;
+        const bool worker = tid < 256;
+        constexpr int LMS = 96 / NW;                                          // 2-row steps per wave: 192 rows per workgroup
+        const int rank = slot + 32 * (xcd < last_xcd ? xcd : xcd - 1);       // 0 .. 223
+        const int row0 = rank * 192;
+        if (rank * 3 >= p.lm_blocks) return;
+        Unit<WT> wl[LMS];
+#pragma unroll
+        for (int s = 0; s < LMS; s++) {
+            const int row = row0 + s * 2 * NW + wave * 2 + rsub;
+            if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
+            else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
+        }
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
+        if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
+        if (wave < 4) {
+            uint32_t v[4];
+            xp_sweep<4, 256>(p.gran + (size_t)(p.n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+            xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+        ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+        uint32_t ax[8];
+        const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+        const float axd = s_xd[sub];
+        const uint32_t axs = s_xs[sub];
+        float *const part = s_part + wave * 2 * LMS * DEC_PS;
+#pragma unroll
+        for (int s = 0; s < LMS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane < 2 LMS finishes local row (lane >> 1) 2 NW + 2 wave + (lane & 1); with NW = 8 lanes 8 j .. 8 j + 7 hold rows of block j
+        float best_val = -INFINITY;
+        int best_idx = 0x7fffffff;
+        if (lane < 2 * LMS) {
+            const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+            if (row < p.n_vocab) {
+                const float v = sum32_in_order(part + lane * DEC_PS);
+                p.logits[row] = v;
+                best_val = v; best_idx = row;
+            }
+        }
+        // per-block partial arg-max (lowest index wins ties): groups of 8 lanes, then the 8 waves through LDS
+#pragma unroll
+        for (int off = 1; off < 64 / NW; off <<= 1) {
+            const float ov = __shfl_xor(best_val, off, 64);
+            const int oi = __shfl_xor(best_idx, off, 64);
+            if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
+        }
+        static_assert(NW == 8 || NW == 16, "block of a finisher lane = lane / (64 / NW)");
+        constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
+        if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
+        __syncthreads();
+        if (tid < 3) {
+            float bv = s_redf[tid * NW];
+            int bi = s_redi[tid * NW];
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+                const float ov = s_redf[tid * NW + w];
+                const int oi = s_redi[tid * NW + w];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const int blk = rank * 3 + tid;
+            if (blk < p.lm_blocks) { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
+            // every workgroup read the position when it started, long before the last layer's output existed
+            if (blk == 0 && p.adv != 0) { p.st->n_past += p.adv; p.st->n_gen += p.adv; }
+        }
     }
 }
 
