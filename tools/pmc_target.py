@@ -12,6 +12,6 @@ if len(sys.argv) > 2 and sys.argv[2] == "prefill":
     g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
     g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
 else:
-    for which in (6, 7, 8, 9, 10, 4):
+    for which in (6, 7, 8, 9, 10, 4) + ((11,) if g.xpipe_state() == 1 else ()):   # 11: the XCD-pipelined launch (all layers + lm_head)
         s, b = g.bench_matvec(which, 0, 48)
         print(which, round(s * 1e6, 2), "us", b, "bytes", flush=True)
