@@ -167,7 +167,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -194,6 +194,7 @@ struct EngineOptions {
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
         xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
+        xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
@@ -267,6 +268,7 @@ struct biogpt_hip_ctx {
     bgk::XpLayer *xp_layers = nullptr;
     bgk::xp_u64 *xp_gran = nullptr;
     uint32_t *xp_ctl = nullptr;
+    bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
     int xp_gelu_p = 0, xp_gelu_n = 0, xp_gelu_z = 0;   // the GELU table's slices every workgroup keeps in LDS (kernels_xpipe.hip.h)
@@ -575,8 +577,9 @@ void xpipe_release(biogpt_hip_ctx *c) {
     if (c->xp_layers) (void)hipFree(c->xp_layers);
     if (c->xp_gran) (void)hipFree(c->xp_gran);
     if (c->xp_ctl) (void)hipFree(c->xp_ctl);
+    if (c->xp_samp) (void)hipFree(c->xp_samp);
     if (c->xp_err_host) (void)hipHostFree(c->xp_err_host);
-    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_ctl = nullptr; c->xp_err_host = nullptr;
+    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
 }
 
 bool xpipe_model_ok(const biogpt_hip_ctx *c) {
@@ -637,12 +640,13 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         y.kcache = c->memory_k + (size_t)l * P * D; y.vcache = c->memory_v + (size_t)l * P * D;
     }
     const size_t gbytes = (size_t)hp.n_layer * bgk::XP_G_LAYER * 8;
-    const uint32_t ctl0[2] = {1u, 0u};
+    const uint32_t ctl0[3] = {1u, 0u, 1u};   // hand-off tag, error word, launch counter
     if (hipMalloc(&c->xp_layers, tab.size() * sizeof(bgk::XpLayer)) != hipSuccess || hipMalloc(&c->xp_gran, gbytes) != hipSuccess ||
         hipMalloc(&c->xp_ctl, 64) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->xp_err_host), 64, hipHostMallocDefault) != hipSuccess ||
         hipMemcpy(c->xp_layers, tab.data(), tab.size() * sizeof(bgk::XpLayer), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->xp_gran, 0, gbytes) != hipSuccess || hipMemset(c->xp_ctl, 0, 64) != hipSuccess ||
-        hipMemcpy(c->xp_ctl, ctl0, 8, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(c->xp_ctl, ctl0, 12, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&c->xp_samp, 2048 * 8) != hipSuccess || hipMemset(c->xp_samp, 0, 2048 * 8) != hipSuccess) {
         (void)hipGetLastError();
         xpipe_release(c);
         return;
@@ -692,6 +696,22 @@ bool xpipe_check(biogpt_hip_ctx *c) {
     for (auto &f : c->graph_eval) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     BG_FAIL(false, "the XCD-pipelined decode step failed (code %u: %s); this context now uses the five-launch layer", code,
             code == 2u ? "its workgroups were not dealt 32 per XCD -- another stream's kernels were dispatched in between" : "a hand-off timed out");
+}
+
+int graph_bucket(int T);
+int bucket_tmax(const biogpt_hip_ctx *c, int b);
+int fast_lm_grid(const biogpt_hip_ctx *c);
+bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max);
+// tokens one pipelined launch may generate from context T = n_past + 1 on: up to the end of T's context bucket (0: not on the pipeline)
+int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
+    if (!c->opt.xpipe_multi || !c->opt.xpipe_lm) return 0;
+    const int tmax = bucket_tmax(c, graph_bucket(T));
+    if (!fused_decode_ok(c, tmax) || !xpipe_usable(c, tmax)) return 0;
+    const auto &hp = c->hp;
+    const MatSlot &m = c->plan.lm_head;
+    const int lm_parts = fast_lm_grid(c), last_xcd = (hp.n_layer - 1) & 7, lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));
+    if (!(m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024)) return 0;
+    return tmax - T + 1;
 }
 
 template <int WT>
@@ -770,7 +790,7 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 }
 
 // l0 / l1 / only: biogpt_hip_bench_matvec launches one kernel of one layer; the decode step is all layers + lm_head
-bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1) {
+bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1) {
     t_ctx = c;
     (void)hipGetLastError();
     const auto &hp = c->hp;
@@ -784,6 +804,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     if (l1 < 0) l1 = hp.n_layer;
     const bool pipelined = only < 0 && l0 == 0 && l1 == hp.n_layer && tok_src != 0 && xpipe_usable(c, t_max);
     bool lm_in_kernel = false;
+    if (n_tok > 1 && !pipelined) BG_FAIL(false, "internal: multi-token launches exist on the XCD pipeline only");
     if (only == -2 && !pipelined) BG_FAIL(false, "the XCD-pipelined decode step is not available for this context");
     if (pipelined) {
         bgk::XpParams xp{};
@@ -802,13 +823,15 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.x_final = c->x;
         {   // lm_head inside the launch: its 64-row blocks (= the stand-alone launch's workgroups) three per workgroup of 7 XCDs
             const MatSlot &m = c->plan.lm_head;
-            const bool fold = c->opt.xpipe_lm && m.type == wt && m.K == 1024 && m.M == V && lm_parts == (V + 63) / 64 && lm_parts <= 3 * 224;
+            const int last_xcd = (hp.n_layer - 1) & 7, lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last layer's XCD take no part
+            const bool fold = c->opt.xpipe_lm && m.type == wt && m.K == 1024 && m.M == V && lm_parts == (V + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
             xp.lm = fold ? 1 : 0;
-            xp.lm_blocks = lm_parts; xp.adv = advance;
+            xp.lm_blocks = lm_parts; xp.adv = fold ? advance : 0; xp.n_tok = n_tok; xp.samp = c->xp_samp;   // no lm_head in here: the lm_head launch moves the position
             xp.Wlm = dev_matrix(c, m);
             xp.lm_ln_w = dev_vec(c, c->plan.ln_w); xp.lm_ln_b = dev_vec(c, c->plan.ln_b);
             xp.logits = c->logits; xp.pmax_out_val = c->pmax_val; xp.pmax_out_idx = c->pmax_idx;
             lm_in_kernel = fold;
+            if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
         }
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
         hipError_t e = hipErrorInvalidValue;
@@ -1706,7 +1729,11 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
             if (!enqueue_argmax(ctx, 0)) return -2;
             pending = false;
         }
-        if (use_graph) {
+        const int multi = pending ? std::min(xpipe_multi_tokens(ctx, T), n_predict - k) : 0;
+        if (multi > 1) {   // the generation loop itself runs on the device: `multi` tokens in ONE launch (kernels_xpipe.hip.h)
+            if (!enqueue_decode_fused(ctx, bucket_tmax(ctx, graph_bucket(T)), 2, 1, 0, -1, -1, multi)) return -2;
+            k += multi - 1;
+        } else if (use_graph) {
             HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1][graph_bucket(T)], ctx->stream));
         } else {
             if (!enqueue_forward(ctx, 1, false, T) || !enqueue_argmax(ctx, 1)) return -2;

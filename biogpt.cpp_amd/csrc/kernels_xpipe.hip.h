@@ -33,6 +33,7 @@
 namespace bgk {
 
 typedef unsigned long long xp_u64;
+typedef float xp_v4f __attribute__((ext_vector_type(4)));
 #define XP_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr uint32_t XP_SPIN_MAX = 400000u;      // ~0.3 s of polling: far beyond any kernel another stream could hold the compute units with
 
@@ -55,7 +56,7 @@ struct XpParams {
     const XpLayer *layers;
     int32_t n_layer;
     xp_u64 *gran;              // [n_layer][XP_G_LAYER], zeroed once at allocation
-    uint32_t *ctl;             // [0] launch counter (starts at 1), [1] error word, [8..15] per-XCD arrival tickets
+    uint32_t *ctl;             // [0] hand-off tag of the launch's first token (starts at 1, + n_tok per launch), [1] error word, [2] launch counter (starts at 1), [8..15] per-XCD arrival tickets
     uint32_t *err_host;        // pinned mirror of the error word
     DevState *st;
     DevMatrix tok_emb, pos_emb;
@@ -73,6 +74,8 @@ struct XpParams {
     // three 64-row blocks of the output projection each -- the blocks, and the per-block arg-max partials, of the stand-alone
     // lm_head launch (matvec_fast_kernel<EPI_LOGITS>, 64 rows per workgroup), so every consumer of the partials is unchanged
     int32_t lm, lm_blocks, adv;
+    int32_t n_tok;             // tokens in this launch (>= 1; > 1 only with lm != 0 and adv != 0: the device-resident greedy loop)
+    xp_u64 *samp;              // [2][1024] granules: per-block arg-max partials {value, index} of the previous token of this launch
     DevMatrix Wlm;
     const float *lm_ln_w, *lm_ln_b;
     float *logits;
@@ -144,8 +147,8 @@ constexpr int XP_S_RED = XP_S_XS + 128;          // [8] double
 constexpr int XP_S_HQ = XP_S_RED + 64;           // [1024] u32 fc1 output as Q8
 constexpr int XP_S_HD = XP_S_HQ + 4096;          // [128]
 constexpr int XP_S_HS = XP_S_HD + 512;           // [128]
-constexpr int XP_S_PART = XP_S_HS + 512;         // [192 rows][DEC_PS] f32 block terms of the q/k/v rows (fc1: 128 rows; fc2: [32][DEC_PS2])
-constexpr int XP_S_G = XP_S_PART + 192 * DEC_PS * 4;   // [128] GELU outputs
+constexpr int XP_S_PART = XP_S_HS + 512;         // [256 rows][DEC_PS] f32 block terms (lm_head: 256 rows per workgroup, q/k/v: 192, fc1: 128; fc2: [32][DEC_PS2])
+constexpr int XP_S_G = XP_S_PART + 256 * DEC_PS * 4;   // [128] GELU outputs
 constexpr int XP_S_LN = XP_S_G + 512;            // [4][1024] f32 ln0_w, ln0_b, ln1_w, ln1_b
 constexpr int XP_S_BIAS = XP_S_LN + 16384;       // [192 + 32 + 128 + 32] f32: q/k/v rows of the head, out_proj / fc1 / fc2 rows of the workgroup
 constexpr int XP_S_CUR = XP_S_BIAS + 1536;       // [192] f32 q, k, v of this token (head = slot)
@@ -154,7 +157,7 @@ constexpr int XP_S_REDF = XP_S_S + 1024;         // [48] f32 + [48] int
 constexpr int XP_S_REDD = XP_S_REDF + 384;       // [16] double
 constexpr int XP_S_PV = XP_S_REDD + 128;         // [1024] double
 constexpr int XP_S_TOTAL = XP_S_PV + 8192;
-static_assert(32 * DEC_PS2 <= 192 * DEC_PS, "fc2 block terms fit the shared region");
+static_assert(32 * DEC_PS2 <= 256 * DEC_PS, "fc2 block terms fit the shared region");
 __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP_S_TOTAL + (size_t)gelu_entries * 2; }
 
 // stacked [q; k; v] row computed by lane group j (0..95) of workgroup `slot`: workgroups h and h + 16 share head h
@@ -193,22 +196,21 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
 
     // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
-    // launches: launch e hands out 32 (e - 1) .. 32 e - 1) says which.  The dispatcher deals workgroups round-robin over the
+    // launches: launch n hands out 32 (n - 1) .. 32 n - 1) says which.  The dispatcher deals workgroups round-robin over the
     // XCDs, so a launch that has the device to itself gets exactly 32 per XCD whatever the starting point; a launch interleaved
     // with another stream's workgroups may not -- then a 33rd arrival raises the error word and the launch drains.
-    const uint32_t epoch = __hip_atomic_load(p.ctl, XP_RLX);
+    const uint32_t epoch0 = __hip_atomic_load(p.ctl, XP_RLX);
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;     // HW_REG_XCC_ID, bits 0..3
         const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
         s_redi[0] = (int)xcc;
-        s_redi[1] = (int)(t - 32u * (epoch - 1u));
+        s_redi[1] = (int)(t - 32u * (__hip_atomic_load(p.ctl + 2, XP_RLX) - 1u));
     }
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past = p.st->n_past;
-    const int T = n_past + 1;
+    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
     const int t_cap = p.t_cap;
 
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
@@ -219,6 +221,13 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
     }
+    const int last_xcd = (p.n_layer - 1) & 7;
+    // Several tokens per launch (n_tok > 1: the device-resident generation loop): token t + 1 starts from the arg-max partials of
+    // token t's logits, handed to XCD 0 as granules; the hand-off tag is the launch counter + the token's index in the launch.
+    for (int tk = 0; tk < p.n_tok; tk++) {
+    const uint32_t epoch = epoch0 + (uint32_t)tk;
+    const int n_past = n_past0 + tk, T = n_past + 1;
+    if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;       // a disturbed launch drains token by token
     for (int L = xcd; L < p.n_layer; L += 8) {
         // the thread index goes through an empty asm in every iteration: without it the compiler hoists a few hundred
         // per-thread addresses (LDS carve, granule slots, weight rows) out of the layer loop and spills them (120 VGPRs
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         const int lane = tid & 63, wave = tid >> 6;
         const int sub = lane & 31, rsub = lane >> 5;
         const bool worker = tid < 256;
-        if (L == xcd && L >= 2) {      // start this XCD's first weight load when layer L - 1 starts, not all eight at once
+        if (tk == 0 && L == xcd && L >= 2) {      // start this XCD's first weight load when layer L - 1 starts, not all eight at once
             if (tid == 0) {
                 const xp_u64 *g = p.gran + (size_t)(L - 2) * XP_G_LAYER + XP_G_X;
                 for (uint32_t spins = 0;; spins++) {
@@ -278,7 +287,61 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (L == 0) {
                 int tok;
-                if (p.tok_src == 2) {
+                if (tk > 0) {
+                    // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
+                    // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024)
+                    float bv = -INFINITY;
+                    int bi = 0x7fffffff;
+                    {
+                        uint32_t v[4] = {0u, 0u, 0u, 0u};
+                        const bool a0 = tid < p.lm_blocks, a1 = tid + NT < p.lm_blocks;
+                        const uint32_t prev = epoch - 1u;
+                        for (uint32_t spins = 0;; spins++) {
+                            bool ok = true;
+                            if (a0) {
+                                const xp_u64 x0 = __hip_atomic_load(p.samp + tid, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid, XP_RLX);
+                                v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
+                                ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
+                            }
+                            if (a1) {
+                                const xp_u64 x0 = __hip_atomic_load(p.samp + tid + NT, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid + NT, XP_RLX);
+                                v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
+                                ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
+                            }
+                            if (__all(ok)) break;
+                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); break; }
+                            if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
+                        if (a1) {
+                            const float ov = __uint_as_float(v[2]);
+                            const int oi = (int)v[3];
+                            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const float ov = __shfl_xor(bv, off, 64);
+                        const int oi = __shfl_xor(bi, off, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    if (lane == 0) { s_redf[wave] = bv; s_redi[wave] = bi; }
+                    __syncthreads();
+                    bv = s_redf[0]; bi = s_redi[0];
+#pragma unroll
+                    for (int w = 1; w < NW; w++)
+                        if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
+                    tok = bi;
+                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                    if (slot == 0 && tid == 0) {
+                        int32_t *tokens = state_tokens(p.st);
+                        const int g = n_gen0 + tk;
+                        if (g < p.n_positions) tokens[p.n_positions + g] = tok;
+                        tokens[0] = tok;
+                    }
+                    __syncthreads();       // s_redf is reused by the attention workgroups
+                } else if (p.tok_src == 2) {
                     // greedy sampler of the PREVIOUS token (main.cpp:109-128, top_k = 1): arg-max over the lm_head kernel's
                     // per-workgroup partials, lowest id wins ties; workgroup 0 records it
                     float bv = -INFINITY;
@@ -304,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
                     if (tok < 0 || tok >= p.n_vocab) tok = 0;
                     if (slot == 0 && tid == 0) {
                         int32_t *tokens = state_tokens(p.st);
-                        const int g = p.st->n_gen;
+                        const int g = n_gen0;
                         if (g < p.n_positions) tokens[p.n_positions + g] = tok;
                         tokens[0] = tok;
                     }
@@ -376,14 +439,17 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             if (kidx < t_cap) {
                 const float4 *kbase = reinterpret_cast<const float4 *>(Y.kcache + (size_t)head * p.P * DK) + (size_t)kidx * (DK / 4) + ksub;
 #pragma unroll
-                for (int m = 0; m < NF4; m++) kr[m] = kbase[LPK * m];
+                for (int m = 0; m < NF4; m++) {     // L1 bypassed: rows appended by earlier tokens of this launch came through the L2
+                    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(kbase + LPK * m));
+                    kr[m] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                }
             }
             {
                 const float *vbase = Y.vcache + (size_t)head * p.P * DK + dd;
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     const int j = sl + NW * k;
-                    if (j < t_cap) vr[k] = vbase[(size_t)j * DK];
+                    if (j < t_cap) vr[k] = __builtin_nontemporal_load(vbase + (size_t)j * DK);
                 }
             }
             {   // the layer input is the residual of stage C; it arrives about 2 us before the q / k / v rows
@@ -625,23 +691,21 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         }
         XP_WALL(5);
         __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next layer of this XCD
-        if (L == p.n_layer - 1 && slot == 0 && tid == 0) __hip_atomic_store(p.ctl, epoch + 1u, XP_RLX);   // every workgroup read it long ago
     }
     // ================= final LayerNorm + lm_head (biogpt.cpp:799-811): the XCDs that are done with their layers =================
-    // Their weights (three 64-row blocks = 12 units per lane) are loaded as soon as the workgroup's last layer is finished --
-    // 1 .. 7 layers before the last layer's output exists -- so the logits cost one hop + LayerNorm + 12 block dots instead of
-    // a launch boundary plus a 24.6 MB stream.
-    const int last_xcd = (p.n_layer - 1) & 7;
-    if (p.lm != 0 && xcd != last_xcd) {
+    // Their weights (four 64-row blocks = 16 units per lane) are loaded as soon as the workgroup's last layer of this token is
+    // finished -- 1 .. 6 layers before the last layer's output exists -- so the logits cost one hop + LayerNorm + 16 block dots
+    // instead of a launch boundary plus a 24.6 MB stream.  XCD 0 (next token's layer 0) and the last layer's XCD take no part.
+    const int lm_xr = xcd - (xcd > 0 ? 1 : 0) - ((last_xcd != 0 && xcd > last_xcd) ? 1 : 0);   // index among the XCDs that take part
+    const int lm_rank = slot + 32 * lm_xr;
+    if (p.lm != 0 && xcd != 0 && xcd != last_xcd && lm_rank * 4 < p.lm_blocks) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6;
         const int sub = lane & 31, rsub = lane >> 5;
         const bool worker = tid < 256;
-        constexpr int LMS = 96 / NW;                                          // 2-row steps per wave: 192 rows per workgroup
-        const int rank = slot + 32 * (xcd < last_xcd ? xcd : xcd - 1);       // 0 .. 223
-        const int row0 = rank * 192;
-        if (rank * 3 >= p.lm_blocks) return;
+        constexpr int LMS = 128 / NW;                                         // 2-row steps per wave: 256 rows per workgroup
+        const int row0 = lm_rank * 256;
         Unit<WT> wl[LMS];
 #pragma unroll
         for (int s = 0; s < LMS; s++) {
@@ -668,7 +732,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // lane < 2 LMS finishes local row (lane >> 1) 2 NW + 2 wave + (lane & 1); with NW = 8 lanes 8 j .. 8 j + 7 hold rows of block j
+        // lane < 2 LMS finishes local row (lane >> 1) 2 NW + 2 wave + (lane & 1); lanes 64 / NW * j .. hold rows of block j
         float best_val = -INFINITY;
         int best_idx = 0x7fffffff;
         if (lane < 2 * LMS) {
@@ -679,18 +743,17 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
                 best_val = v; best_idx = row;
             }
         }
-        // per-block partial arg-max (lowest index wins ties): groups of 8 lanes, then the 8 waves through LDS
+        // per-block partial arg-max (lowest index wins ties): groups of 64 / NW lanes, then the NW waves through LDS
 #pragma unroll
         for (int off = 1; off < 64 / NW; off <<= 1) {
             const float ov = __shfl_xor(best_val, off, 64);
             const int oi = __shfl_xor(best_idx, off, 64);
             if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
         }
-        static_assert(NW == 8 || NW == 16, "block of a finisher lane = lane / (64 / NW)");
         constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
         if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
         __syncthreads();
-        if (tid < 3) {
+        if (tid < 4) {
             float bv = s_redf[tid * NW];
             int bi = s_redi[tid * NW];
 #pragma unroll
@@ -699,11 +762,25 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
                 const int oi = s_redi[tid * NW + w];
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
-            const int blk = rank * 3 + tid;
-            if (blk < p.lm_blocks) { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
-            // every workgroup read the position when it started, long before the last layer's output existed
-            if (blk == 0 && p.adv != 0) { p.st->n_past += p.adv; p.st->n_gen += p.adv; }
+            const int blk = lm_rank * 4 + tid;
+            if (blk < p.lm_blocks) {
+                p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi;
+                if (tk + 1 < p.n_tok) {        // the sampler of the next token runs on XCD 0
+                    xp_put(p.samp + blk, epoch, __float_as_uint(bv));
+                    xp_put(p.samp + 1024 + blk, epoch, (uint32_t)bi);
+                }
+            }
         }
+        __syncthreads();       // s_redf / s_part / s_xq are rewritten by this workgroup's next layer
+    }
+    }   // tokens
+    // every workgroup read the launch counter and the position when it started, long before the last layer's output existed
+    if (threadIdx.x == 0) {
+        if (xcd == last_xcd && slot == 0) {
+            __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
+            __hip_atomic_store(p.ctl + 2, __hip_atomic_load(p.ctl + 2, XP_RLX) + 1u, XP_RLX);
+        }
+        if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { p.st->n_past = n_past0 + p.n_tok; p.st->n_gen = n_gen0 + p.n_tok; }
     }
 }
 
