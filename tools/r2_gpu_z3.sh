@@ -1,6 +1,6 @@
 # same-process A/B of pipeline options: us/token at 41 / 104 / 201 keys
-M=/tmp/biogpt_amd_bench/synthetic-L24-q4_0.bin
-[ -f $M ] || python bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+FT=${FT:-q4_0}; M=/tmp/biogpt_amd_bench/synthetic-L24-$FT.bin
+[ -f $M ] || python bench.py --ftype $FT --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 python - <<PY
 import os, sys; sys.path.insert(0, '.')
 import _pkg
