@@ -257,10 +257,12 @@ def main():
                     per["five_launch_layer_fc1"] = per.pop("fc1")
                     per = {("five_launch_layer_" + k if not k.startswith("five_") else k): v for k, v in per.items()}
                     secs, nbytes = sx, bx
-                    kname = ("dec_xpipe_kernel<%s> (all %d layers of one token at 104 keys in ONE persistent launch, layer l on the 32 compute units of XCD l %% 8, "
-                             "weights stationary in registers, hand-offs through the XCD's L2; 1 launch/token)" % (args.ftype.upper(), hp.n_layer))
-                    method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel (hipGraph, as the decode step is replayed), real arena weights; "
-                              "algorithmic bytes = the four matrices of every layer at file density + K / V rows of 104 keys + the new K / V rows + x in / out; "
+                    kname = ("dec_xpipe_kernel<%s> (all %d layers + final LayerNorm + lm_head of one token at 104 keys in ONE persistent launch, layer l on the 32 compute units "
+                             "of XCD l %% 8, weights stationary in registers, hand-offs through the XCD's L2; the headline's 200-token continuation runs the same kernel with "
+                             "60-72 tokens per launch)" % (args.ftype.upper(), hp.n_layer))
+                    method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel as a single-token launch (hipGraph, as biogpt_eval's step is replayed), real arena weights; "
+                              "algorithmic bytes = the four matrices of every layer and the output projection at file density + K / V rows of 104 keys + the new K / V rows + x in / out + the logits row; "
+                              "rocprofv3 agreement: profiles/rocprofv3_kernel_stats_r2.csv is taken with BIOGPT_HIP_XPIPE_MULTI=0 (every call one token); "
                               "the launch is LATENCY-bound by design: a layer is %.1f us of dependent stages (profiles/xpipe_timeline_r2.txt) on 1/8 of the chip while the "
                               "other XCDs prefetch -- 8 TB/s would move a layer's 7.1 MB in 0.9 us" % (sx * 1e6 / hp.n_layer))
             else:
@@ -299,7 +301,9 @@ def main():
                                    "GBps": round(b / s / 1e9, 1), "frac_of_peak": round(b / s / 1e9 / HBM_PEAK_GBS, 4),
                                    "bytes_per_token": int(b)}
             out["token_roofline"] = tok
-            out["decode_path"] = "xcd-pipeline (1 persistent launch per token + lm_head)" if model.xpipe_state() == 1 else "five launches per layer + lm_head"
+            multi = os.environ.get("BIOGPT_HIP_XPIPE_MULTI", "1") != "0"
+            out["decode_path"] = (("xcd-pipeline: layers + lm_head + greedy sampler in ONE persistent launch per context bucket (64 / 128 / 256 keys)" if multi else
+                                   "xcd-pipeline: layers + lm_head in ONE persistent launch per token") if model.xpipe_state() == 1 else "five launches per layer + lm_head")
             # batched multi-sequence decode on this one GPU (biogpt_hip_generate_greedy_batch): S independent
             # 200-token continuations decoded together, weights read once per step for all S -- NOT the headline
             # (configs[1] is single-stream), reported because it is what the HBM-bound regime of this chip looks like

@@ -348,3 +348,52 @@ def test_xpipe_disturbed_launch_is_repeated_on_the_five_launch_layer(pkg, files,
     ref.eval_device(prompt, 0); ref.synchronize()
     assert (ref.eval([7], 4) == l0).all()
     ref.close()
+
+
+def test_xpipe_survives_a_second_stream_generating_at_the_same_time(pkg, files):
+    """Two contexts of one device generating concurrently from two host threads: one holds the pipeline, the other runs the
+    five-launch layer on its own stream, so workgroups of both are dispatched interleaved.  Whatever happens to the pipelined
+    launches (undisturbed, or drained and repeated on the five-launch layer) every call must return the undisturbed ids."""
+    import threading
+    a = pkg.BiogptModel.load(files["q4_0"])
+    if a.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    b = pkg.BiogptModel.load(files["q4_0"])
+    prompt_a, prompt_b = [2, 100, 200, 300], [2, 7, 8, 9, 10]
+    want_a, _ = a.generate_greedy(prompt_a, n_predict=120, n_batch=8)
+    want_b, _ = b.generate_greedy(prompt_b, n_predict=120, n_batch=8)
+    assert a.xpipe_state() == 1 and b.xpipe_state() == 0          # b found the device's pipeline slot taken
+    errs = []
+
+    def run(g, prompt, want, reps):
+        try:
+            for _ in range(reps):
+                got, _ = g.generate_greedy(prompt, n_predict=120, n_batch=8)
+                if list(got) != list(want):
+                    errs.append("ids differ")
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ta = threading.Thread(target=run, args=(a, prompt_a, want_a, 12))
+    tb = threading.Thread(target=run, args=(b, prompt_b, want_b, 12))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert a.xpipe_state() in (1, -1)
+    a.close(); b.close()
+
+
+def test_xpipe_many_launches_stay_clean(pkg, files):
+    """4000 tokens through the pipeline (multi-token launches and single-token evals mixed): no timeout, no fallback, same ids."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 11, 12, 13]
+    want, _ = g.generate_greedy(prompt, n_predict=200, n_batch=8)
+    for rep in range(19):
+        got, _ = g.generate_greedy(prompt, n_predict=200, n_batch=8)
+        assert list(got) == list(want)
+        if rep % 5 == 0:
+            lg = g.eval([int(want[0])], len(prompt))
+            assert int(lg.argmax()) == int(want[1])
+    assert g.xpipe_state() == 1
+    g.close()

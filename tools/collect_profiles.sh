@@ -6,8 +6,12 @@ python bench.py --steps 5 --warmup 1 > $OUT/bench_r2_n1.json 2> $OUT/bench.err
 M=/tmp/biogpt_amd_bench/synthetic-L24-q4_0.bin
 export R=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o dec -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /tmp/prof.err
+# kernel-trace stats twice: with single-token launches only (BIOGPT_HIP_XPIPE_MULTI=0: every dec_xpipe_kernel call is ONE token, the launch
+# roofline.us_per_launch is about) and as the headline runs (the 200-token continuation = three multi-token launches of 60 / 64 / 72 tokens)
+BIOGPT_HIP_XPIPE_MULTI=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o dec -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /tmp/prof.err
 find /tmp/prof -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_r2.csv \;
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o dec -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof_multi.json 2> /tmp/prof_m.err
+find /tmp/prof_m -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_r2_multi.csv \;
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pre -o pre -- python $R/bench.py --workload prefill --no-cpu-baseline > /dev/null 2>&1
 find /tmp/prof_pre -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_r2_prefill.csv \;
 # PMC passes, each on its own (no trace options beside --kernel-trace): HBM-side bytes of the decode kernels, MFMA counters of a prompt pass
