@@ -75,6 +75,24 @@ __device__ __forceinline__ int group32_sum(int v) {
 #define DEC_WALL(which) do {} while (0)
 #endif
 
+// The two divisions of quantize_row_q8_0 / q8_1 (d = amax / 127, id = 1 / d) sit on the dependent chain of every LayerNorm and of
+// every activation hand-over.  Three-instruction forms that equal the IEEE quotients BIT FOR BIT, checked exhaustively on the
+// MI355X (tools/microbench12.hip -> profiles/microbench12_q8_divisions_r2.txt): d' = fma(fma(-127, q, a), C, q) with q = a * C,
+// C = RN(1 / 127), matches for every finite a >= 0 (2,139,095,040 values); id' = fma(fma(-d, r, 1), r, r) with r = v_rcp_f32(d)
+// matches for 2^-100 <= a < 2^100 (it differs for a < 1.5e-36).  Outside that range the divisions themselves are used.
+__device__ __forceinline__ void q8_scales(float amax, float &d, float &id) {
+    if (amax >= 0x1p-100f && amax < 0x1p100f) {
+        const float C = 1.0f / 127.0f;
+        const float q = __fmul_rn(amax, C);
+        d = __fmaf_rn(__fmaf_rn(-127.0f, q, amax), C, q);
+        const float r = __builtin_amdgcn_rcpf(d);
+        id = __fmaf_rn(__fmaf_rn(-d, r, 1.0f), r, r);
+    } else {
+        d = amax / 127.0f;
+        id = (d != 0.0f) ? 1.0f / d : 0.0f;
+    }
+}
+
 // LayerNorm (ggml_norm + affine, double statistics) and Q8_0 / Q8_1 quantization of ONE 1024-element column inside a
 // 1024-thread workgroup.  Measured (profiles/decode_5kernel_timeline_r2.txt): with all 16 waves taking part (one element per
 // thread) the double-precision adds of 16 waves contend for the SIMDs and every barrier waits for the slowest wave --
@@ -124,8 +142,8 @@ __device__ __forceinline__ void ln4_q8_1024(float4 v, float4 lw, float4 lb, floa
         LN_STAMP(13);
         // quantize_row_q8_0 / q8_1: one block = 8 consecutive lanes x 4 values
         const float amax = group8_max(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d4))));
-        const float d = amax / 127.0f;
-        const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+        float d, id;
+        q8_scales(amax, d, id);
         const int q0 = (int)roundf(__fmul_rn(a, id)), q1 = (int)roundf(__fmul_rn(b, id));
         const int q2 = (int)roundf(__fmul_rn(c, id)), q3 = (int)roundf(__fmul_rn(d4, id));
         const int isum = group8_sum(q0 + q1 + q2 + q3);
@@ -157,8 +175,8 @@ __device__ __forceinline__ float sum32_in_order(const float *part) {
 // quantize_row_q8_0 / q8_1 of 32 values held one per lane by an aligned group of 32 lanes
 __device__ __forceinline__ void q8_block32(float v, bool q81, int8_t &q_out, float &d_out, uint32_t &s_out) {
     const float amax = group32_max(fabsf(v));
-    const float d = amax / 127.0f;
-    const float id = (d != 0.0f) ? 1.0f / d : 0.0f;
+    float d, id;
+    q8_scales(amax, d, id);
     const int q = (int)roundf(__fmul_rn(v, id));
     const int isum = group32_sum(q);
     q_out = (int8_t)q;
