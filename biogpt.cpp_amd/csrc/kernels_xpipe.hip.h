@@ -1,28 +1,33 @@
-// Single-token decode step as ONE launch, pipelined over the MI355X's 8 XCDs (accelerator dies: 32 compute units and one
-// 4 MB L2 each).  biogpt.cpp:664-795 for all layers; the arithmetic per element is that of kernels_decode.hip.h.
+// The decode step as ONE persistent launch, pipelined over the MI355X's 8 XCDs (accelerator dies: 32 compute units and one
+// 4 MB L2 each).  biogpt.cpp:664-811 for all layers + the output projection; the arithmetic per element is that of
+// kernels_decode.hip.h.
 //
 // Why: the five-launch layer of kernels_decode.hip.h spends 7.5 of its 20 us in launch boundaries (1.3-1.6 us each:
 // every boundary is a device-wide all-to-all), and each kernel then starts cold (0.7-1.5 us until its first weights
 // arrive).  What a layer needs between its five stages is an all-to-all among the workgroups THAT COMPUTE THE LAYER --
-// and on this chip 32 compute units behind one L2 can do that in ~1 us with tagged 8-byte granules
-// (tools/microbench11.hip: all six hand-offs of a layer, model-sized, 6.9 us per layer end to end).
+// and on this chip 32 compute units behind one L2 can do that in 0.4-0.8 us with tagged 8-byte granules
+// (tools/microbench11.hip: all six hand-offs of a layer, model-sized, 4.7 us per layer end to end).
 //
-// Shape: grid = 256 workgroups x 1024 threads, one per compute unit; workgroup b runs on XCD b % 8 (checked against
-// HW_REG_XCC_ID in every launch, rank inside the XCD from a ticket; the host probes the device once).  Layer l is computed
-// by the 32 workgroups of XCD l % 8.  While the other XCDs compute their layers, an XCD loads the weights of ITS next
-// layer into registers (7.08 MB of Q4_0 per layer = 221 KB per compute unit = 12 block units per lane, 60 VGPRs), so a
-// layer's stages never wait for weights: stage latency = hand-off + arithmetic.
+// Shape: grid = 256 workgroups x 512 threads, one per compute unit.  A workgroup reads its XCD from HW_REG_XCC_ID and takes
+// its rank inside the XCD from a per-XCD arrival ticket (the host probes the device once: 8 XCDs, workgroups dealt evenly).
+// Layer l is computed by the 32 workgroups of XCD l % 8.  While the other XCDs compute their layers, an XCD loads the weights
+// of ITS next layer into registers (7.08 MB of Q4_0 per layer = 221 KB per compute unit = 18-30 block units per lane, 90-150
+// of a lane's 256 VGPRs), so a layer's stages never wait for weights: stage latency = hand-off + arithmetic.
 //
-//   stage A  x (granules from the previous layer's XCD, or the embedding) -> LayerNorm -> Q8 -> 96 q/k/v rows per
-//            workgroup; KV append; workgroups 16-31 hand their rows (second half of K, V of head slot - 16) to 0-15
-//   stage B  workgroups 0-15: attention of head `slot` (old keys from the cache, the new key/value from stage A)
+//   stage A  (workgroups 16-31 of the XCD) x -- granules from the previous layer's XCD, or the embedding of the sampled token --
+//            -> LayerNorm -> Q8 -> all 192 q/k/v rows of head slot - 16; KV append; the rows go to workgroup slot - 16
+//   stage B  (workgroups 0-15) attention of head `slot`: old keys / values from the cache (in registers since the XCD's
+//            previous layer finished), the new ones from stage A
 //   stage C  out_proj rows (32 per workgroup) + bias + residual
-//   stage D  LayerNorm -> Q8 -> fc1 rows (128 per workgroup = 4 Q8 blocks) -> GELU table -> Q8
+//   stage D  LayerNorm -> Q8 -> fc1 rows (128 per workgroup = 4 Q8 blocks) -> GELU table (LDS slice) -> Q8
 //   stage E  fc2 rows (32 per workgroup) + bias + residual -> x for the next layer's XCD
+//   then     final LayerNorm + lm_head on the XCDs that are done (four 64-row blocks per workgroup, loaded ahead), and -- in a
+//            multi-token launch (biogpt_hip_generate_greedy) -- the greedy sampler of the next token on XCD 0: the whole loop
+//            over the tokens of a context bucket runs inside ONE launch
 //
 // Hand-offs: "R2" granules of MI355X_MICROARCH.md -- one naturally aligned 8-byte {value, tag} written by ONE relaxed
-// agent-scope atomic store and polled with relaxed agent-scope atomic loads; tag = the context's launch counter
-// (ctl[0], bumped by the last layer's first workgroup once every workgroup has provably read it), buffers are per
+// agent-scope atomic store and polled with relaxed agent-scope atomic loads; tag = the context's hand-off counter + the token's
+// index in the launch (ctl[0], moved on by the last layer's first workgroup when every workgroup has provably read it), buffers are per
 // layer, so a tag can only match data of THIS launch.  No fences, no flags.  EVERY spin is bounded: after XP_SPIN_MAX
 // passes a poller raises ctl[1] (and the pinned host word), every other poller sees it within 1024 passes, the launch
 // drains in milliseconds with garbage outputs, and the host reports the failure and leaves this path for good.
@@ -388,7 +393,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             }
             return xv;
         };
-        asm volatile("; XPMARK stage_A" ::: "memory");
         if (!attn_wg) {
             // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
             Unit<WT> wqkv[QS];
@@ -542,7 +546,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             }
         }
         XP_WALL(2);
-        asm volatile("; XPMARK stage_C" ::: "memory");
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if (wave < 5) {
             uint32_t v[1];
@@ -572,7 +575,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             }
         }
         XP_WALL(3);
-        asm volatile("; XPMARK stage_D" ::: "memory");
         // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
         if (wave < 4) {
@@ -621,7 +623,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
         }
         XP_WALL(4);
-        asm volatile("; XPMARK stage_E" ::: "memory");
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
         {   // 1024 + 128 + 128 granules in ONE poll loop: every pass has all of a lane's loads in flight together
             constexpr int NQ = 1024 / NT;
