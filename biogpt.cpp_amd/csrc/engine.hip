@@ -700,7 +700,7 @@ bool xpipe_check(biogpt_hip_ctx *c) {
     for (auto &row : c->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     for (auto &f : c->graph_eval) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     BG_FAIL(false, "the XCD-pipelined decode step failed (code %u: %s); this context now uses the five-launch layer", code,
-            code == 2u ? "its workgroups were not dealt 32 per XCD -- another stream's kernels were dispatched in between" : "a hand-off timed out");
+            code == 2u ? "its workgroups were not dealt 32 per XCD -- another stream's kernels were dispatched in between" : code == 5u ? "hand-off tags used up" : "a hand-off timed out");
 }
 
 int graph_bucket(int T);

@@ -778,6 +778,9 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     // every workgroup read the launch counter and the position when it started, long before the last layer's output existed
     if (threadIdx.x == 0) {
         if (xcd == last_xcd && slot == 0) {
+            // tags must never wrap onto a stale granule: after 4.0e9 tokens (two weeks of continuous decode) the context leaves this
+            // path through the ordinary error route (the host repeats the call on the five-launch layer and stays there)
+            if (epoch0 + (uint32_t)p.n_tok > 0xF0000000u) xp_fail(p, 5u);
             __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
             __hip_atomic_store(p.ctl + 2, __hip_atomic_load(p.ctl + 2, XP_RLX) + 1u, XP_RLX);
         }
