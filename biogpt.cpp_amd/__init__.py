@@ -95,6 +95,7 @@ SYMBOLS = [
     ("biogpt_hip_bench_api_loop", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_stream", C.c_int, [_P, C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_quantize_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
+    ("biogpt_hip_quantize_rows_device", C.c_int, [C.c_int, C.c_int32, _P, C.c_int64, C.c_int64, _P]),
     ("biogpt_hip_write_synthetic", C.c_int, [C.c_char_p, C.POINTER(HParams), C.c_uint64]),
     # text <-> ids (host-only)
     ("biogpt_hip_vocab_load", _P, [C.c_char_p]),
@@ -137,6 +138,17 @@ def quantize_file(src, dst, ftype):
     ft = FTYPES[ftype] if isinstance(ftype, str) else int(ftype)
     if lib().biogpt_hip_quantize_file(os.fsencode(src), os.fsencode(dst), ft) != 0:
         raise BiogptError(_err())
+
+
+def quantize_rows_device(rows, type_id, device=0):
+    """ggml_quantize_* on the device: a [nrows, k] float32 array -> the file's block bytes (uint8 array)."""
+    a = np.ascontiguousarray(rows, dtype=np.float32)
+    nrows, k = a.shape
+    bb = {2: 18, 3: 20, 6: 22, 7: 24, 8: 34}[int(type_id)]
+    out = np.empty(nrows * (k // 32) * bb, dtype=np.uint8)
+    if lib().biogpt_hip_quantize_rows_device(int(device), int(type_id), a.ctypes.data, nrows, k, out.ctypes.data) != 0:
+        raise BiogptError(_err())
+    return out
 
 
 def write_synthetic(path, seed=0x42494F47, **hparams):

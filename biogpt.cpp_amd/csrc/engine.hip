@@ -31,6 +31,7 @@
 #include "kernels_mfma.hip.h"
 #include "kernels_decode.hip.h"
 #include "kernels_xpipe.hip.h"
+#include "kernels_quant.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
 
@@ -2273,6 +2274,31 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
             fprintf(stderr, "\n");
         }
     }
+    return 0;
+}
+
+// SURVEY 8 f1 on the device: `nrows` rows of `k` f32 values (host memory) -> the file's block format of `type`, byte-identical to
+// the host quantizer (biogpt_hip_quantize_file uses the host one: it has to work without a GPU)
+int biogpt_hip_quantize_rows_device(int device, int32_t type, const float *src, int64_t nrows, int64_t k, uint8_t *dst) {
+    clear_error();
+    if (!src || !dst || nrows < 1 || k < QK || k % QK) BG_FAIL(-1, "bad argument (row length must be a multiple of %d)", QK);
+    if (!is_quantized(type)) BG_FAIL(-1, "type %d is not a block-quantized format", type);
+    if (!select_device(device)) return -1;
+    const long long nblocks = (long long)nrows * (k / QK);
+    const size_t in_bytes = (size_t)nrows * (size_t)k * 4, out_bytes = (size_t)nblocks * file_block_bytes(type);
+    float *d_src = nullptr;
+    uint8_t *d_dst = nullptr;
+    HIP_TRY(-2, hipMalloc(&d_src, in_bytes));
+    if (hipMalloc(&d_dst, out_bytes) != hipSuccess) { (void)hipFree(d_src); BG_FAIL(-2, "hipMalloc of %zu bytes failed", out_bytes); }
+    hipError_t e = hipMemcpy(d_src, src, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bgk::quantize_blocks_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, 0, d_src, d_dst, nblocks, (int)type,
+                           (int)file_block_bytes(type));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(dst, d_dst, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_src); (void)hipFree(d_dst);
+    HIP_TRY(-2, e);
     return 0;
 }
 

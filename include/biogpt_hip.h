@@ -265,6 +265,11 @@ int biogpt_hip_tokenizer_byte_class(int which, uint8_t *out256);
  * ne[0]; header ftype rewritten; vocab/merges copied verbatim. */
 int biogpt_hip_quantize_file(const char *fname_in, const char *fname_out, int32_t ftype);
 
+/* The quantizer's inner loops on the device (biogpt.cpp:565-603 -> ggml_quantize_q4_0 .. q8_0): nrows rows of k
+ * f32 values in host memory -> the FILE's block format of ggml type `type` (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0) in host
+ * memory, byte-identical to biogpt_hip_quantize_file's host encoder. */
+int biogpt_hip_quantize_rows_device(int device, int32_t type, const float *src, int64_t nrows, int64_t k, uint8_t *dst);
+
 /* Write a synthetic seeded BioGPT model: F32 (ftype 0) or F16 (ftype 1) file in the
  * reference's format, weights ~ N(0, 0.02^2), LayerNorm gains 1 + N(0, 0.02^2), biases N(0, 0.02^2),
  * embed_tokens row 1 zero; n_merges merge records are written (40000 keeps the reference's

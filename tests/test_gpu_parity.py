@@ -212,3 +212,32 @@ def test_prompt_pass_equals_chunk_by_chunk_evals(loaded, pkg, tiny_models, promp
     assert (l2 == lg).all()
     h.close()
     assert d == 0.0 or d <= ATOL
+
+
+# ---- the quantizer's inner loops on the device -------------------------------------------------------------------
+
+@pytest.mark.parametrize("type_id,name", [(2, "q4_0"), (3, "q4_1"), (6, "q5_0"), (7, "q5_1"), (8, "q8_0")])
+def test_device_quantizer_is_byte_identical_to_the_oracle_codec(pkg, oracle, type_id, name):
+    """biogpt_hip_quantize_rows_device against the oracle's restatement of ggml_quantize_* (byte-exact bar): weight-like rows,
+    wide-range rows, and the edge blocks the reference's formats are sensitive to (all zeros, one extreme value of either sign,
+    equal magnitudes of both signs, ties at .5 codes, tiny values, a constant block)."""
+    rng = np.random.default_rng(100 + type_id)
+    k = 1024
+    rows = [rng.normal(0.0, 0.02, (64, k)), rng.normal(0.0, 1.0, (64, k)) * np.exp(rng.normal(0.0, 3.0, (64, 1))),
+            rng.integers(-8, 9, (8, k)).astype(np.float64) * 0.125]
+    edge = np.zeros((8, k), dtype=np.float64)
+    edge[1, 0] = 3.0; edge[1, 40] = -3.0                     # equal magnitudes: the first one decides the sign of a symmetric scale
+    edge[2, :32] = -7.5; edge[2, 5] = 7.5
+    edge[3, :] = 0.3                                         # constant block: asymmetric scale 0
+    edge[4, ::2] = 1e-36; edge[4, 1::2] = -1e-36             # tiny but normal: 1 / d stays finite (with a denormal d it overflows and the
+                                                             # reference's own float -> int conversion is undefined: not compared)
+    edge[5, :32] = np.arange(32) * 0.5 - 8.0                 # codes landing on .5 boundaries
+    edge[6, :32] = np.linspace(-1.0, 1.0, 32); edge[6, 7] = 65504.0
+    edge[7, 3] = -1e-30
+    rows.append(edge)
+    a = np.concatenate(rows).astype(np.float32)
+    got = pkg.quantize_rows_device(a, type_id)
+    want = oracle.quantize(type_id, a.reshape(-1), k)
+    assert got.size == want.size
+    bad = np.nonzero(got != np.frombuffer(bytes(want), dtype=np.uint8))[0]
+    assert bad.size == 0, "%s: %d bytes differ, first at %d" % (name, bad.size, int(bad[0]))
