@@ -592,8 +592,8 @@ bool xpipe_model_ok(const biogpt_hip_ctx *c) {
 
 template <int WT>
 bool xpipe_set_lds_t(size_t sm) {
-    const void *fns[3] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8>)};
+    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256>)};
     for (const void *fn : fns)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return false;
     return true;
@@ -724,9 +724,10 @@ template <int WT>
 hipError_t launch_xpipe(biogpt_hip_ctx *c, const bgk::XpParams &xp) {
     const size_t sm = bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n);
     // 8 waves per workgroup: 24 weight units per lane (120 VGPRs) + the head's old keys / values fit the 256-register budget
-    if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8>), dim3(256), dim3(512), sm, c->stream, xp);
-    else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8>), dim3(256), dim3(512), sm, c->stream, xp);
-    else hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8>), dim3(256), dim3(512), sm, c->stream, xp);
+    if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64>), dim3(256), dim3(512), sm, c->stream, xp);
+    else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128>), dim3(256), dim3(512), sm, c->stream, xp);
+    else if (xp.t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192>), dim3(256), dim3(512), sm, c->stream, xp);   // 24 instead of 32 value registers
+    else hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256>), dim3(256), dim3(512), sm, c->stream, xp);
     return hipGetLastError();
 }
 

@@ -169,7 +169,7 @@ __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP
 __device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
 __device__ __forceinline__ int xp_qkv_row(int slot, int j) { const int jj = xp_qkv_local(slot, j); return (jj >> 6) * 1024 + (slot & 15) * 64 + (jj & 63); }
 
-template <int WT, int LPK, int NW>
+template <int WT, int LPK, int NW, int KCAP>
 __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
-    constexpr int NF4 = 16 / LPK, NV = 64 / LPK;
+    static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
+    constexpr int NF4 = 16 / LPK, NV = KCAP / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
             {
                 // all LDS reads first, no branches in the loop: a key past the context adds +0.0 (exact), never its stale weight
                 const float vcur = s_cur[128 + dd];
-                constexpr int CH = NV < 16 ? NV : 16;      // softmax weights fetched 16 at a time (register budget at 256 keys)
+                constexpr int CH = NV < 16 ? NV : (NV % 16 == 0 ? 16 : 8);      // softmax weights fetched at most 16 at a time (register budget)
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int k0 = 0; k0 < NV; k0 += CH) {

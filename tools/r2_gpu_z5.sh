@@ -6,7 +6,7 @@ import _pkg
 m=_pkg.load()
 g=m.BiogptModel.load("$M")
 prompt=[2, 100, 200, 300]
-for n in (61, 62, 125, 126, 140, 200):
+for n in (61, 125, 189, 200):
     g.generate_greedy(prompt, n_predict=n, n_batch=8)
     best=1e9; bi=1e9
     for rep in range(5):
