@@ -15,7 +15,7 @@ for rep in range(3):
             if k.startswith("BIOGPT_HIP_XPIPE"): os.environ.pop(k)
         os.environ.update(c)
         g=m.BiogptModel.load("$M")     # table slices / LDS size are fixed at load time
-        res.setdefault(i,[]).append([g.bench_decode(n, 60)*1e6 for n in (40,103,200)])
+        res.setdefault(i,[]).append([g.bench_decode(n, 60)*1e6 for n in (40,103,160,200)])
         g.close()
 for i,c in enumerate(cfgs):
     print(c, " | ".join(" ".join("%.1f" % v for v in r) for r in res[i]))
