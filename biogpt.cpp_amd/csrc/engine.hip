@@ -680,11 +680,6 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
 // may this step (context bucket t_max) go through the pipeline ?  Takes the device's pipeline slot if it is free.
 bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
     if (!c->opt.xpipe || c->xp_state != 1 || t_max > 256 || c->device < 0 || c->device >= 64) return false;
-    {   // Q5 units take 6 registers: beside 64 registers of K / V (129-256 keys: 2 lanes per key) the kernel spills 39 VGPRs and a token
-        // costs 559 us against 516 us on the five-launch layer (measured); up to 128 keys it is 381 against 474
-        const int32_t wt = ftype_to_type(c->hp.ftype);
-        if (t_max > 128 && (wt == T_Q5_0 || wt == T_Q5_1)) return false;
-    }
     std::lock_guard<std::mutex> lk(g_xp_mu);
     if (g_xp_owner[c->device] == nullptr) g_xp_owner[c->device] = c;
     return g_xp_owner[c->device] == c;

@@ -169,8 +169,12 @@ __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP
 __device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
 __device__ __forceinline__ int xp_qkv_row(int slot, int j) { const int jj = xp_qkv_local(slot, j); return (jj >> 6) * 1024 + (slot & 15) * 64 + (jj & 63); }
 
-template <int WT, int LPK, int NW, int KCAP>
-__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
+// The launch's work for one role: ATTN = this workgroup is one of the XCD's 16 attention heads (else it computes q/k/v rows).  The
+// role is a template parameter because the register allocator, given ONE function with a run-time role branch, spills 21-39 VGPRs
+// although each role alone fits (measured: 198-240 of 256 registers per role): two copies of the loop, no spills.
+template <int WT, int LPK, int NW, int KCAP, bool ATTN>
+__device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
+                                       const int n_gen0) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
@@ -179,7 +183,6 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
     static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
     constexpr int NF4 = 16 / LPK, NV = KCAP / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
@@ -200,33 +203,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
-
-    // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
-    // launches: launch n hands out 32 (n - 1) .. 32 n - 1) says which.  The dispatcher deals workgroups round-robin over the
-    // XCDs, so a launch that has the device to itself gets exactly 32 per XCD whatever the starting point; a launch interleaved
-    // with another stream's workgroups may not -- then a 33rd arrival raises the error word and the launch drains.
-    const uint32_t epoch0 = __hip_atomic_load(p.ctl, XP_RLX);
-    if (threadIdx.x == 0) {
-        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;     // HW_REG_XCC_ID, bits 0..3
-        const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
-        s_redi[0] = (int)xcc;
-        s_redi[1] = (int)(t - 32u * (__hip_atomic_load(p.ctl + 2, XP_RLX) - 1u));
-    }
-    __syncthreads();
-    const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
-    __syncthreads();
-    if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
     const int t_cap = p.t_cap;
-
-    // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
-    // in fp16) nor -0 (x <= -5.42): kept in LDS for the whole launch, fc1's 128 rows per workgroup look it up there
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
-        const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
-        for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
-        for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
-    }
     const int last_xcd = (p.n_layer - 1) & 7;
     // Several tokens per launch (n_tok > 1: the device-resident generation loop): token t + 1 starts from the arg-max partials of
     // token t's logits, handed to XCD 0 as granules; the hand-off tag is the launch counter + the token's index in the launch.
@@ -260,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         // ---- this layer's weights into registers, its small vectors into LDS: issued as soon as the previous layer of this
         //      XCD is done, i.e. seven layers ahead of their use.  Workgroups 0-15 are the layer's attention heads and hold the
         //      head's old keys / values instead of q/k/v weights; workgroup 16 + h computes all 192 q/k/v rows of head h.
-        const bool attn_wg = slot < 16;
+        constexpr bool attn_wg = ATTN;
         const int head = slot & 15;
         Unit<WT> wo[OS], w1[FS], w2[F2R][2];
         {
@@ -787,6 +764,68 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         }
         if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { p.st->n_past = n_past0 + p.n_tok; p.st->n_gen = n_gen0 + p.n_tok; }
     }
+}
+
+template <int WT, int LPK, int NW, int KCAP>
+__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
+    using TI = TypeInfo<WT>;
+    static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
+    static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
+    static_assert(NW == 8 || NW == 16, "waves per workgroup");
+    constexpr int D = 1024, DK = 64, NT = NW * 64;
+    constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
+    static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
+    constexpr int NF4 = 16 / LPK, NV = KCAP / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
+    float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
+    uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
+    float *const s_xd = reinterpret_cast<float *>(smem + XP_S_XD);
+    uint32_t *const s_xs = reinterpret_cast<uint32_t *>(smem + XP_S_XS);
+    double *const s_red = reinterpret_cast<double *>(smem + XP_S_RED);
+    uint32_t *const s_hq = reinterpret_cast<uint32_t *>(smem + XP_S_HQ);
+    float *const s_hd = reinterpret_cast<float *>(smem + XP_S_HD);
+    uint32_t *const s_hs = reinterpret_cast<uint32_t *>(smem + XP_S_HS);
+    float *const s_part = reinterpret_cast<float *>(smem + XP_S_PART);
+    float *const s_g = reinterpret_cast<float *>(smem + XP_S_G);
+    float *const s_ln = reinterpret_cast<float *>(smem + XP_S_LN);
+    float *const s_bias = reinterpret_cast<float *>(smem + XP_S_BIAS);
+    float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
+    float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
+    float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 192);
+    double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
+    double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
+    uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+
+    // Which XCD am I on, and which of its 32 workgroups am I ?  HW_REG_XCC_ID says where; a per-XCD ticket (monotonic across
+    // launches: launch n hands out 32 (n - 1) .. 32 n - 1) says which.  The dispatcher deals workgroups round-robin over the
+    // XCDs, so a launch that has the device to itself gets exactly 32 per XCD whatever the starting point; a launch interleaved
+    // with another stream's workgroups may not -- then a 33rd arrival raises the error word and the launch drains.
+    const uint32_t epoch0 = __hip_atomic_load(p.ctl, XP_RLX);
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;     // HW_REG_XCC_ID, bits 0..3
+        const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
+        s_redi[0] = (int)xcc;
+        s_redi[1] = (int)(t - 32u * (__hip_atomic_load(p.ctl + 2, XP_RLX) - 1u));
+    }
+    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
+    __syncthreads();
+    if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
+    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
+    const int t_cap = p.t_cap;
+
+    // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
+    // in fp16) nor -0 (x <= -5.42): kept in LDS for the whole launch, fc1's 128 rows per workgroup look it up there
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
+        const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
+        for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
+        for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
+    }
+    if (slot < 16) xp_run<WT, LPK, NW, KCAP, true>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    else xp_run<WT, LPK, NW, KCAP, false>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
 }
 
 // where workgroup b of a 256-workgroup launch runs: the host checks b % 8 once per device before it trusts the pipeline
