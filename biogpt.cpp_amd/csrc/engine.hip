@@ -792,7 +792,9 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 }
 
 // l0 / l1 / only: biogpt_hip_bench_matvec launches one kernel of one layer; the decode step is all layers + lm_head
-bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1) {
+// host_row (optional): pinned host buffer that also receives the logits row; *host_row_done tells whether the launch wrote it itself
+bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1, float *host_row = nullptr,
+                          bool *host_row_done = nullptr) {
     t_ctx = c;
     (void)hipGetLastError();
     const auto &hp = c->hp;
@@ -831,8 +833,9 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             xp.lm_blocks = lm_parts; xp.adv = fold ? advance : 0; xp.n_tok = n_tok; xp.samp = c->xp_samp;   // no lm_head in here: the lm_head launch moves the position
             xp.Wlm = dev_matrix(c, m);
             xp.lm_ln_w = dev_vec(c, c->plan.ln_w); xp.lm_ln_b = dev_vec(c, c->plan.ln_b);
-            xp.logits = c->logits; xp.pmax_out_val = c->pmax_val; xp.pmax_out_idx = c->pmax_idx;
+            xp.logits = c->logits; xp.logits_host = fold ? host_row : nullptr; xp.pmax_out_val = c->pmax_val; xp.pmax_out_idx = c->pmax_idx;
             lm_in_kernel = fold;
+            if (host_row_done) *host_row_done = fold && host_row != nullptr;
             if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
         }
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
@@ -1503,8 +1506,9 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
                 hipGraph_t g = nullptr;
                 HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
                 if (sgi == 0) hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
-                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1]);
-                if (ok && form == 1 && sgi == nseg - 1)
+                bool row_done = false;
+                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1], -1, 1, form == 1 ? ctx->logits_host : nullptr, &row_done);
+                if (ok && form == 1 && sgi == nseg - 1 && !row_done)
                     hipLaunchKernelGGL(bgk::logits_to_host_kernel, dim3((unsigned)((V + 1023) / 1024)), dim3(256), 0, ctx->stream, ctx->logits, ctx->logits_host, (int)V);
                 const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
                 if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }

@@ -684,13 +684,15 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, 
     }
     __syncthreads();
     const float t0 = s_t0;
-    // 2. one sweep over the row, 8 loads in flight per thread
-    for (int i0 = tid; i0 < V; i0 += 8 * 1024) {
-        float x[8];
+    // 2. one sweep over the row, 24 loads in flight per thread (the row was written by other compute units: every round is a
+    //    trip to the memory side, and 42384 logits are two rounds instead of six)
+    constexpr int TK_U = 24;
+    for (int i0 = tid; i0 < V; i0 += TK_U * 1024) {
+        float x[TK_U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = (i0 + 1024 * u < V) ? logits[i0 + 1024 * u] : -INFINITY;
+        for (int u = 0; u < TK_U; u++) x[u] = (i0 + 1024 * u < V) ? logits[i0 + 1024 * u] : -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < TK_U; u++) {
             if (i0 + 1024 * u < V && x[u] >= t0) {
                 const int slot = atomicAdd(&s_n, 1);
                 if (slot < TOPK_CAP) { s_cv[slot] = x[u]; s_ci[slot] = i0 + 1024 * u; }

@@ -84,6 +84,7 @@ struct XpParams {
     DevMatrix Wlm;
     const float *lm_ln_w, *lm_ln_b;
     float *logits;
+    float *logits_host;        // optional pinned host copy of the row (biogpt_eval's output): written by the same lanes, no copy node behind the launch
     float *pmax_out_val; int32_t *pmax_out_idx;
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
 };
@@ -719,6 +720,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (row < p.n_vocab) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
                 p.logits[row] = v;
+                if (p.logits_host) p.logits_host[row] = v;
                 best_val = v; best_idx = row;
             }
         }
