@@ -166,10 +166,6 @@ constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 256 * DEC_PS, "fc2 block terms fit the shared region");
 __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP_S_TOTAL + (size_t)gelu_entries * 2; }
 
-// stacked [q; k; v] row computed by lane group j (0..95) of workgroup `slot`: workgroups h and h + 16 share head h
-__device__ __forceinline__ int xp_qkv_local(int slot, int j) { return (slot >> 4) * 96 + j; }                 // 0..191: q | k | v of the head
-__device__ __forceinline__ int xp_qkv_row(int slot, int j) { const int jj = xp_qkv_local(slot, j); return (jj >> 6) * 1024 + (slot & 15) * 64 + (jj & 63); }
-
 // The launch's work for one role: ATTN = this workgroup is one of the XCD's 16 attention heads (else it computes q/k/v rows).  The
 // role is a template parameter because the register allocator, given ONE function with a run-time role branch, spills 21-39 VGPRs
 // although each role alone fits (measured: 198-240 of 256 registers per role): two copies of the loop, no spills.
@@ -177,7 +173,7 @@ template <int WT, int LPK, int NW, int KCAP, bool ATTN>
 __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
                                        const int n_gen0) {
     using TI = TypeInfo<WT>;
-    static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
+    static_assert(TI::quant && WT != W_Q8_0, "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit)");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
@@ -771,7 +767,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 template <int WT, int LPK, int NW, int KCAP>
 __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     using TI = TypeInfo<WT>;
-    static_assert(TI::quant && WT != W_Q8_0, "12 weight units per lane must fit the register file");
+    static_assert(TI::quant && WT != W_Q8_0, "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit)");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
