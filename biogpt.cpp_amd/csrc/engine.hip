@@ -586,14 +586,22 @@ void xpipe_release(biogpt_hip_ctx *c) {
 bool xpipe_model_ok(const biogpt_hip_ctx *c) {
     const auto &hp = c->hp;
     const int32_t wt = ftype_to_type(hp.ftype);
-    return (wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 &&
+    return (wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1 || wt == T_Q8_0) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 &&
            hp.n_positions >= 64 && hp.n_layer >= 1;
 }
 
+// Q8_0 (9 registers per weight unit) runs with split layers: attention half and MLP half of a layer on consecutive XCDs
+template <int WT> constexpr bool xpipe_split() { return WT == bgk::W_Q8_0; }
+// pipeline units of the model: layers, or half layers; the XCD of the last one (and XCD 0) computes no lm_head rows
+int xpipe_last_xcd(const biogpt_hip_ctx *c) {
+    const int units = (ftype_to_type(c->hp.ftype) == T_Q8_0 ? 2 : 1) * c->hp.n_layer;
+    return (units - 1) & 7;
+}
 template <int WT>
 bool xpipe_set_lds_t(size_t sm) {
-    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256>)};
+    constexpr bool SP = xpipe_split<WT>();
+    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, SP>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, SP>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, SP>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, SP>)};
     for (const void *fn : fns)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return false;
     return true;
@@ -607,6 +615,7 @@ bool xpipe_set_lds(biogpt_hip_ctx *c) {
         case T_Q4_1: return xpipe_set_lds_t<bgk::W_Q4_1>(sm);
         case T_Q5_0: return xpipe_set_lds_t<bgk::W_Q5_0>(sm);
         case T_Q5_1: return xpipe_set_lds_t<bgk::W_Q5_1>(sm);
+        case T_Q8_0: return xpipe_set_lds_t<bgk::W_Q8_0>(sm);
         default: return false;
     }
 }
@@ -710,7 +719,7 @@ int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
     if (!fused_decode_ok(c, tmax) || !xpipe_usable(c, tmax)) return 0;
     const auto &hp = c->hp;
     const MatSlot &m = c->plan.lm_head;
-    const int lm_parts = fast_lm_grid(c), last_xcd = (hp.n_layer - 1) & 7, lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));
+    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));
     if (!(m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024)) return 0;
     return tmax - T + 1;
 }
@@ -719,10 +728,11 @@ template <int WT>
 hipError_t launch_xpipe(biogpt_hip_ctx *c, const bgk::XpParams &xp) {
     const size_t sm = bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n);
     // 8 waves per workgroup: 24 weight units per lane (120 VGPRs) + the head's old keys / values fit the 256-register budget
-    if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64>), dim3(256), dim3(512), sm, c->stream, xp);
-    else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128>), dim3(256), dim3(512), sm, c->stream, xp);
-    else if (xp.t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192>), dim3(256), dim3(512), sm, c->stream, xp);   // 24 instead of 32 value registers
-    else hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256>), dim3(256), dim3(512), sm, c->stream, xp);
+    constexpr bool SP = xpipe_split<WT>();
+    if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, SP>), dim3(256), dim3(512), sm, c->stream, xp);
+    else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, SP>), dim3(256), dim3(512), sm, c->stream, xp);
+    else if (xp.t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, SP>), dim3(256), dim3(512), sm, c->stream, xp);   // 24 instead of 32 value registers
+    else hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, SP>), dim3(256), dim3(512), sm, c->stream, xp);
     return hipGetLastError();
 }
 
@@ -827,7 +837,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.x_final = c->x;
         {   // lm_head inside the launch: its 64-row blocks (= the stand-alone launch's workgroups) three per workgroup of 7 XCDs
             const MatSlot &m = c->plan.lm_head;
-            const int last_xcd = (hp.n_layer - 1) & 7, lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last layer's XCD take no part
+            const int last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last unit's XCD take no part
             const bool fold = c->opt.xpipe_lm && m.type == wt && m.K == 1024 && m.M == V && lm_parts == (V + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
             xp.lm = fold ? 1 : 0;
             xp.lm_blocks = lm_parts; xp.adv = fold ? advance : 0; xp.n_tok = n_tok; xp.samp = c->xp_samp;   // no lm_head in here: the lm_head launch moves the position
@@ -845,6 +855,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             case T_Q4_1: e = launch_xpipe<bgk::W_Q4_1>(c, xp); break;
             case T_Q5_0: e = launch_xpipe<bgk::W_Q5_0>(c, xp); break;
             case T_Q5_1: e = launch_xpipe<bgk::W_Q5_1>(c, xp); break;
+            case T_Q8_0: e = launch_xpipe<bgk::W_Q8_0>(c, xp); break;
             default: break;
         }
         HIP_TRY(false, e);

@@ -169,11 +169,17 @@ __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP
 // The launch's work for one role: ATTN = this workgroup is one of the XCD's 16 attention heads (else it computes q/k/v rows).  The
 // role is a template parameter because the register allocator, given ONE function with a run-time role branch, spills 21-39 VGPRs
 // although each role alone fits (measured: 198-240 of 256 registers per role): two copies of the loop, no spills.
-template <int WT, int LPK, int NW, int KCAP, bool ATTN>
+// SPLIT (Q8_0: 9 registers per weight unit, a whole layer does not fit one XCD's registers): a layer is two pipeline units -- LayerNorm,
+// q/k/v, attention, out_proj on an EVEN XCD (roles 0 / 1), LayerNorm, fc1, fc2 on the next, ODD XCD (role 2: all 32 workgroups) -- and
+// the out_proj output crosses XCDs like the layer output does.
+template <int WT, int LPK, int NW, int KCAP, int ROLE, bool SPLIT>
 __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
                                        const int n_gen0) {
     using TI = TypeInfo<WT>;
-    static_assert(TI::quant && WT != W_Q8_0, "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit)");
+    static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit: split layers)");
+    static_assert(ROLE == 0 || ROLE == 1 || (ROLE == 2 && SPLIT), "0 attention head, 1 q/k/v rows, 2 (split layers) the MLP half");
+    constexpr bool ATTN = ROLE == 0;
+    constexpr bool FIRST = !SPLIT || ROLE != 2, SECOND = !SPLIT || ROLE == 2;      // which stages this workgroup runs
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
@@ -201,14 +207,16 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
     const int t_cap = p.t_cap;
-    const int last_xcd = (p.n_layer - 1) & 7;
+    const int n_units = SPLIT ? 2 * p.n_layer : p.n_layer;                     // pipeline units: layers, or half layers
+    const int last_xcd = (n_units - 1) & 7;
     // Several tokens per launch (n_tok > 1: the device-resident generation loop): token t + 1 starts from the arg-max partials of
     // token t's logits, handed to XCD 0 as granules; the hand-off tag is the launch counter + the token's index in the launch.
     for (int tk = 0; tk < p.n_tok; tk++) {
     const uint32_t epoch = epoch0 + (uint32_t)tk;
     const int n_past = n_past0 + tk, T = n_past + 1;
     if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;       // a disturbed launch drains token by token
-    for (int L = xcd; L < p.n_layer; L += 8) {
+    for (int U = xcd; U < n_units; U += 8) {
+        const int L = SPLIT ? (U >> 1) : U;
         // the thread index goes through an empty asm in every iteration: without it the compiler hoists a few hundred
         // per-thread addresses (LDS carve, granule slots, weight rows) out of the layer loop and spills them (120 VGPRs
         // of "folded spills" measured); recomputing them costs a handful of integer instructions per stage
@@ -217,9 +225,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         const int lane = tid & 63, wave = tid >> 6;
         const int sub = lane & 31, rsub = lane >> 5;
         const bool worker = tid < 256;
-        if (tk == 0 && L == xcd && L >= 2) {      // start this XCD's first weight load when layer L - 1 starts, not all eight at once
+        if (tk == 0 && U == xcd && U >= 2) {      // start this XCD's first weight load when unit U - 1 starts, not all eight at once
             if (tid == 0) {
-                const xp_u64 *g = p.gran + (size_t)(L - 2) * XP_G_LAYER + XP_G_X;
+                // the output of unit U - 2: a layer's x, or (split layers, U - 2 has U's parity) the first half's x1 / the second half's x
+                const xp_u64 *g = SPLIT ? p.gran + (size_t)(L - 1) * XP_G_LAYER + (ROLE != 2 ? XP_G_X1 : XP_G_X) : p.gran + (size_t)(L - 2) * XP_G_LAYER + XP_G_X;
                 for (uint32_t spins = 0;; spins++) {
                     if ((uint32_t)(__hip_atomic_load(g, XP_RLX) >> 32) == epoch) break;
                     if (spins >= XP_SPIN_MAX) { xp_fail(p, 3u); break; }
@@ -240,25 +249,29 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         {
             float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0;
             if (worker) {
-                l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid];
-                l2 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l3 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid];
+                if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
+                if (SECOND) { l2 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l3 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
             }
             float bv = 0.0f;
-            if (tid < 192) bv = Y.bqkv[(tid >> 6) * 1024 + head * 64 + (tid & 63)];
-            else if (tid < 224) bv = Y.bo[slot * 32 + tid - 192];
-            else if (tid < 352) bv = Y.b1[slot * 128 + tid - 224];
-            else if (tid < 384) bv = Y.b2[slot * 32 + tid - 352];
+            if (tid < 192) { if (FIRST) bv = Y.bqkv[(tid >> 6) * 1024 + head * 64 + (tid & 63)]; }
+            else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
+            else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
+            else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
+            if (FIRST) {
 #pragma unroll
-            for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+            }
+            if (SECOND) {
 #pragma unroll
-            for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
 #pragma unroll
-            for (int r = 0; r < F2R; r++)
+                for (int r = 0; r < F2R; r++)
 #pragma unroll
-                for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+                    for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+            }
             if (worker) {
-                reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1;
-                reinterpret_cast<float4 *>(s_ln + 2048)[tid] = l2; reinterpret_cast<float4 *>(s_ln + 3072)[tid] = l3;
+                if (FIRST) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
+                if (SECOND) { reinterpret_cast<float4 *>(s_ln + 2048)[tid] = l2; reinterpret_cast<float4 *>(s_ln + 3072)[tid] = l3; }
             }
             if (tid < 384) s_bias[tid] = bv;
         }
@@ -368,6 +381,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             return xv;
         };
+        if constexpr (FIRST) {
         if (!attn_wg) {
             // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
             Unit<WT> wqkv[QS];
@@ -546,10 +560,13 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (lane < 2 * OS) {
                 const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
-                xp_put_local(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));
+                if (SPLIT) xp_put(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
+                else xp_put_local(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));
             }
         }
         XP_WALL(3);
+        }   // FIRST
+        if constexpr (SECOND) {
         // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
         if (wave < 4) {
@@ -666,7 +683,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
         }
         XP_WALL(5);
-        __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next layer of this XCD
+        }   // SECOND
+        __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit of this XCD
     }
     // ================= final LayerNorm + lm_head (biogpt.cpp:799-811): the XCDs that are done with their layers =================
     // Their weights (four 64-row blocks = 16 units per lane) are loaded as soon as the workgroup's last layer of this token is
@@ -764,10 +782,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     }
 }
 
-template <int WT, int LPK, int NW, int KCAP>
+template <int WT, int LPK, int NW, int KCAP, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     using TI = TypeInfo<WT>;
-    static_assert(TI::quant && WT != W_Q8_0, "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit)");
+    static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "Q8_0 (9 registers per weight unit) runs with split layers");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
@@ -822,8 +840,11 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
     }
-    if (slot < 16) xp_run<WT, LPK, NW, KCAP, true>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
-    else xp_run<WT, LPK, NW, KCAP, false>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    if constexpr (SPLIT) {
+        if (xcd & 1) { xp_run<WT, LPK, NW, KCAP, 2, true>(p, smem, xcd, slot, epoch0, n_past0, n_gen0); return; }
+    }
+    if (slot < 16) xp_run<WT, LPK, NW, KCAP, 0, SPLIT>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    else xp_run<WT, LPK, NW, KCAP, 1, SPLIT>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
 }
 
 // where workgroup b of a 256-workgroup launch runs: the host checks b % 8 once per device before it trusts the pipeline

@@ -240,7 +240,7 @@ def test_opt_in_causal_mask(pkg, oracle, files, monkeypatch, name):
 
 # ---- XCD-pipelined decode step (csrc/kernels_xpipe.hip.h): ONE persistent launch for all layers -----------------------------
 
-XPIPE_TYPES = ["q4_0", "q4_1", "q5_0", "q5_1"]
+XPIPE_TYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"]
 
 
 def _with_xpipe(g, monkeypatch, on):
@@ -294,7 +294,7 @@ def test_xpipe_step_is_bit_identical_to_the_five_launch_layer_and_the_oracle(pkg
     g.close()
 
 
-@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
 def test_xpipe_generation_equals_the_oracle(pkg, oracle, files, monkeypatch, name):
     """Greedy generation (device-resident sampler folded into the pipeline's first stage) through all three pipeline buckets
     and across the hand-over to the five-launch graphs at 257 keys: the oracle's ids, and the ids with the pipeline off."""
