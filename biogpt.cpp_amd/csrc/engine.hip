@@ -591,10 +591,10 @@ bool xpipe_model_ok(const biogpt_hip_ctx *c) {
 }
 
 // Q8_0 (9 registers per weight unit) runs with split layers: attention half and MLP half of a layer on consecutive XCDs
-template <int WT> constexpr bool xpipe_split() { return WT == bgk::W_Q8_0; }
+template <int WT> constexpr bool xpipe_split() { return true; }
 // pipeline units of the model: layers, or half layers; the XCD of the last one (and XCD 0) computes no lm_head rows
 int xpipe_last_xcd(const biogpt_hip_ctx *c) {
-    const int units = (ftype_to_type(c->hp.ftype) == T_Q8_0 ? 2 : 1) * c->hp.n_layer;
+    const int units = 2 * c->hp.n_layer;
     return (units - 1) & 7;
 }
 template <int WT>

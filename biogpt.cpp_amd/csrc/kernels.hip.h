@@ -318,6 +318,45 @@ __device__ __forceinline__ float unit_dot_quant(const Unit<WT> &u, const uint32_
     return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), (float)s), __fmul_rn(mw, xs_f));
 }
 
+// A 4- / 5-bit unit unpacked IN REGISTERS to 32 bytes (q0: elements 0..15, q1: elements 16..31, still unsigned 0..15 / 0..31): the
+// XCD-pipelined decode kernel does this while the weights wait for their layer's turn, so the dependent chain of a stage holds
+// 8 dot4 per unit instead of 8 dot4 + 16 (Q4) or 64 (Q5) unpack instructions.  unit_dot_expanded == unit_dot_quant bit for bit.
+template <int WT>
+__device__ __forceinline__ void expand_unit(Unit<WT> &u) {
+    static_assert(WT == W_Q4_0 || WT == W_Q4_1 || WT == W_Q5_0 || WT == W_Q5_1, "nibble formats");
+    const uint32_t q[4] = {u.q0.x, u.q0.y, u.q0.z, u.q0.w};
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        lo[i] = q[i] & 0x0F0F0F0Fu;
+        hi[i] = (q[i] >> 4) & 0x0F0F0F0Fu;
+        if (WT == W_Q5_0 || WT == W_Q5_1) {
+            lo[i] |= spread4(u.qh >> (4 * i));
+            hi[i] |= spread4(u.qh >> (16 + 4 * i));
+        }
+    }
+    u.q0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    u.q1 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+template <int WT>
+__device__ __forceinline__ float unit_dot_expanded(const Unit<WT> &u, const uint32_t *xq, float xd, float xs_f, int xs_i) {
+    const uint4 xa = *reinterpret_cast<const uint4 *>(xq);
+    const uint4 xb = *reinterpret_cast<const uint4 *>(xq + 4);
+    int s = 0;
+    s = dot4(u.q0.x, xa.x, s); s = dot4(u.q0.y, xa.y, s); s = dot4(u.q0.z, xa.z, s); s = dot4(u.q0.w, xa.w, s);
+    s = dot4(u.q1.x, xb.x, s); s = dot4(u.q1.y, xb.y, s); s = dot4(u.q1.z, xb.z, s); s = dot4(u.q1.w, xb.w, s);
+    if (WT == W_Q4_0) {
+        s -= 8 * xs_i;
+        return __fmul_rn(__fmul_rn((float)s, h2f((uint16_t)u.sc)), xd);
+    }
+    if (WT == W_Q5_0) {
+        s -= 16 * xs_i;
+        return __fmul_rn(__fmul_rn(h2f((uint16_t)u.sc), xd), (float)s);
+    }
+    const float dw = h2f((uint16_t)(u.sc & 0xFFFFu)), mw = h2f((uint16_t)(u.sc >> 16));
+    return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), (float)s), __fmul_rn(mw, xs_f));
+}
+
 template <int WT>
 __device__ __forceinline__ double unit_dot_float(const Unit<WT> &u, const float *xf) {
     double acc = 0.0;

@@ -166,6 +166,22 @@ constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 256 * DEC_PS, "fc2 block terms fit the shared region");
 __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP_S_TOTAL + (size_t)gelu_entries * 2; }
 
+// nibble formats travel through the stages unpacked (EXPAND = every type but Q8_0; needs split layers: 9 registers per unit)
+template <int WT, bool EXPAND>
+__device__ __forceinline__ float xp_dot(const Unit<WT> &u, const uint32_t *xq, float xd, float xs_f, int xs_i) {
+    if constexpr (EXPAND) return unit_dot_expanded<WT>(u, xq, xd, xs_f, xs_i);
+    else return unit_dot_quant<WT>(u, xq, xd, xs_f, xs_i);
+}
+// unpack a freshly loaded unit and keep the result in registers HERE (the empty asm stops the scheduler from sinking the unpack
+// instructions back to the unit's use, where they would sit on the stage's dependent chain again)
+template <int WT, bool EXPAND>
+__device__ __forceinline__ void xp_settle(Unit<WT> &u) {
+    if constexpr (EXPAND) {
+        expand_unit<WT>(u);
+        asm volatile("" : "+v"(u.q0.x), "+v"(u.q0.y), "+v"(u.q0.z), "+v"(u.q0.w), "+v"(u.q1.x), "+v"(u.q1.y), "+v"(u.q1.z), "+v"(u.q1.w));
+    }
+}
+
 // The launch's work for one role: ATTN = this workgroup is one of the XCD's 16 attention heads (else it computes q/k/v rows).  The
 // role is a template parameter because the register allocator, given ONE function with a run-time role branch, spills 21-39 VGPRs
 // although each role alone fits (measured: 198-240 of 256 registers per role): two copies of the loop, no spills.
@@ -179,6 +195,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit: split layers)");
     static_assert(ROLE == 0 || ROLE == 1 || (ROLE == 2 && SPLIT), "0 attention head, 1 q/k/v rows, 2 (split layers) the MLP half");
     constexpr bool ATTN = ROLE == 0;
+    constexpr bool EXPAND = SPLIT && WT != W_Q8_0;
     constexpr bool FIRST = !SPLIT || ROLE != 2, SECOND = !SPLIT || ROLE == 2;      // which stages this workgroup runs
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
@@ -274,6 +291,18 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 if (SECOND) { reinterpret_cast<float4 *>(s_ln + 2048)[tid] = l2; reinterpret_cast<float4 *>(s_ln + 3072)[tid] = l3; }
             }
             if (tid < 384) s_bias[tid] = bv;
+            if constexpr (EXPAND) {      // waits for the loads: idle time, the unit's turn is layers away
+                if (FIRST) {
+#pragma unroll
+                    for (int s = 0; s < OS; s++) xp_settle<WT, EXPAND>(wo[s]);
+                }
+                if (SECOND) {
+#pragma unroll
+                    for (int s = 0; s < FS; s++) xp_settle<WT, EXPAND>(w1[s]);
+#pragma unroll
+                    for (int r = 0; r < F2R; r++) { xp_settle<WT, EXPAND>(w2[r][0]); xp_settle<WT, EXPAND>(w2[r][1]); }
+                }
+            }
         }
         // the layer input, 4 elements per LayerNorm worker (waves 0-3): the embedding (layer 0) or the previous layer's granules
         auto layer_input = [&]() -> float4 {
@@ -390,6 +419,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int jj = s * 2 * NW + wave * 2 + rsub;
                 load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
             }
+#pragma unroll
+            for (int s = 0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
             const float4 xv = layer_input();
             XP_WALL(0);
             float4 lnw = xv, lnb = xv;
@@ -406,7 +437,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const uint32_t axs = s_xs[sub];
             float *const part = s_part + wave * 2 * QS * DEC_PS;
 #pragma unroll
-            for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+            for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -553,7 +584,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const uint32_t axs = s_xs[sub];
             float *const part = s_part + wave * 2 * OS * DEC_PS;
 #pragma unroll
-            for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
+            for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -587,7 +618,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const uint32_t axs = s_xs[sub];
             float *const part = s_part + wave * 2 * FS * DEC_PS;
 #pragma unroll
-            for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
+            for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -657,7 +688,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const float axd = s_hd[u];
                 const uint32_t axs = s_hs[u];
 #pragma unroll
-                for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = unit_dot_quant<WT>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
+                for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = xp_dot<WT, EXPAND>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -707,6 +738,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
             else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
         }
+#pragma unroll
+        for (int s = 0; s < LMS; s++) xp_settle<WT, EXPAND>(wl[s]);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
         if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
         if (wave < 4) {
@@ -722,7 +755,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         const uint32_t axs = s_xs[sub];
         float *const part = s_part + wave * 2 * LMS * DEC_PS;
 #pragma unroll
-        for (int s = 0; s < LMS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
+        for (int s = 0; s < LMS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
