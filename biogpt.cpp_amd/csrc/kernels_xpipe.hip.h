@@ -10,9 +10,11 @@
 //
 // Shape: grid = 256 workgroups x 512 threads, one per compute unit.  A workgroup reads its XCD from HW_REG_XCC_ID and takes
 // its rank inside the XCD from a per-XCD arrival ticket (the host probes the device once: 8 XCDs, workgroups dealt evenly).
-// Layer l is computed by the 32 workgroups of XCD l % 8.  While the other XCDs compute their layers, an XCD loads the weights
-// of ITS next layer into registers (7.08 MB of Q4_0 per layer = 221 KB per compute unit = 18-30 block units per lane, 90-150
-// of a lane's 256 VGPRs), so a layer's stages never wait for weights: stage latency = hand-off + arithmetic.
+// A layer is two pipeline units: stages A-C (LayerNorm, q/k/v, attention, out_proj) on the 32 workgroups of an EVEN XCD, stages
+// D-E (LayerNorm, fc1, fc2) on those of the next, ODD XCD; unit u runs on XCD u % 8.  While the other XCDs compute their units,
+// an XCD loads the weights of ITS next unit into registers (8-16 block units per lane) and unpacks the nibble formats there
+// to one byte per weight, so a stage never waits for weights and its chain holds 8 v_dot4 per unit: stage latency = hand-off
+// + arithmetic.  (SPLIT = false keeps a whole layer on one XCD with packed units: measured slower, kept for comparison.)
 //
 //   stage A  (workgroups 16-31 of the XCD) x -- granules from the previous layer's XCD, or the embedding of the sampled token --
 //            -> LayerNorm -> Q8 -> all 192 q/k/v rows of head slot - 16; KV append; the rows go to workgroup slot - 16
