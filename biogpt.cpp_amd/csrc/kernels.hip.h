@@ -338,6 +338,38 @@ __device__ __forceinline__ void expand_unit(Unit<WT> &u) {
     u.q0 = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     u.q1 = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
+// ... and the fp16 scale converted to f32 once (u.sc = bits of d; not for Q4_1 / Q5_1).  Q8_0 units take part too (settle_unit only
+// converts their scale).
+template <int WT>
+__device__ __forceinline__ void settle_unit(Unit<WT> &u) {
+    if constexpr (WT != W_Q8_0) expand_unit<WT>(u);
+    // Q4_1 / Q5_1 keep {d, m} packed: two f32 would be a tenth register per unit (8-9 spilled VGPRs measured in the 256-key variant)
+    if constexpr (WT != W_Q4_1 && WT != W_Q5_1) u.sc = __float_as_uint(h2f((uint16_t)u.sc));
+}
+// unit_dot_quant on a settled unit, bit for bit
+template <int WT>
+__device__ __forceinline__ float unit_dot_settled(const Unit<WT> &u, const uint32_t *xq, float xd, float xs_f, int xs_i) {
+    const uint4 xa = *reinterpret_cast<const uint4 *>(xq);
+    const uint4 xb = *reinterpret_cast<const uint4 *>(xq + 4);
+    int s = 0;
+    s = dot4(u.q0.x, xa.x, s); s = dot4(u.q0.y, xa.y, s); s = dot4(u.q0.z, xa.z, s); s = dot4(u.q0.w, xa.w, s);
+    s = dot4(u.q1.x, xb.x, s); s = dot4(u.q1.y, xb.y, s); s = dot4(u.q1.z, xb.z, s); s = dot4(u.q1.w, xb.w, s);
+    if (WT == W_Q4_1 || WT == W_Q5_1) {
+        const float d1 = h2f((uint16_t)(u.sc & 0xFFFFu)), m1 = h2f((uint16_t)(u.sc >> 16));
+        return __fadd_rn(__fmul_rn(__fmul_rn(d1, xd), (float)s), __fmul_rn(m1, xs_f));
+    }
+    const float dw = __uint_as_float(u.sc);
+    if (WT == W_Q8_0) return __fmul_rn((float)s, __fmul_rn(dw, xd));
+    if (WT == W_Q4_0) {
+        s -= 8 * xs_i;
+        return __fmul_rn(__fmul_rn((float)s, dw), xd);
+    }
+    if (WT == W_Q5_0) {
+        s -= 16 * xs_i;
+    }
+    return __fmul_rn(__fmul_rn(dw, xd), (float)s);      // Q5_0
+}
+
 template <int WT>
 __device__ __forceinline__ float unit_dot_expanded(const Unit<WT> &u, const uint32_t *xq, float xd, float xs_f, int xs_i) {
     const uint4 xa = *reinterpret_cast<const uint4 *>(xq);

@@ -168,10 +168,11 @@ constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 256 * DEC_PS, "fc2 block terms fit the shared region");
 __host__ __device__ inline size_t xpipe_smem_bytes(int gelu_entries) { return XP_S_TOTAL + (size_t)gelu_entries * 2; }
 
-// nibble formats travel through the stages unpacked (EXPAND = every type but Q8_0; needs split layers: 9 registers per unit)
+// units travel through the stages settled -- nibbles unpacked to bytes, fp16 scales converted to f32 (EXPAND; needs split layers: 9-10
+// registers per unit)
 template <int WT, bool EXPAND>
 __device__ __forceinline__ float xp_dot(const Unit<WT> &u, const uint32_t *xq, float xd, float xs_f, int xs_i) {
-    if constexpr (EXPAND) return unit_dot_expanded<WT>(u, xq, xd, xs_f, xs_i);
+    if constexpr (EXPAND) return unit_dot_settled<WT>(u, xq, xd, xs_f, xs_i);
     else return unit_dot_quant<WT>(u, xq, xd, xs_f, xs_i);
 }
 // unpack a freshly loaded unit and keep the result in registers HERE (the empty asm stops the scheduler from sinking the unpack
@@ -179,8 +180,8 @@ __device__ __forceinline__ float xp_dot(const Unit<WT> &u, const uint32_t *xq, f
 template <int WT, bool EXPAND>
 __device__ __forceinline__ void xp_settle(Unit<WT> &u) {
     if constexpr (EXPAND) {
-        expand_unit<WT>(u);
-        asm volatile("" : "+v"(u.q0.x), "+v"(u.q0.y), "+v"(u.q0.z), "+v"(u.q0.w), "+v"(u.q1.x), "+v"(u.q1.y), "+v"(u.q1.z), "+v"(u.q1.w));
+        settle_unit<WT>(u);
+        asm volatile("" : "+v"(u.q0.x), "+v"(u.q0.y), "+v"(u.q0.z), "+v"(u.q0.w), "+v"(u.q1.x), "+v"(u.q1.y), "+v"(u.q1.z), "+v"(u.q1.w), "+v"(u.sc));
     }
 }
 
@@ -197,7 +198,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit: split layers)");
     static_assert(ROLE == 0 || ROLE == 1 || (ROLE == 2 && SPLIT), "0 attention head, 1 q/k/v rows, 2 (split layers) the MLP half");
     constexpr bool ATTN = ROLE == 0;
-    constexpr bool EXPAND = SPLIT && WT != W_Q8_0;
+    constexpr bool EXPAND = SPLIT;      // units are settled (nibbles unpacked, scales converted) while they wait; Q8_0: the scale only
     constexpr bool FIRST = !SPLIT || ROLE != 2, SECOND = !SPLIT || ROLE == 2;      // which stages this workgroup runs
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
