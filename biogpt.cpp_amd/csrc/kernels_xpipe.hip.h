@@ -161,8 +161,8 @@ constexpr int XP_S_LN = XP_S_G + 512;            // [4][1024] f32 ln0_w, ln0_b, 
 constexpr int XP_S_BIAS = XP_S_LN + 16384;       // [192 + 32 + 128 + 32] f32: q/k/v rows of the head, out_proj / fc1 / fc2 rows of the workgroup
 constexpr int XP_S_CUR = XP_S_BIAS + 1536;       // [192] f32 q, k, v of this token (head = slot)
 constexpr int XP_S_S = XP_S_CUR + 768;           // [256] softmax numerators
-constexpr int XP_S_REDF = XP_S_S + 1024;         // [48] f32 + [48] int
-constexpr int XP_S_REDD = XP_S_REDF + 384;       // [16] double
+constexpr int XP_S_REDF = XP_S_S + 1024;         // [64] f32 + [64] int
+constexpr int XP_S_REDD = XP_S_REDF + 512;       // [16] double
 constexpr int XP_S_PV = XP_S_REDD + 128;         // [1024] double
 constexpr int XP_S_TOTAL = XP_S_PV + 8192;
 static_assert(32 * DEC_PS2 <= 256 * DEC_PS, "fc2 block terms fit the shared region");
@@ -222,7 +222,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
     float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
     float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
-    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 192);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 256);
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
     float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
     float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
-    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 192);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 256);
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
