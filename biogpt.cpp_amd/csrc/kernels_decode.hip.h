@@ -665,38 +665,48 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, 
     __shared__ int s_n;
     const int tid = threadIdx.x;
     if (tid == 0) { s_t0 = -INFINITY; s_n = 0; }
+    // 0. the row's loads first (they do not depend on the threshold): up to 42 per thread, all in flight while step 1 runs -- the
+    //    row was written by other compute units, every round of loads is a trip to the memory side
+    constexpr int TK_U = 42;
+    float x[TK_U];
+#pragma unroll
+    for (int u = 0; u < TK_U; u++) x[u] = (tid + 1024 * u < V) ? logits[tid + 1024 * u] : -INFINITY;
     // 1. threshold: the partial maxima in 128 groups of 8; the k-th largest GROUP maximum is still the maximum of some
     //    workgroup, so at least k logits reach it -- a lower bound of the k-th largest logit, found with 128 x 128 compares
+    //    (8 threads per group, 16 compares each)
     const int np = min(nparts, 1024);
     float gm = (tid < np) ? pmax_val[tid] : -INFINITY;
     gm = group8_max(gm);
     if ((tid & 7) == 0) s_gm[tid >> 3] = gm;
     __syncthreads();
     const int ngroups = (np + 7) >> 3;
-    if (k <= ngroups && nparts <= 1024 && tid < 128) {
-        const float mine = s_gm[tid];
+    if (k <= ngroups && nparts <= 1024) {
+        const int gi = tid >> 3, j0 = (tid & 7) * 16;
+        const float mine = s_gm[gi];
         int beat = 0;
-        for (int j = 0; j < 128; j++) {
+#pragma unroll
+        for (int j = j0; j < j0 + 16; j++) {
             const float o = s_gm[j];
-            beat += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+            beat += (o > mine || (o == mine && j < gi)) ? 1 : 0;
         }
-        if (beat == k - 1) s_t0 = mine;
+        beat = group8_sum(beat);
+        if ((tid & 7) == 0 && beat == k - 1) s_t0 = mine;
     }
     __syncthreads();
     const float t0 = s_t0;
-    // 2. one sweep over the row, 24 loads in flight per thread (the row was written by other compute units: every round is a
-    //    trip to the memory side, and 42384 logits are two rounds instead of six)
-    constexpr int TK_U = 24;
-    for (int i0 = tid; i0 < V; i0 += TK_U * 1024) {
-        float x[TK_U];
+    // 2. the candidates: every logit that reaches the threshold
 #pragma unroll
-        for (int u = 0; u < TK_U; u++) x[u] = (i0 + 1024 * u < V) ? logits[i0 + 1024 * u] : -INFINITY;
-#pragma unroll
-        for (int u = 0; u < TK_U; u++) {
-            if (i0 + 1024 * u < V && x[u] >= t0) {
-                const int slot = atomicAdd(&s_n, 1);
-                if (slot < TOPK_CAP) { s_cv[slot] = x[u]; s_ci[slot] = i0 + 1024 * u; }
-            }
+    for (int u = 0; u < TK_U; u++) {
+        if (tid + 1024 * u < V && x[u] >= t0) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < TOPK_CAP) { s_cv[slot] = x[u]; s_ci[slot] = tid + 1024 * u; }
+        }
+    }
+    for (int i0 = tid + TK_U * 1024; i0 < V; i0 += 1024) {      // vocabularies beyond 43008 entries
+        const float xv = logits[i0];
+        if (xv >= t0) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < TOPK_CAP) { s_cv[slot] = xv; s_ci[slot] = i0; }
         }
     }
     __syncthreads();
