@@ -870,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
 
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
     // in fp16) nor -0 (x <= -5.42): kept in LDS for the whole launch, fc1's 128 rows per workgroup look it up there
-    {
+    if (!SPLIT || (xcd & 1)) {      // split layers: only the MLP halves (odd XCDs) look GELU up; XCD 0 starts layer 0 without the copy
         const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
         const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
