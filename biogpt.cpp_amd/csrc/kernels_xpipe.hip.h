@@ -14,7 +14,8 @@
 // D-E (LayerNorm, fc1, fc2) on those of the next, ODD XCD; unit u runs on XCD u % 8.  While the other XCDs compute their units,
 // an XCD loads the weights of ITS next unit into registers (8-16 block units per lane) and unpacks the nibble formats there
 // to one byte per weight, so a stage never waits for weights and its chain holds 8 v_dot4 per unit: stage latency = hand-off
-// + arithmetic.  (SPLIT = false keeps a whole layer on one XCD with packed units: measured slower, kept for comparison.)
+// + arithmetic.  (SPLIT = false -- a whole layer per XCD, packed units -- was this kernel's first form: 3.37 k against 3.65 k tok/s;
+// the host no longer instantiates it.)
 //
 //   stage A  (workgroups 16-31 of the XCD) x -- granules from the previous layer's XCD, or the embedding of the sampled token --
 //            -> LayerNorm -> Q8 -> all 192 q/k/v rows of head slot - 16; KV append; the rows go to workgroup slot - 16
