@@ -415,7 +415,17 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             return xv;
         };
         if constexpr (FIRST) {
-        if (!attn_wg) {
+        // split layers: the head's workgroup computes its OWN q / k / v rows (12 units beside the K / V rows fit now) -- the hand-over
+        // of the rows from a partner workgroup (0.58 us per layer) is gone; workgroups 16-31 only take part in out_proj
+        // (up to 128 keys: with the 56-64 K / V registers of the 192- / 256-key variants the 12 extra units spill 10-43 VGPRs, or fit
+        // exactly and run slower: 303 against 297 us per token at 161 keys)
+        constexpr bool MERGE = SPLIT && KCAP <= 128;
+        if (!attn_wg && MERGE) {
+            const float4 xv = layer_input();
+            if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;
+            XP_WALL(0);
+        }
+        if (!attn_wg && !MERGE) {
             // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
             Unit<WT> wqkv[QS];
 #pragma unroll
@@ -457,7 +467,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             XP_WALL(1);
-        } else {
+        }
+        if (attn_wg) {
             // ================= stage B (workgroups 0-15): attention of head `head` (biogpt.cpp:729-764) =================
             // the old keys / values of this head: in flight since the previous layer of this XCD finished
             float4 kr[NF4];
@@ -480,15 +491,59 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (j < t_cap) vr[k] = __builtin_nontemporal_load(vbase + (size_t)j * DK);
                 }
             }
-            {   // the layer input is the residual of stage C; it arrives about 2 us before the q / k / v rows
+            if constexpr (MERGE) {
+                // ---- stage A in here: LayerNorm -> Q8 -> the 192 q / k / v rows of this head, straight into s_cur ----
+                Unit<WT> wqkv[QS];
+#pragma unroll
+                for (int s = 0; s < QS; s++) {
+                    const int jj = s * 2 * NW + wave * 2 + rsub;
+                    load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+                }
+#pragma unroll
+                for (int s = 0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
                 const float4 xv = layer_input();
-                if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;
-            }
-            XP_WALL(0);
-            if (wave < 3) {
-                uint32_t v[1];
-                xp_sweep<1>(G + XP_G_QKV + wave * 1024 + head * 64 + lane, true, epoch, v, p);
-                s_cur[tid] = __uint_as_float(v[0]);
+                XP_WALL(0);
+                float4 lnw = xv, lnb = xv;
+                if (worker) {
+                    reinterpret_cast<float4 *>(s_x)[tid] = xv;
+                    lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
+                }
+                ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                XP_WALL(6);
+                uint32_t ax[8];
+                const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                const float axd = s_xd[sub];
+                const uint32_t axs = s_xs[sub];
+                float *const part = s_part + wave * 2 * QS * DEC_PS;
+#pragma unroll
+                for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 2 * QS) {
+                    const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                    float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
+                    const int which = jj >> 6, d = jj & 63;
+                    if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                    s_cur[jj] = v;
+                    if (which != 0) {                                               // KV append (biogpt.cpp:721-727), head-major cache
+                        float *cache = (which == 1) ? Y.kcache : Y.vcache;
+                        cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                    }
+                }
+                XP_WALL(1);
+            } else {
+                {   // the layer input is the residual of stage C; it arrives about 2 us before the q / k / v rows
+                    const float4 xv = layer_input();
+                    if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;
+                }
+                XP_WALL(0);
+                if (wave < 3) {
+                    uint32_t v[1];
+                    xp_sweep<1>(G + XP_G_QKV + wave * 1024 + head * 64 + lane, true, epoch, v, p);
+                    s_cur[tid] = __uint_as_float(v[0]);
+                }
             }
             __syncthreads();
             XP_WALL(7);
