@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# multi-process RCCL on this host driver needs dmabuf IPC (see biogpt.cpp_amd/replicas.py); read by the HSA runtime at the first HIP call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -344,6 +347,29 @@ def main():
                                     "note": "biogpt_eval_sample-style: eval + device top-40 per token (512 B to the host), C++ loop"}
         except Exception as e:  # keep the headline line even if a side measurement fails
             out["roofline_error"] = str(e)
+        # configs[3]: the same workload on the other block formats (same synthetic weights, quantized by the build's own quantizer), 3
+        # continuations each after one warm-up; each model is its own context on this device -- the pipeline slot is handed over
+        # between contexts whenever the holder has synchronised
+        if args.ftype == "q4_0" and not os.environ.get("BIOGPT_BENCH_SKIP_TYPES"):
+            for other in ("q5_1", "q8_0"):
+                try:
+                    mo = pkg.BiogptModel.load(ensure_model(pkg, args.workdir, other, args.n_layer), device=local_rank)
+                    mo.generate_greedy(make_prompt(hp.n_vocab, 1), n_predict, n_batch=8)
+                    t1 = time.perf_counter()
+                    for k in range(3):
+                        mo.generate_greedy(make_prompt(hp.n_vocab, 2 + k), n_predict, n_batch=8)
+                    mo.synchronize()
+                    dt = (time.perf_counter() - t1) / 3
+                    s1k = mo.bench_decode(1023, reps=20)
+                    b104, b1024 = pkg.decode_bytes_per_token(mo.hparams, 104), pkg.decode_bytes_per_token(mo.hparams, 1024)
+                    out["decode_" + other] = {"tokens_per_s": round(n_predict / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": 3,
+                                              "frac_of_peak_T104": round(b104 * n_predict / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                              "T=1024": {"us_per_token": round(s1k * 1e6, 2), "tokens_per_s": round(1.0 / s1k, 1),
+                                                         "frac_of_peak": round(b1024 / s1k / 1e9 / HBM_PEAK_GBS, 4)},
+                                              "xpipe_state": mo.xpipe_state()}
+                    mo.close()
+                except Exception as e:
+                    out["decode_" + other] = {"error": str(e)}
 
     # ---- CPU baseline: the oracle (restatement of the reference's ggml CPU path), bounded sample -----
     if world == 1 and not args.no_cpu_baseline and not prefill:

@@ -261,8 +261,8 @@ struct biogpt_hip_ctx {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipGraphExec_t graph_step[2][6] = {};  // [advance][context bucket: 64,128,192,256,512,P keys]
-    hipGraphExec_t graph_eval[2][6][4] = {};   // [form][bucket][segment] single-token biogpt_hip_eval*: the decode step with the token taken
+    hipGraphExec_t graph_step[2][2][6] = {};  // [pipelined][advance][context bucket: 64,128,192,256,512,P keys]; pipelined = captured with the XCD-pipelined launch (replayed only while this context holds the device's pipeline slot)
+    hipGraphExec_t graph_eval[2][2][6][4] = {};   // [pipelined][form][bucket][segment] single-token biogpt_hip_eval*: the decode step with the token taken
                                                // from the state; form 0 = one graph, form 1 = a short first segment + the rest
     int graph_eval_segs[2] = {0, 0};
     // XCD-pipelined decode step (kernels_xpipe.hip.h): layer table, hand-off granules, {launch counter, error word}, pinned error mirror
@@ -565,8 +565,11 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
 
 // ---- XCD-pipelined decode step (kernels_xpipe.hip.h): one persistent launch for all layers ------------------------
 // Two such launches of different contexts on one device could each hold part of the compute units and wait for the rest
-// (their workgroups only leave when their pipeline has run), so one context per device owns the path at a time; the
-// others keep the five-launch layer.
+// (their workgroups only leave when their pipeline has run), so one context per device holds the path at a time: the slot is
+// taken when a pipelined launch (or a graph holding one) is about to be enqueued and handed back whenever the holder's stream
+// is known to be idle (every synchronising API call ends in xpipe_check).  A context that finds the slot taken runs that call on
+// the five-launch layer.  The slot table is the ONE piece of process-global state of this library; it serialises contexts of
+// this process only -- two PROCESSES driving pipelined contexts on one device are not coordinated.
 std::mutex g_xp_mu;
 biogpt_hip_ctx *g_xp_owner[64] = {};
 
@@ -686,24 +689,35 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
     c->xp_state = 1;
 }
 
-// may this step (context bucket t_max) go through the pipeline ?  Takes the device's pipeline slot if it is free.
+// may a step of context bucket t_max go through the pipeline at all (model, device, options, bucket) ?
+bool xpipe_bucket_ok(const biogpt_hip_ctx *c, int t_max) {
+    return c->opt.xpipe && c->xp_state == 1 && t_max <= 256 && c->device >= 0 && c->device < 64;
+}
+// ... and does this context hold the device's pipeline slot (taken here if it is free) ?
 bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
-    if (!c->opt.xpipe || c->xp_state != 1 || t_max > 256 || c->device < 0 || c->device >= 64) return false;
+    if (!xpipe_bucket_ok(c, t_max)) return false;
     std::lock_guard<std::mutex> lk(g_xp_mu);
     if (g_xp_owner[c->device] == nullptr) g_xp_owner[c->device] = c;
     return g_xp_owner[c->device] == c;
+}
+// the context's stream is idle (the caller just synchronised it): nothing pipelined is in flight, another context may have the slot
+void xpipe_handback(biogpt_hip_ctx *c) {
+    if (c->device < 0 || c->device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_xp_mu);
+    if (g_xp_owner[c->device] == c) g_xp_owner[c->device] = nullptr;
 }
 
 // after a synchronisation: did a hand-off of the pipeline time out (or a workgroup land on an unexpected XCD) ?  Then the
 // outputs of that call are garbage: report it, drop the captured graphs and never use the path again in this context.
 bool xpipe_check(biogpt_hip_ctx *c) {
+    xpipe_handback(c);
     if (!c->xp_err_host || *c->xp_err_host == 0u) return true;
     const uint32_t code = *c->xp_err_host;
     *c->xp_err_host = 0u;
     c->xp_state = -1;
     c->xp_tripped = true;
-    for (auto &row : c->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    for (auto &f : c->graph_eval) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &pl : c->graph_step) for (auto &row : pl) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &pl : c->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     BG_FAIL(false, "the XCD-pipelined decode step failed (code %u: %s); this context now uses the five-launch layer", code,
             code == 2u ? "its workgroups were not dealt 32 per XCD -- another stream's kernels were dispatched in between" : code == 5u ? "hand-off tags used up" : "a hand-off timed out");
 }
@@ -764,6 +778,7 @@ hipError_t launch_decode_layer(biogpt_hip_ctx *c, const bgk::DecQkvParams &a, co
         sa.oq_q = at.oq_q; sa.oq_d = at.oq_d; sa.oq_s = at.oq_s; sa.q81 = at.q81;
         sa.sp_scores = c->sp_scores; sa.sp_max = c->sp_max; sa.sp_pv = c->sp_pv;
         sa.n_split = (sa.t_cap + bgk::SPLIT_KEYS - 1) / bgk::SPLIT_KEYS;
+        if (sa.n_split > bgk::SPLIT_MAX) BG_FAIL(hipErrorInvalidValue, "internal: %d key ranges exceed the %d the split attention kernels hold", sa.n_split, bgk::SPLIT_MAX);
         hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(16, sa.n_split), dim3(256), 0, st, sa);
         hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(16, sa.n_split), dim3(256), 0, st, sa);
         hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(16), dim3(64), 0, st, sa);
@@ -803,8 +818,10 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 
 // l0 / l1 / only: biogpt_hip_bench_matvec launches one kernel of one layer; the decode step is all layers + lm_head
 // host_row (optional): pinned host buffer that also receives the logits row; *host_row_done tells whether the launch wrote it itself
+// pl: -1 = go through the XCD pipeline if this context can take the device's slot now; 0 / 1 = the caller decided (graph capture: the
+//     graph is replayed only in the matching state)
 bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1, float *host_row = nullptr,
-                          bool *host_row_done = nullptr) {
+                          bool *host_row_done = nullptr, int pl = -1) {
     t_ctx = c;
     (void)hipGetLastError();
     const auto &hp = c->hp;
@@ -816,7 +833,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     unsigned long long *const ts = (c->opt.dbg & 96) ? c->tstamp : nullptr;
     unsigned long long *const wall = (c->opt.dbg & 64) ? c->tstamp + 128 : nullptr;
     if (l1 < 0) l1 = hp.n_layer;
-    const bool pipelined = only < 0 && l0 == 0 && l1 == hp.n_layer && tok_src != 0 && xpipe_usable(c, t_max);
+    const bool pipelined = only < 0 && l0 == 0 && l1 == hp.n_layer && tok_src != 0 && (pl < 0 ? xpipe_usable(c, t_max) : (pl == 1 && xpipe_bucket_ok(c, t_max)));
     bool lm_in_kernel = false;
     if (n_tok > 1 && !pipelined) BG_FAIL(false, "internal: multi-token launches exist on the XCD pipeline only");
     if (only == -2 && !pipelined) BG_FAIL(false, "the XCD-pipelined decode step is not available for this context");
@@ -1016,6 +1033,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                     // long context, one query: spread the head's keys over the chip (three dependent launches)
                     a.sp_scores = c->sp_scores; a.sp_max = c->sp_max; a.sp_pv = c->sp_pv;
                     a.n_split = (a.t_cap + bgk::SPLIT_KEYS - 1) / bgk::SPLIT_KEYS;
+                    if (a.n_split > bgk::SPLIT_MAX) BG_FAIL(false, "internal: %d key ranges exceed the %d the split attention kernels hold", a.n_split, bgk::SPLIT_MAX);
                     hipLaunchKernelGGL(bgk::attn_split_scores_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_pv_kernel, dim3(H, a.n_split), dim3(256), 0, st, a);
                     hipLaunchKernelGGL(bgk::attn_split_combine_kernel, dim3(H), dim3(64), 0, st, a);
@@ -1286,8 +1304,8 @@ bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
 void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (auto &row : c->graph_step) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
-    for (auto &f : c->graph_eval) for (auto &row : f) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &pl : c->graph_step) for (auto &row : pl) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &pl : c->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
     xpipe_release(c);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
@@ -1378,19 +1396,20 @@ int bucket_tmax(const biogpt_hip_ctx *c, int b) {
     return std::min(t, c->hp.n_positions);
 }
 
-bool ensure_graph(biogpt_hip_ctx *c, int advance, int bucket) {
-    if (c->graph_step[advance][bucket]) return true;
+// pl: 1 = the step as the XCD-pipelined launch (the caller holds the device's pipeline slot), 0 = the five-launch layer
+bool ensure_graph(biogpt_hip_ctx *c, int advance, int bucket, int pl) {
+    if (c->graph_step[pl][advance][bucket]) return true;
     hipGraph_t g = nullptr;
     HIP_TRY(false, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     // fused step (contexts up to 256 keys): the sampler of the previous token is the first kernel's prologue and the
     // lm_head kernel advances the position; otherwise embed ... lm_head + the arg-max kernel
     const int tmax = bucket_tmax(c, bucket);
-    bool ok = fused_decode_ok(c, tmax) ? enqueue_decode_fused(c, tmax, 2, advance)
+    bool ok = fused_decode_ok(c, tmax) ? enqueue_decode_fused(c, tmax, 2, advance, 0, -1, -1, 1, nullptr, nullptr, pl)
                                        : (enqueue_forward(c, 1, false, tmax) && enqueue_argmax(c, advance));
     hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
     HIP_TRY(false, e);
-    HIP_TRY(false, hipGraphInstantiate(&c->graph_step[advance][bucket], g, nullptr, nullptr, 0));
+    HIP_TRY(false, hipGraphInstantiate(&c->graph_step[pl][advance][bucket], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
     return true;
 }
@@ -1456,8 +1475,8 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
     ctx->opt.load();
     // captured graphs bake launch shapes chosen from the options
-    for (auto &row : ctx->graph_step) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    for (auto &f : ctx->graph_eval) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &pl : ctx->graph_step) for (auto &row : pl) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto &pl : ctx->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     ctx->graph_batch_n = 0;
     return 0;
@@ -1499,14 +1518,20 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     HIP_TRY(-2, hipSetDevice(ctx->device));
     // one token at a position of the five-launch decode step: replay its captured graph -- its first node pulls the
     // token and the position from a pinned mailbox slot -- instead of a copy command and 121 launches one by one
-    if (n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, n_past + 1)) {
+    if (n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(n_past + 1)))) {   // the captured step runs at the BUCKET's context bound
+        if (ctx->mbox_host && ctx->mbox_sent - ctx->mbox_synced >= 64) {   // never overwrite a slot a queued replay has not read yet
+            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+            ctx->mbox_synced = ctx->mbox_sent;
+            if (!xpipe_check(ctx)) return -2;
+        }
         const int b = graph_bucket(n_past + 1);
+        const int pl = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;   // holds the slot until the stream is next synchronised (xpipe_check)
         if (!ctx->mbox_host) {
             HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->mbox_host), 64 * 8 * 4, hipHostMallocDefault));
             HIP_TRY(-2, hipMalloc(&ctx->mbox_ctr, 16));
             HIP_TRY(-2, hipMemset(ctx->mbox_ctr, 0, 16));
         }
-        if (!ctx->graph_eval[form][b][0]) {
+        if (!ctx->graph_eval[pl][form][b][0]) {
             const int L = ctx->hp.n_layer;
             const int nseg = 1;
             const int bounds[3] = {0, L, L};
@@ -1518,26 +1543,21 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
                 HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
                 if (sgi == 0) hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
                 bool row_done = false;
-                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1], -1, 1, form == 1 ? ctx->logits_host : nullptr, &row_done);
+                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1], -1, 1, form == 1 ? ctx->logits_host : nullptr, &row_done, pl);
                 if (ok && form == 1 && sgi == nseg - 1 && !row_done)
                     hipLaunchKernelGGL(bgk::logits_to_host_kernel, dim3((unsigned)((V + 1023) / 1024)), dim3(256), 0, ctx->stream, ctx->logits, ctx->logits_host, (int)V);
                 const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
                 if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
                 HIP_TRY(-2, e);
-                HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[form][b][sgi], g, nullptr, nullptr, 0));
+                HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[pl][form][b][sgi], g, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(g);
             }
             ctx->graph_eval_segs[form] = nseg;
         }
-        if (ctx->mbox_sent - ctx->mbox_synced >= 64) {   // never overwrite a slot a queued replay has not read yet
-            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-            ctx->mbox_synced = ctx->mbox_sent;
-    if (!xpipe_check(ctx)) return -2;
-        }
         int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
         slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
         ctx->mbox_sent++;
-        for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[form][b][sgi], ctx->stream));
+        for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[pl][form][b][sgi], ctx->stream));
         return 0;
     }
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
@@ -1639,7 +1659,7 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
     const int rc = eval_device_impl(ctx, tokens, n, n_past, 1);
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->hp.n_vocab * 4;
-    const bool in_graph = n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, n_past + 1);   // the replayed graph already wrote the pinned row
+    const bool in_graph = n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(n_past + 1)));   // the replayed graph already wrote the pinned row
     if (!in_graph) {   // device -> pinned staging -> caller's (pageable) buffer: one DMA instead of the runtime's chunked staging
         if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), bytes, hipHostMallocDefault));
         HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1721,9 +1741,11 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     const bool use_graph = ctx->opt.no_graph == 0;
+    // the device's pipeline slot, if it is free, is this call's until its final synchronisation
+    auto pl_of = [&](int b) { return xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0; };
     if (use_graph)  // instantiate every bucket this run will touch before the clock starts
         for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++)
-            if (!ensure_graph(ctx, 1, b)) return -2;
+            if (!ensure_graph(ctx, 1, b, pl_of(b))) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -1751,7 +1773,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
             if (!enqueue_decode_fused(ctx, bucket_tmax(ctx, graph_bucket(T)), 2, 1, 0, -1, -1, multi)) return -2;
             k += multi - 1;
         } else if (use_graph) {
-            HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[1][graph_bucket(T)], ctx->stream));
+            HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl_of(graph_bucket(T))][1][graph_bucket(T)], ctx->stream));
         } else {
             if (!enqueue_forward(ctx, 1, false, T) || !enqueue_argmax(ctx, 1)) return -2;
         }
@@ -2177,19 +2199,20 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
         HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
         HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
     }
-    if (!ensure_graph(ctx, 0, b)) return -2;
+    const int pl = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;
+    if (!ensure_graph(ctx, 0, b, pl)) return -2;
     const int32_t tok0 = 2;
     if (!upload_state(ctx, &tok0, 1, n_past)) return -2;
-    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0][b], ctx->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl][0][b], ctx->stream));
     HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[0][b], ctx->stream));
+    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl][0][b], ctx->stream));
     HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
     HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
     if (!xpipe_check(ctx)) return -2;
-    if ((ctx->opt.dbg & 128) && ctx->tstamp && xpipe_usable(ctx, bucket_tmax(ctx, b))) {
+    if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1) {
         // XCD pipeline (build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS): wall clock (100 MHz) of workgroup 0 of each layer's XCD, last replay
         const int nl = ctx->hp.n_layer;
         std::vector<unsigned long long> w((size_t)nl * 16);

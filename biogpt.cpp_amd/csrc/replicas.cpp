@@ -106,13 +106,25 @@ biogpt_hip_replicas *biogpt_hip_replicas_load(const char *fname, const int *devi
     Rccl rccl;
     if (!rccl.open()) BG_FAIL(nullptr, "librccl.so not found or incomplete (%s): multi-GPU replicas need RCCL", dlerror() ? dlerror() : "missing symbols");
     r->arenas.assign((size_t)n_devices - 1, nullptr);
-    std::vector<hipStream_t> streams((size_t)n_devices, nullptr);
+    // streams and communicators live only for the broadcast: released on EVERY way out of this function (the arenas belong to r)
+    struct Transient {
+        const Rccl &rccl; const std::vector<int> &dev;
+        std::vector<hipStream_t> streams; std::vector<nccl_comm_t> comms;
+        ~Transient() {
+            for (size_t i = 0; i < dev.size(); i++) {
+                (void)hipSetDevice(dev[i]);
+                if (comms[i]) (void)rccl.comm_destroy(comms[i]);
+                if (streams[i]) (void)hipStreamDestroy(streams[i]);
+            }
+        }
+    } tr{rccl, r->devices, std::vector<hipStream_t>((size_t)n_devices, nullptr), std::vector<nccl_comm_t>((size_t)n_devices, nullptr)};
+    std::vector<hipStream_t> &streams = tr.streams;
+    std::vector<nccl_comm_t> &comms = tr.comms;
     for (int i = 0; i < n_devices; i++) {
         HIP_TRY_R(nullptr, hipSetDevice(devices[i]));
         HIP_TRY_R(nullptr, hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking));
         if (i > 0) HIP_TRY_R(nullptr, hipMalloc(&r->arenas[(size_t)i - 1], r->arena_bytes));
     }
-    std::vector<nccl_comm_t> comms((size_t)n_devices, nullptr);
     int rc = rccl.comm_init_all(comms.data(), n_devices, devices);
     if (rc != 0) BG_FAIL(nullptr, "ncclCommInitAll failed: %s", rccl.err(rc));
     const auto t0 = std::chrono::steady_clock::now();
@@ -123,16 +135,17 @@ biogpt_hip_replicas *biogpt_hip_replicas_load(const char *fname, const int *devi
     }
     const int rc_end = rccl.group_end();
     if (rc == 0) rc = rc_end;
+    hipError_t sync_err = hipSuccess;
+    int sync_dev = -1;
     for (int i = 0; i < n_devices; i++) {
-        (void)hipSetDevice(devices[i]);
-        (void)hipStreamSynchronize(streams[(size_t)i]);
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(streams[(size_t)i]);
+        if (e != hipSuccess && sync_err == hipSuccess) { sync_err = e; sync_dev = devices[i]; }
     }
     r->broadcast_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int i = 0; i < n_devices; i++) {
-        (void)hipSetDevice(devices[i]);
-        if (comms[(size_t)i]) (void)rccl.comm_destroy(comms[(size_t)i]);
-        (void)hipStreamDestroy(streams[(size_t)i]);
-    }
+    if (rc != 0 && sync_err != hipSuccess)
+        BG_FAIL(nullptr, "ncclBroadcast of the weight arena failed: %s; and the stream of device %d: %s", rccl.err(rc), sync_dev, hipGetErrorString(sync_err));
+    if (sync_err != hipSuccess) BG_FAIL(nullptr, "the broadcast stream of device %d failed: %s", sync_dev, hipGetErrorString(sync_err));
     if (rc != 0) BG_FAIL(nullptr, "ncclBroadcast of the weight arena failed: %s", rccl.err(rc));
     if (verbosity > 0)
         fprintf(stderr, "biogpt_hip_replicas_load: %.1f MiB arena broadcast to %d device(s) in %.2f ms\n", r->arena_bytes / 1048576.0, n_devices,

@@ -17,6 +17,10 @@ def shard_units(n_units, rank, world):
 
 def init_process_group(backend):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    # RCCL shares device buffers between the ranks of one node through IPC handles; this host driver only supports the
+    # dmabuf form (without the switch: `hipIpcGetMemHandle: invalid argument` at the first collective).  The HSA runtime reads
+    # it when it initialises, i.e. at the process's first HIP call -- bench.py therefore also sets it before importing torch.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     if dist.is_initialized():
         return dist

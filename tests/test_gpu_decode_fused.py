@@ -104,22 +104,27 @@ def test_generation_across_the_fused_range(pkg, oracle, files, monkeypatch, name
 
 
 @pytest.fixture(scope="module")
-def base24(pkg, tmp_path_factory):
-    """The full BioGPT-base configuration (24 layers, biogpt.h:25-35), synthetic seeded weights, Q4_0."""
+def base24_f32(pkg, tmp_path_factory):
+    """The full BioGPT-base configuration (24 layers, biogpt.h:25-35), synthetic seeded weights (the bench's own seed)."""
     d = tmp_path_factory.mktemp("base24")
-    f32, q40 = str(d / "f32.bin"), str(d / "q4_0.bin")
+    f32 = str(d / "f32.bin")
     pkg.write_synthetic(f32, seed=0x42494F47, **dict(KW, n_layer=24))
-    pkg.quantize_file(f32, q40, "q4_0")
-    os.remove(f32)
-    return q40
+    yield f32
+    if os.path.exists(f32):
+        os.remove(f32)
 
 
-def test_biogpt_base_24_layers(pkg, oracle, base24):
-    """configs[1] at full depth: 32 teacher-forced single-token evals (logits vs the oracle) and the bench workload itself,
-    the 200-token greedy continuation of a 4-token prompt (README.md:29 ids), ids == oracle."""
-    g = pkg.BiogptModel.load(base24)
-    o = oracle.OracleModel(base24, n_threads=16)
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_biogpt_base_24_layers(pkg, oracle, base24_f32, tmp_path, name):
+    """configs[1] (Q4_0) and configs[3] (Q5_1, Q8_0) at full depth: 32 teacher-forced single-token evals (logits vs the oracle) and the
+    bench workload itself, the 200-token greedy continuation of a 4-token prompt (README.md:29 ids), ids == oracle -- on the XCD pipeline
+    (48 half-layer units: every XCD takes six), which must still hold the path at the end."""
+    path = str(tmp_path / (name + ".bin"))
+    pkg.quantize_file(base24_f32, path, name)
+    g = pkg.BiogptModel.load(path)
+    o = oracle.OracleModel(path, n_threads=16)
     assert g.hparams.n_layer == 24
+    had_pipeline = g.xpipe_state() == 1
     prompt = [2, 7548, 1171, 32924]
     lg, lo = g.eval(prompt, 0), o.eval(prompt, 0)
     worst, exact, n_past = float(np.abs(lg - lo).max()), 0, 4
@@ -130,13 +135,16 @@ def test_biogpt_base_24_layers(pkg, oracle, base24):
         worst = max(worst, float(np.abs(lg - lo).max()))
         exact += int((lg == lo).all())
         n_past += 1
-    print("24 layers: worst |diff| %.2e, %d/32 steps bit-identical" % (worst, exact))
+    print("24 layers %s: worst |diff| %.2e, %d/32 steps bit-identical" % (name, worst, exact))
     assert worst <= ATOL
     ids, secs = g.generate_greedy(prompt, 200, n_batch=8)
-    ref, _ = oracle.OracleModel(base24, n_threads=16).generate_greedy(prompt, 200, n_batch=8)
+    ref, _ = oracle.OracleModel(path, n_threads=16).generate_greedy(prompt, 200, n_batch=8)
     assert list(ids) == list(ref)
-    print("24 layers: 200 greedy ids identical, %.0f tok/s" % (200 / secs))
+    print("24 layers %s: 200 greedy ids identical, %.0f tok/s" % (name, 200 / secs))
+    if had_pipeline:
+        assert g.xpipe_state() == 1, "the pipeline was abandoned during the run"
     g.close()
+    os.remove(path)
 
 
 def _last_json_line(text):
@@ -152,7 +160,7 @@ def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     load at examples/main/main.cpp:38.  The JSON line must be the last stdout line and the ids of the last continuation
     must be the oracle's."""
     dump = str(tmp_path / "ids.json")
-    env = dict(os.environ, BIOGPT_BENCH_DUMP_IDS=dump, BIOGPT_BENCH_DIR=str(tmp_path / "work"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BIOGPT_BENCH_DUMP_IDS=dump, BIOGPT_BENCH_DIR=str(tmp_path / "work"))   # bench.py sets HSA_ENABLE_IPC_MODE_LEGACY=0 itself (replicas.py says why)
     args = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--n-layer", "4", "--n-predict", "40"]
     if launcher == "env":
         env.update(BIOGPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
@@ -351,9 +359,10 @@ def test_xpipe_disturbed_launch_is_repeated_on_the_five_launch_layer(pkg, files,
 
 
 def test_xpipe_survives_a_second_stream_generating_at_the_same_time(pkg, files):
-    """Two contexts of one device generating concurrently from two host threads: one holds the pipeline, the other runs the
-    five-launch layer on its own stream, so workgroups of both are dispatched interleaved.  Whatever happens to the pipelined
-    launches (undisturbed, or drained and repeated on the five-launch layer) every call must return the undisturbed ids."""
+    """Two contexts of one device generating concurrently from two host threads: whichever takes the device's pipeline slot first runs
+    its call pipelined, the other runs the five-launch layer on its own stream for that call, so workgroups of both are dispatched
+    interleaved.  Whatever happens to the pipelined launches (undisturbed, or drained and repeated on the five-launch layer) every call
+    must return the undisturbed ids."""
     import threading
     a = pkg.BiogptModel.load(files["q4_0"])
     if a.xpipe_state() != 1:
@@ -362,7 +371,7 @@ def test_xpipe_survives_a_second_stream_generating_at_the_same_time(pkg, files):
     prompt_a, prompt_b = [2, 100, 200, 300], [2, 7, 8, 9, 10]
     want_a, _ = a.generate_greedy(prompt_a, n_predict=120, n_batch=8)
     want_b, _ = b.generate_greedy(prompt_b, n_predict=120, n_batch=8)
-    assert a.xpipe_state() == 1 and b.xpipe_state() == 0          # b found the device's pipeline slot taken
+    assert a.xpipe_state() == 1 and b.xpipe_state() == 1          # the slot is handed back whenever its holder's stream has been synchronised
     errs = []
 
     def run(g, prompt, want, reps):
@@ -397,3 +406,99 @@ def test_xpipe_many_launches_stay_clean(pkg, files):
             assert int(lg.argmax()) == int(want[1])
     assert g.xpipe_state() == 1
     g.close()
+
+
+# ---- pipeline wrap-around: 10 layers = 20 half-layer units, every XCD takes 2-3 units (the "load the next unit while waiting" and
+#      lm_head-ahead paths), all five block formats; a vocabulary that is not a multiple of 64 (partial last lm_head block) ----------
+
+KW10 = dict(KW, n_layer=10, n_vocab=20011, n_merges=1000)
+
+
+@pytest.fixture(scope="module")
+def files10(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("fused10")
+    f32 = str(d / "f32.bin")
+    pkg.write_synthetic(f32, seed=10, **KW10)
+    out = {}
+    for name in QUANT:
+        out[name] = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, out[name], name)
+    os.remove(f32)
+    return out
+
+
+@pytest.mark.parametrize("name", XPIPE_TYPES)
+def test_xpipe_wraparound_step_and_generation(pkg, oracle, files10, monkeypatch, name):
+    """10 layers: single-token steps with the pipeline on and off (bit-identical, oracle within the contract) around the buckets, then a
+    greedy generation through every pipeline bucket in multi-token launches == pipeline off == oracle (first 48 ids); the pipeline must
+    still be on at the end of every phase."""
+    g = pkg.BiogptModel.load(files10[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device (xpipe_state %d)" % g.xpipe_state())
+    o = oracle.OracleModel(files10[name], n_threads=16)
+    rng = np.random.default_rng(101)
+    toks = [2] + [int(v) for v in rng.integers(4, KW10["n_vocab"], 256)]
+    checked = [0, 1, 63, 64, 100, 127, 128, 191, 192, 255]
+    n_past, worst = 0, 0.0
+    while n_past <= checked[-1]:
+        if n_past in checked:
+            _with_xpipe(g, monkeypatch, True)
+            lp = g.eval([toks[n_past]], n_past)
+            assert g.xpipe_state() == 1, "pipeline abandoned at n_past %d" % n_past
+            _with_xpipe(g, monkeypatch, False)
+            lf = g.eval([toks[n_past]], n_past)
+            lo = o.eval([toks[n_past]], n_past)
+            assert (lp == lf).all(), "%s: pipeline != five-launch layer at n_past %d (max diff %g)" % (name, n_past, np.abs(lp - lf).max())
+            worst = max(worst, float(np.abs(lp - lo).max()))
+            assert int(lp.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            g.eval_device(chunk, n_past); g.synchronize(); o.eval(chunk, n_past)
+            n_past += m
+    assert worst <= ATOL
+    _with_xpipe(g, monkeypatch, True)
+    prompt = toks[:9]
+    ids_p, _ = g.generate_greedy(prompt, n_predict=262, n_batch=8)          # contexts 10 .. 271 keys
+    assert g.xpipe_state() == 1
+    _with_xpipe(g, monkeypatch, False)
+    ids_f, _ = g.generate_greedy(prompt, n_predict=262, n_batch=8)
+    assert list(ids_p) == list(ids_f)
+    ids_o, _ = oracle.OracleModel(files10[name], n_threads=16).generate_greedy(prompt, n_predict=48, n_batch=8)
+    assert list(ids_p[:48]) == list(ids_o)
+    g.close()
+
+
+def test_pipeline_slot_is_handed_back_and_replicas_reload(pkg, oracle, files):
+    """One pipeline slot per device: a second context of the same device gets it as soon as the first one's call has synchronised (both
+    generate pipelined, alternately, same ids as alone); biogpt_hip_replicas_load -> free -> load again gives the slot, the RCCL
+    handle and the arenas back (ids == oracle both times)."""
+    a = pkg.BiogptModel.load(files["q4_0"])
+    if a.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    b = pkg.BiogptModel.load(files["q5_0"])
+    pa, pb = [2, 100, 200, 300], [2, 7, 8, 9, 10]
+    want_a, _ = a.generate_greedy(pa, n_predict=40, n_batch=8)
+    want_b, _ = b.generate_greedy(pb, n_predict=40, n_batch=8)
+    for _ in range(3):
+        got_a, sa = a.generate_greedy(pa, n_predict=40, n_batch=8)
+        assert a.xpipe_state() == 1 and b.xpipe_state() == 1
+        got_b, sb = b.generate_greedy(pb, n_predict=40, n_batch=8)
+        assert list(got_a) == list(want_a) and list(got_b) == list(want_b)
+    # an un-synchronised pipelined eval of `a` keeps the slot: `b` runs that call on the five-launch layer, same logits
+    lb_ref = b.eval([11], 5)
+    a.eval_device([12], 4)
+    assert b.xpipe_state() in (0, 1)
+    assert (b.eval([11], 5) == lb_ref).all()
+    a.synchronize()
+    assert a.xpipe_state() == 1 and b.xpipe_state() == 1
+    a.close(); b.close()
+    for _ in range(2):
+        r = pkg.Replicas(files["q4_0"], [0])
+        ids, _ = r.generate_greedy([pa], 12, n_batch=8)
+        ref, _ = oracle.OracleModel(files["q4_0"], n_threads=16).generate_greedy(pa, 12, n_batch=8)
+        assert list(ids[0]) == list(ref)
+        r.close()
