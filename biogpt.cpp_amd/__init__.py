@@ -45,10 +45,10 @@ class BiogptError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile libbiogpt_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "biogpt_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + [os.path.join(_HERE, "..", "include", "biogpt_hip.h")]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
-    cmd = ["make", "-C", CSRC, "-B", "all"]
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else []) + ["all"]   # objects under csrc/obj/ (git-ignored)
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL, stderr=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 

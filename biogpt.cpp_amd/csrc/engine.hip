@@ -30,7 +30,7 @@
 #include "kernels_fast.hip.h"
 #include "kernels_mfma.hip.h"
 #include "kernels_decode.hip.h"
-#include "kernels_xpipe.hip.h"
+#include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
 #include "kernels_quant.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
@@ -168,7 +168,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -195,6 +195,7 @@ struct EngineOptions {
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
         xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
+        xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
@@ -268,6 +269,7 @@ struct biogpt_hip_ctx {
     // XCD-pipelined decode step (kernels_xpipe.hip.h): layer table, hand-off granules, {launch counter, error word}, pinned error mirror
     bgk::XpLayer *xp_layers = nullptr;
     bgk::xp_u64 *xp_gran = nullptr;
+    bgk::xp_u64 *xp_gran_l = nullptr;      // long-context variant (kernels_xlong.hip.h): scores and partial outputs of the key-range helpers
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
@@ -580,10 +582,11 @@ void xpipe_release(biogpt_hip_ctx *c) {
     }
     if (c->xp_layers) (void)hipFree(c->xp_layers);
     if (c->xp_gran) (void)hipFree(c->xp_gran);
+    if (c->xp_gran_l) (void)hipFree(c->xp_gran_l);
     if (c->xp_ctl) (void)hipFree(c->xp_ctl);
     if (c->xp_samp) (void)hipFree(c->xp_samp);
     if (c->xp_err_host) (void)hipHostFree(c->xp_err_host);
-    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
+    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_gran_l = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
 }
 
 bool xpipe_model_ok(const biogpt_hip_ctx *c) {
@@ -593,34 +596,21 @@ bool xpipe_model_ok(const biogpt_hip_ctx *c) {
            hp.n_positions >= 64 && hp.n_layer >= 1;
 }
 
-// Q8_0 (9 registers per weight unit) runs with split layers: attention half and MLP half of a layer on consecutive XCDs
-template <int WT> constexpr bool xpipe_split() { return true; }
-// pipeline units of the model: layers, or half layers; the XCD of the last one (and XCD 0) computes no lm_head rows
+// the pipelined kernels live in their own translation unit (xpipe_tu.hip)
+extern "C" int bg_xpipe_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
+extern "C" int bg_xpipe_set_lds(int wt, size_t smem_bytes);
+
+// pipeline units of the model: half layers (attention half on an even XCD, MLP half on the next, odd one); the XCD of the last one (and XCD 0)
+// computes no lm_head rows
 int xpipe_last_xcd(const biogpt_hip_ctx *c) {
     const int units = 2 * c->hp.n_layer;
     return (units - 1) & 7;
-}
-template <int WT>
-bool xpipe_set_lds_t(size_t sm) {
-    constexpr bool SP = xpipe_split<WT>();
-    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, SP>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, SP>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, SP>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, SP>)};
-    for (const void *fn : fns)
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return false;
-    return true;
 }
 // > 64 KB of dynamic LDS needs the opt-in attribute (per device); set outside any stream capture
 bool xpipe_set_lds(biogpt_hip_ctx *c) {
     const size_t sm = bgk::xpipe_smem_bytes(c->xp_gelu_p + c->xp_gelu_n);
     if (sm <= 64 * 1024) return true;
-    switch (ftype_to_type(c->hp.ftype)) {
-        case T_Q4_0: return xpipe_set_lds_t<bgk::W_Q4_0>(sm);
-        case T_Q4_1: return xpipe_set_lds_t<bgk::W_Q4_1>(sm);
-        case T_Q5_0: return xpipe_set_lds_t<bgk::W_Q5_0>(sm);
-        case T_Q5_1: return xpipe_set_lds_t<bgk::W_Q5_1>(sm);
-        case T_Q8_0: return xpipe_set_lds_t<bgk::W_Q8_0>(sm);
-        default: return false;
-    }
+    return bg_xpipe_set_lds(ftype_to_type(c->hp.ftype), sm) == (int)hipSuccess;     // T_* values are the kernels' WType values
 }
 
 // once per context, outside any stream capture: is this an 8-XCD x 32-CU device that places workgroup b on XCD b % 8 ?
@@ -664,6 +654,14 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         xpipe_release(c);
         return;
     }
+    if (hp.n_positions > 256 && c->opt.xpipe_long) {   // contexts beyond 256 keys: the key-range helpers' granules (393 KB per layer); without them those contexts keep the five-launch layer
+        const size_t lbytes = (size_t)hp.n_layer * bgk::XL_G_LAYER * 8;
+        if (hipMalloc(&c->xp_gran_l, lbytes) != hipSuccess || hipMemset(c->xp_gran_l, 0, lbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->xp_gran_l) (void)hipFree(c->xp_gran_l);
+            c->xp_gran_l = nullptr;
+        }
+    }
     if (c->opt.xpipe_fault) {
         const uint32_t one = 1u;
         (void)hipMemcpy(c->xp_ctl + 8, &one, 4, hipMemcpyHostToDevice);
@@ -691,7 +689,7 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
 
 // may a step of context bucket t_max go through the pipeline at all (model, device, options, bucket) ?
 bool xpipe_bucket_ok(const biogpt_hip_ctx *c, int t_max) {
-    return c->opt.xpipe && c->xp_state == 1 && t_max <= 256 && c->device >= 0 && c->device < 64;
+    return c->opt.xpipe && c->xp_state == 1 && (t_max <= 256 || (t_max <= 1024 && c->xp_gran_l != nullptr && c->opt.xpipe_long)) && c->device >= 0 && c->device < 64;
 }
 // ... and does this context hold the device's pipeline slot (taken here if it is free) ?
 bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
@@ -736,18 +734,6 @@ int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
     const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));
     if (!(m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024)) return 0;
     return tmax - T + 1;
-}
-
-template <int WT>
-hipError_t launch_xpipe(biogpt_hip_ctx *c, const bgk::XpParams &xp) {
-    const size_t sm = bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n);
-    // 8 waves per workgroup: 24 weight units per lane (120 VGPRs) + the head's old keys / values fit the 256-register budget
-    constexpr bool SP = xpipe_split<WT>();
-    if (xp.t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, SP>), dim3(256), dim3(512), sm, c->stream, xp);
-    else if (xp.t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, SP>), dim3(256), dim3(512), sm, c->stream, xp);
-    else if (xp.t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, SP>), dim3(256), dim3(512), sm, c->stream, xp);   // 24 instead of 32 value registers
-    else hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, SP>), dim3(256), dim3(512), sm, c->stream, xp);
-    return hipGetLastError();
 }
 
 // ---- fused single-token decode step (kernels_decode.hip.h): 3 launches per layer + lm_head ---------------------
@@ -839,7 +825,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     if (only == -2 && !pipelined) BG_FAIL(false, "the XCD-pipelined decode step is not available for this context");
     if (pipelined) {
         bgk::XpParams xp{};
-        xp.layers = c->xp_layers; xp.n_layer = hp.n_layer; xp.gran = c->xp_gran; xp.ctl = c->xp_ctl; xp.err_host = c->xp_err_host;
+        xp.layers = c->xp_layers; xp.n_layer = hp.n_layer; xp.gran = c->xp_gran; xp.gran_l = c->xp_gran_l; xp.ctl = c->xp_ctl; xp.err_host = c->xp_err_host;
         xp.st = c->state;
         xp.tok_emb = dev_matrix(c, c->plan.embed_tokens); xp.pos_emb = dev_matrix(c, c->plan.embed_pos);
         xp.embed_scale = sqrtf((float)D);
@@ -866,15 +852,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
         }
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
-        hipError_t e = hipErrorInvalidValue;
-        switch (wt) {
-            case T_Q4_0: e = launch_xpipe<bgk::W_Q4_0>(c, xp); break;
-            case T_Q4_1: e = launch_xpipe<bgk::W_Q4_1>(c, xp); break;
-            case T_Q5_0: e = launch_xpipe<bgk::W_Q5_0>(c, xp); break;
-            case T_Q5_1: e = launch_xpipe<bgk::W_Q5_1>(c, xp); break;
-            case T_Q8_0: e = launch_xpipe<bgk::W_Q8_0>(c, xp); break;
-            default: break;
-        }
+        const hipError_t e = (hipError_t)bg_xpipe_launch(wt, xp.t_cap, bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n), c->stream, &xp, sizeof(xp));
         HIP_TRY(false, e);
     }
     for (int l = l0; l < l1 && !pipelined; l++) {

@@ -1,0 +1,789 @@
+// The XCD-pipelined decode step (kernels_xpipe.hip.h) for contexts BEYOND 256 keys: 257 .. 512 keys (KR = 32) and 513 .. 1024 keys
+// (KR = 64).  biogpt.cpp:664-811 for all layers + the output projection; the attention of biogpt.cpp:729-764 is spread over the chip.
+//
+// Why another shape: up to 256 keys a head's workgroup keeps the head's old K / V rows in registers (<= 64 KB).  At 1024 keys a
+// layer's K / V are 8 MB -- 512 KB per head -- which no single compute unit, and not even one XCD's L2 (4 MB), can hold; the
+// five-launch layer with its three key-split attention launches (attn_split_*_kernel) costs 25 us per layer there (608 us per token).
+// Here the weights stay exactly where kernels_xpipe.hip.h puts them (unit u = half a layer on XCD u % 8, stationary in registers,
+// loaded 7 units ahead), and ONLY the attention is redistributed:
+//
+//   * head h belongs to XCD h / 2 -- for EVERY layer.  Workgroup (xcd, slot) is the "helper" of head 2 xcd + slot / 16 and key
+//     range r = slot % 16: keys [r KR, (r + 1) KR).  It holds its range's K and V rows of the NEXT layer in 8-16 registers per
+//     lane (32 KB per workgroup per layer, loaded one layer ahead): all 256 compute units stream the cache, 8 MB per layer, while
+//     they wait for their own unit's turn anyway.
+//   * the layer's own (even) XCD computes LayerNorm + the q / k / v rows as before and publishes them as granules (one cross-XCD hop);
+//     the helper of the range that holds position n_past appends the new K / V rows to the cache and uses them from LDS.
+//   * helper: 64 (32) scores -> granules inside ITS XCD -> all 16 helpers of the head read the head's T scores (one in-XCD hop),
+//     each computes the global maximum, every e_j = exp_table(S_j - max) and the double sum itself (identical in all 16: sums of
+//     <= 1024 fp16-valued terms in double are exact whatever the order), then p_j = fl(e_j * (float)(1 / sum)) and its partial
+//     sum_j V_jd p_j over its own keys in double (the arithmetic of attn_split_pv_kernel) -> 64 doubles as granules (in-XCD hop)
+//     -> the head's first helper adds the partials in range order (attn_split_combine_kernel's association), quantizes the 64
+//     outputs to two Q8 blocks and publishes them for the layer's XCD (one cross-XCD hop), where out_proj runs as before.
+//   * K / V rows appended during a multi-token launch are written and later re-read by the SAME workgroup (plain stores, L1-bypassing
+//     loads): no cross-XCD visibility question arises for the cache.
+//
+// Four hops (two cross-XCD, two in-XCD) instead of the <= 256-key variants' two in-XCD ones: about +2.6 us per layer, against
+// +13 us for three launches.  Everything else -- stages A, C, D, E, the lm_head on the XCDs that are done, the sampler of the next
+// token on XCD 0, tags, bounded spins, error word -- is kernels_xpipe.hip.h's, restructured so that every workgroup walks ALL
+// layers in order (helper duty for each, its own unit's stages in between).
+#pragma once
+
+#include "kernels_xpipe.hip.h"
+
+namespace bgk {
+
+// granules of one layer in the long-context buffer (XpParams::gran_l)
+constexpr int XL_G_SC = 0;                     // [16 heads][1024 keys] scores
+constexpr int XL_G_PV = 16 * 1024;             // [16 heads][16 ranges][64 lo + 64 hi] partial sum_j V_jd p_j (double)
+constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
+
+#ifdef BIOGPT_HIP_PROFILE_HOOKS
+// wall clock of workgroups 0 and 16 of the layer's own XCD ([n_layer][32] slots; workgroup 0 is also the first helper of head 2 xcd)
+#define XL_WALL(k) do { if (p.wall && tid == 0 && (slot & 15) == 0 && own_first) p.wall[L * 32 + (k)] = wall_clock64(); } while (0)
+#else
+#define XL_WALL(k) do {} while (0)
+#endif
+
+// ROLE 0: workgroups 0-15 of an even XCD (LayerNorm + the 192 q / k / v rows of head `slot`, out_proj rows); 1: workgroups 16-31 of an even
+// XCD (out_proj rows only); 2: the 32 workgroups of an odd XCD (LayerNorm, fc1, fc2).  Every role is a helper for every layer.
+template <int WT, int KR, int ROLE>
+__device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
+                                       const int n_gen0) {
+    using TI = TypeInfo<WT>;
+    static_assert(TI::quant, "block-quantized weights");
+    static_assert(KR == 32 || KR == 64, "keys per helper: 16 ranges cover 512 / 1024 keys");
+    constexpr bool FIRST = ROLE != 2, SECOND = ROLE == 2;
+    constexpr int NW = 8, NT = 512, DK = 64;
+    constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW, LMS = 128 / NW;
+    constexpr int LPK = NT / KR, NF4 = 16 / LPK, NV = KR / NW, NSC = 16 * KR / NT;      // lanes per key; float4 of a key row per lane; values per lane; scores polled per lane
+    float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
+    float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
+    uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
+    float *const s_xd = reinterpret_cast<float *>(smem + XP_S_XD);
+    uint32_t *const s_xs = reinterpret_cast<uint32_t *>(smem + XP_S_XS);
+    double *const s_red = reinterpret_cast<double *>(smem + XP_S_RED);
+    uint32_t *const s_hq = reinterpret_cast<uint32_t *>(smem + XP_S_HQ);
+    float *const s_hd = reinterpret_cast<float *>(smem + XP_S_HD);
+    uint32_t *const s_hs = reinterpret_cast<uint32_t *>(smem + XP_S_HS);
+    float *const s_part = reinterpret_cast<float *>(smem + XP_S_PART);
+    float *const s_g = reinterpret_cast<float *>(smem + XP_S_G);
+    float *const s_ln = reinterpret_cast<float *>(smem + XP_S_LN);
+    float *const s_bias = reinterpret_cast<float *>(smem + XP_S_BIAS);
+    float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
+    float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
+    float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 256);
+    double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
+    double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
+    uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+    const int n_layer = p.n_layer, n_units = 2 * n_layer, last_xcd = (n_units - 1) & 7;
+    const int P = p.P;
+    // helper duty: head and key range of this workgroup, the same for every layer and token
+    const int hx_head = 2 * xcd + (slot >> 4), hx_r = slot & 15, hx_j0 = hx_r * KR;
+    // own pipeline units: layers L with L % 4 == my_l0 (their first half on an even XCD, their second half on the next, odd one)
+    const int my_l0 = xcd >> 1;
+    const int my_last = (my_l0 < n_layer) ? my_l0 + ((n_layer - 1 - my_l0) & ~3) : -1;     // last own layer (-1: none)
+    // lm_head: XCD 0 (the next token's layer 0) and the last unit's XCD take no part
+    const int lm_xr = xcd - (xcd > 0 ? 1 : 0) - ((last_xcd != 0 && xcd > last_xcd) ? 1 : 0);
+    const int lm_rank = slot + 32 * lm_xr;
+    const bool lm_mine = p.lm != 0 && xcd != 0 && xcd != last_xcd && lm_rank * 4 < p.lm_blocks;
+
+    // this workgroup's share of the NEXT layer's old keys / values (rows of positions it has appended itself come back through its own L2)
+    float4 kr[NF4];
+    float vr[NV];
+    auto fetch_kv = [&](const int L, const int n_past) __attribute__((always_inline)) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (hx_j0 <= n_past) {          // the range is, or becomes, active with this token
+            const XpLayer &Y = p.layers[L];
+            const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
+            if (hx_j0 + kidx < P) {
+                const float4 *kbase = reinterpret_cast<const float4 *>(Y.kcache + (size_t)hx_head * P * DK) + (size_t)(hx_j0 + kidx) * (DK / 4) + ksub;
+#pragma unroll
+                for (int m = 0; m < NF4; m++) {
+                    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(kbase + LPK * m));
+                    kr[m] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                }
+            }
+            const float *vbase = Y.vcache + (size_t)hx_head * P * DK + dd;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const int j = hx_j0 + sl + NW * k;
+                if (j < P) vr[k] = __builtin_nontemporal_load(vbase + (size_t)j * DK);
+            }
+        }
+    };
+
+    // ================= helper duty for layer L (every workgroup, every layer): biogpt.cpp:729-764 for keys [hx_j0, hx_j0 + KR) of head hx_head =================
+    auto helper = [&](const int L, const uint32_t epoch, const int n_past, const bool own_first, const bool more) __attribute__((always_inline)) {
+        const int T = n_past + 1;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        if (hx_j0 < T) {
+            const XpLayer &Y = p.layers[L];
+            xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+            xp_u64 *const GL = p.gran_l + (size_t)L * XL_G_LAYER;
+            const bool has_new = n_past < hx_j0 + KR;                  // (and n_past >= hx_j0): this range holds the token's own key
+            // ---- the head's query row; the new key / value rows where they belong to this range (also appended to the cache: biogpt.cpp:721-727) ----
+            if (wave == 0 || (has_new && wave < 3)) {
+                uint32_t v[1];
+                xp_sweep<1>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p);
+                s_cur[tid] = __uint_as_float(v[0]);
+                if (wave != 0) {
+                    float *cache = (wave == 1) ? Y.kcache : Y.vcache;
+                    cache[((size_t)hx_head * P + n_past) * DK + lane] = __uint_as_float(v[0]);
+                }
+            }
+            __syncthreads();
+            XL_WALL(16);
+            // ---- scores of the own keys ----
+            const int ksub = tid & (LPK - 1), kidx = tid / LPK, j = hx_j0 + kidx;
+            {
+                if (j == n_past) {
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                }
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int m = 0; m < NF4; m++) {
+                    const float4 qm = *reinterpret_cast<const float4 *>(s_cur + 4 * (LPK * m + ksub));
+                    a0 += (double)__fmul_rn(kr[m].x, qm.x); a1 += (double)__fmul_rn(kr[m].y, qm.y);
+                    a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
+                }
+                double acc = (a0 + a1) + (a2 + a3);
+                acc += dpp_d<DPP_QUAD_XOR1>(acc);
+                acc += dpp_d<DPP_QUAD_XOR2>(acc);
+                acc += dpp_d<DPP_ROW_HALF_MIRROR>(acc);
+                if (LPK >= 16) acc += dpp_d<DPP_ROW_MIRROR>(acc);
+                if (ksub == 0 && j < T) xp_put_local(GL + XL_G_SC + hx_head * 1024 + j, epoch, __float_as_uint((float)acc));
+            }
+            XL_WALL(17);
+            // ---- all T scores of the head: global maximum, fp16-table exp, double sum (ggml_soft_max) -- identical in the head's 16 helpers ----
+            float sc[NSC];
+            {
+                uint32_t v[NSC];
+                const xp_u64 *g = GL + XL_G_SC + hx_head * 1024 + tid;
+                for (uint32_t spins = 0;; spins++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < NSC; k++) {
+                        if (tid + NT * k < T) {
+                            const xp_u64 a = __hip_atomic_load(g + NT * k, XP_RLX);
+                            v[k] = (uint32_t)a;
+                            ok &= (uint32_t)(a >> 32) == epoch;
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 6u); break; }
+                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int k = 0; k < NSC; k++) sc[k] = (tid + NT * k < T) ? __uint_as_float(v[k]) : -INFINITY;
+            }
+            XL_WALL(18);
+            float mx = sc[0];
+#pragma unroll
+            for (int k = 1; k < NSC; k++) mx = fmaxf(mx, sc[k]);
+            mx = wave_max_f32(mx);
+            if (lane == 0) s_redf[wave] = mx;
+            __syncthreads();
+            mx = s_redf[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NSC; k++) {
+                const int jj = tid + NT * k;
+                if (jj < T) {
+                    const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc[k], mx))]);
+                    sum += (double)val;
+                    if (jj >= hx_j0 && jj < hx_j0 + KR) s_S[jj - hx_j0] = val;
+                }
+            }
+            sum = wave_sum_f64(sum);
+            if (lane == 0) s_redd[wave] = sum;
+            __syncthreads();
+            sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) sum += s_redd[w];
+            const float inv = inv_sum_f32(sum);
+            XL_WALL(19);
+            // ---- partial sum_j V_jd p_j over the own keys, in double (attn_split_pv_kernel) ----
+            {
+                const int dd = tid & (DK - 1), sl = tid >> 6;
+                const float vcur = s_cur[128 + dd];
+                float pj[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) pj[k] = s_S[sl + NW * k];
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < NV; k += 2) {
+                    const int j0 = hx_j0 + sl + NW * k, j1 = j0 + NW;
+                    const double c0 = (double)__fmul_rn(j0 == n_past ? vcur : vr[k], __fmul_rn(pj[k], inv));
+                    const double c1 = (double)__fmul_rn(j1 == n_past ? vcur : vr[k + 1], __fmul_rn(pj[k + 1], inv));
+                    a0 += (j0 < T) ? c0 : 0.0;
+                    a1 += (j1 < T) ? c1 : 0.0;
+                }
+                s_pv[tid] = a0 + a1;
+            }
+            __syncthreads();
+            if (tid < DK) {
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
+                const double part = t0 + t1;
+                xp_u64 *const gp = GL + XL_G_PV + (hx_head * 16 + hx_r) * 128 + tid;
+                xp_put_local(gp, epoch, (uint32_t)__double2loint(part));
+                xp_put_local(gp + 64, epoch, (uint32_t)__double2hiint(part));
+            }
+            XL_WALL(20);
+        }
+        // this workgroup's K / V rows for its next helper duty: the next layer of this token, or layer 0 of the next token
+        if (L + 1 < n_layer) fetch_kv(L + 1, n_past);
+        else if (more) fetch_kv(0, n_past + 1);
+        if (hx_j0 < T && hx_r == 0) {
+            // ---- the head's first helper adds the partials in range order (attn_split_combine_kernel), Q8, publishes for the layer's own XCD ----
+            __syncthreads();                      // s_pv: the slice sums above have been read
+            const int nr = (T + KR - 1) / KR;     // active ranges
+            const xp_u64 *const G0 = p.gran_l + (size_t)L * XL_G_LAYER + XL_G_PV + hx_head * 16 * 128;
+            {
+                const int d = tid & (DK - 1), part = tid >> 6;          // ranges part and part + 8
+                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                const bool a0 = part < nr, a1 = part + 8 < nr;
+                const xp_u64 *g0 = G0 + part * 128 + d, *g1 = G0 + (part + 8) * 128 + d;
+                for (uint32_t spins = 0;; spins++) {
+                    bool ok = true;
+                    if (a0) {
+                        const xp_u64 x0 = __hip_atomic_load(g0, XP_RLX), x1 = __hip_atomic_load(g0 + 64, XP_RLX);
+                        v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
+                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
+                    }
+                    if (a1) {
+                        const xp_u64 x0 = __hip_atomic_load(g1, XP_RLX), x1 = __hip_atomic_load(g1 + 64, XP_RLX);
+                        v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
+                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
+                    }
+                    if (__all(ok)) break;
+                    if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); break; }
+                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
+                s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
+            }
+            __syncthreads();
+            XL_WALL(21);
+            if (tid < DK) {
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < 16; s += 2) {
+                    if (s < nr) t0 += s_pv[s * DK + tid];
+                    if (s + 1 < nr) t1 += s_pv[(s + 1) * DK + tid];
+                }
+                const float o = (float)(t0 + t1);
+                int8_t q8; float d8; uint32_t s8;
+                q8_block32(o, TI::q81, q8, d8, s8);
+                const uint32_t packed = xp_pack4(q8);
+                xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+                const int blk = hx_head * 2 + (tid >> 5);
+                if ((tid & 3) == 0) xp_put(G + XP_G_ATT + hx_head * 16 + (tid >> 2), epoch, packed);
+                if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
+            }
+            XL_WALL(22);
+            __syncthreads();                      // s_pv is rewritten by the next helper duty
+        }
+    };
+
+    for (int tk = 0; tk < p.n_tok; tk++) {
+        const uint32_t epoch = epoch0 + (uint32_t)tk;
+        const int n_past = n_past0 + tk;
+        const int n_gen = n_gen0 + tk;
+        const bool more = tk + 1 < p.n_tok;
+        if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;       // a disturbed launch drains token by token
+        if (tk == 0) fetch_kv(0, n_past);
+        // the unit weights are per-token objects: nothing of them is carried from one token to the next (register budget: 14-16 units beside
+        // the lm_head's 16 would not fit)
+        Unit<WT> wqkv[FIRST && ROLE == 0 ? QS : 1], wo[FIRST ? OS : 1], w1[SECOND ? FS : 1], w2[SECOND ? F2R : 1][2];
+        // ---- the weights of own layer L into registers (unpacked there while they wait), its small vectors into LDS ----
+        auto load_unit_weights = [&](const int L) __attribute__((always_inline)) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+            const bool worker = tid < 256;
+            const XpLayer &Y = p.layers[L];
+            float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
+            if (worker) {
+                if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
+                else { l0 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
+            }
+            float bv = 0.0f;
+            if (tid < 192) { if (ROLE == 0) bv = Y.bqkv[(tid >> 6) * 1024 + slot * 64 + (tid & 63)]; }
+            else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
+            else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
+            else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int s = 0; s < QS; s++) {
+                    const int jj = s * 2 * NW + wave * 2 + rsub;
+                    load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + slot * 64 + (jj & 63)) * 32 + sub);
+                }
+            }
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+            }
+            if constexpr (SECOND) {
+#pragma unroll
+                for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+#pragma unroll
+                for (int r = 0; r < F2R; r++)
+#pragma unroll
+                    for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+            }
+            if (worker) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
+            if (tid < 384) s_bias[tid] = bv;
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int s = 0; s < QS; s++) xp_settle<WT, true>(wqkv[s]);
+            }
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int s = 0; s < OS; s++) xp_settle<WT, true>(wo[s]);
+            }
+            if constexpr (SECOND) {
+#pragma unroll
+                for (int s = 0; s < FS; s++) xp_settle<WT, true>(w1[s]);
+#pragma unroll
+                for (int r = 0; r < F2R; r++) { xp_settle<WT, true>(w2[r][0]); xp_settle<WT, true>(w2[r][1]); }
+            }
+        };
+
+        // An own layer: [stage A] -> helper duty -> [stage C | stages D, E] (+ the next own unit's weights); every other layer: helper duty only.
+        // (Three separate walks below, so that no unit weights are live before the first and after the last own layer.)
+        auto stage_pre = [&](const int L) __attribute__((always_inline)) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6;
+            const int sub = lane & 31, rsub = lane >> 5;
+            const bool worker = tid < 256;
+            constexpr bool own_first = FIRST;
+            xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+            if constexpr (FIRST) {
+                {
+                    // ---- the layer input: the embedding of the sampled token (layer 0) or the previous layer's granules ----
+                    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (L == 0) {
+                        int tok;
+                        if (tk > 0 || p.tok_src == 2) {
+                            // greedy sampler of the previous token (main.cpp:109-128, top_k = 1): arg-max over the per-block partials of its logits --
+                            // granules from the lm_head XCDs inside a multi-token launch, else the partials the previous launch left; lowest id wins ties
+                            float bv = -INFINITY;
+                            int bi = 0x7fffffff;
+                            if (tk > 0) {
+                                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                                const bool a0 = tid < p.lm_blocks, a1 = tid + NT < p.lm_blocks;
+                                const uint32_t prev = epoch - 1u;
+                                for (uint32_t spins = 0;; spins++) {
+                                    bool ok = true;
+                                    if (a0) {
+                                        const xp_u64 x0 = __hip_atomic_load(p.samp + tid, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid, XP_RLX);
+                                        v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
+                                        ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
+                                    }
+                                    if (a1) {
+                                        const xp_u64 x0 = __hip_atomic_load(p.samp + tid + NT, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid + NT, XP_RLX);
+                                        v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
+                                        ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
+                                    }
+                                    if (__all(ok)) break;
+                                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); break; }
+                                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
+                                if (a1) {
+                                    const float ov = __uint_as_float(v[2]);
+                                    const int oi = (int)v[3];
+                                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                                }
+                            } else {
+                                for (int k = tid; k < p.nparts; k += NT) {
+                                    const float v = p.pmax_val[k];
+                                    const int ix = p.pmax_idx[k];
+                                    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+                                }
+                            }
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1) {
+                                const float ov = __shfl_xor(bv, off, 64);
+                                const int oi = __shfl_xor(bi, off, 64);
+                                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                            }
+                            if (lane == 0) { s_redf[wave] = bv; s_redi[wave] = bi; }
+                            __syncthreads();
+                            bv = s_redf[0]; bi = s_redi[0];
+#pragma unroll
+                            for (int w = 1; w < NW; w++)
+                                if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
+                            tok = bi;
+                            if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                            if (slot == 0 && tid == 0) {
+                                int32_t *tokens = state_tokens(p.st);
+                                if (n_gen < p.n_positions) tokens[p.n_positions + n_gen] = tok;
+                                tokens[0] = tok;
+                            }
+                            __syncthreads();       // s_redf is reused by the helper duty
+                        } else {
+                            tok = state_tokens(p.st)[0];
+                        }
+                        if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
+                            float e[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                            xv = make_float4(e[0], e[1], e[2], e[3]);
+                        }
+                    } else if (wave < 4) {
+                        uint32_t v[4];
+                        xp_sweep<4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                        xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+                    }
+                    if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;      // residual of stage C
+                    XL_WALL(0);
+                    if constexpr (ROLE == 0) {
+                        // ================= stage A: LayerNorm -> Q8 -> the 192 q / k / v rows of head `slot`, published for the head's helpers =================
+                        float4 lnw = xv, lnb = xv;
+                        if (worker) { lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid]; }
+                        ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                        XL_WALL(6);
+                        uint32_t ax[8];
+                        const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                        const float axd = s_xd[sub];
+                        const uint32_t axs = s_xs[sub];
+                        float *const part = s_part + wave * 2 * QS * DEC_PS;
+#pragma unroll
+                        for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < 2 * QS) {
+                            const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                            float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
+                            const int which = jj >> 6, d = jj & 63;
+                            if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                            xp_put(G + XP_G_QKV + which * 1024 + slot * 64 + d, epoch, __float_as_uint(v));
+                        }
+                        XL_WALL(1);
+                    }
+                }
+            }
+        };
+        auto stage_post = [&](const int L) __attribute__((always_inline)) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6;
+            const int sub = lane & 31, rsub = lane >> 5;
+            constexpr bool own_first = FIRST;
+            xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+            if constexpr (FIRST) {
+                {
+                    // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
+                    if (wave < 5) {
+                        uint32_t v[1];
+                        xp_sweep<1>(G + XP_G_ATT + tid, true, epoch, v, p);
+                        if (tid < 256) s_xq[tid] = v[0];
+                        else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
+                        else s_xs[tid - 288] = v[0];
+                    }
+                    __syncthreads();
+                    XL_WALL(8);
+                    {
+                        uint32_t ax[8];
+                        const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                        const float axd = s_xd[sub];
+                        const uint32_t axs = s_xs[sub];
+                        float *const part = s_part + wave * 2 * OS * DEC_PS;
+#pragma unroll
+                        for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < 2 * OS) {
+                            const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
+                            const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
+                            xp_put(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
+                        }
+                    }
+                    XL_WALL(3);
+                    __syncthreads();       // s_ln / s_bias are rewritten by the next unit's load
+                    if (L + 4 < n_layer) load_unit_weights(L + 4);
+                }
+            }
+            if constexpr (SECOND) {
+                {
+                    // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
+                    float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
+                    if (wave < 4) {
+                        uint32_t v[4];
+                        xp_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
+                        x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+                        reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
+                        lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
+                    }
+                    ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                    {
+                        uint32_t ax[8];
+                        const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                        ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                        const float axd = s_xd[sub];
+                        const uint32_t axs = s_xs[sub];
+                        float *const part = s_part + wave * 2 * FS * DEC_PS;
+#pragma unroll
+                        for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < 2 * FS) {
+                            const int jr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                            const float v = __fadd_rn(s_bias[224 + jr], sum32_in_order(part + lane * DEC_PS));
+                            const uint32_t ix = f2h(v), neg = ix - 0x8000u;               // ggml_gelu: fp16 table
+                            uint16_t g16;
+                            if (ix < (uint32_t)p.gelu_p) g16 = s_gelu[ix];
+                            else if (ix <= 0x7C00u) g16 = (p.gelu_p > 0) ? (uint16_t)ix : p.gelu_tab[ix];
+                            else if (neg < (uint32_t)p.gelu_n) g16 = s_gelu[p.gelu_p + neg];
+                            else if (neg < 0x7C00u && p.gelu_n > 0) g16 = (uint16_t)p.gelu_z;
+                            else g16 = p.gelu_tab[ix];                                     // -inf, NaN (or no slice in LDS)
+                            s_g[jr] = h2f(g16);
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < 128) {
+                        int8_t q8; float d8; uint32_t s8;
+                        q8_block32(s_g[tid], TI::q81, q8, d8, s8);
+                        const uint32_t packed = xp_pack4(q8);
+                        const int blk = slot * 4 + (tid >> 5);
+                        if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), epoch, packed);
+                        if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
+                    }
+                    // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
+                    {
+                        constexpr int NQ = 1024 / NT;
+                        uint32_t v[NQ + 1];
+                        const xp_u64 *g = G + XP_G_H + tid;
+                        const bool tail = tid < 256;
+                        for (uint32_t spins = 0;; spins++) {
+                            bool ok = true;
+#pragma unroll
+                            for (int k = 0; k < NQ; k++) {
+                                const xp_u64 a = __hip_atomic_load(g + k * NT, XP_RLX);
+                                v[k] = (uint32_t)a;
+                                ok &= (uint32_t)(a >> 32) == epoch;
+                            }
+                            if (tail) {
+                                const xp_u64 a = __hip_atomic_load(g + 1024, XP_RLX);
+                                v[NQ] = (uint32_t)a;
+                                ok &= (uint32_t)(a >> 32) == epoch;
+                            }
+                            if (__all(ok)) break;
+                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); break; }
+                            if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];
+                        if (tid < 128) s_hd[tid] = __uint_as_float(v[NQ]);
+                        else if (tid < 256) s_hs[tid - 128] = v[NQ];
+                    }
+                    __syncthreads();
+                    {
+                        float *const part = s_part + wave * F2R * DEC_PS2;
+#pragma unroll
+                        for (int it = 0; it < 2; it++) {
+                            const int u = lane + 64 * it;
+                            uint32_t ax[8];
+                            const uint4 a = *reinterpret_cast<const uint4 *>(s_hq + u * 8), b = *reinterpret_cast<const uint4 *>(s_hq + u * 8 + 4);
+                            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                            const float axd = s_hd[u];
+                            const uint32_t axs = s_hs[u];
+#pragma unroll
+                            for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = xp_dot<WT, true>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < F2R) {
+                            const float4 *p4 = reinterpret_cast<const float4 *>(part + lane * DEC_PS2);
+                            float sumf = 0.0f;
+#pragma unroll
+                            for (int b0 = 0; b0 < 32; b0 += 8) {
+                                float4 t[8];
+#pragma unroll
+                                for (int j = 0; j < 8; j++) t[j] = p4[b0 + j];
+#pragma unroll
+                                for (int j = 0; j < 8; j++) {
+                                    sumf = __fadd_rn(sumf, t[j].x); sumf = __fadd_rn(sumf, t[j].y);
+                                    sumf = __fadd_rn(sumf, t[j].z); sumf = __fadd_rn(sumf, t[j].w);
+                                }
+                            }
+                            const int lr = wave * F2R + lane, row = slot * 32 + lr;
+                            const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
+                            xp_put(G + XP_G_X + xp_col_slot(row), epoch, __float_as_uint(v));
+                            if (L == n_layer - 1) p.x_final[row] = v;
+                        }
+                    }
+                    __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit's load
+                    if (L + 4 < n_layer) load_unit_weights(L + 4);
+                }
+            }
+        };
+
+        // ---- walk 1: layers before this XCD's first own one (first token of the launch only: its first weight load is issued one layer ahead of
+        //      its turn, not all eight XCDs' at kernel start -- 57 MB at once would delay layer 0) ----
+        const int l_pre = (my_last < 0) ? n_layer : ((tk == 0) ? (my_l0 > 0 ? my_l0 - 1 : 0) : 0);
+        for (int L = 0; L < l_pre; L++) helper(L, epoch, n_past, false, more);
+        if (my_last >= 0) {
+            load_unit_weights(my_l0);
+            // ---- walk 2: up to the last own layer ----
+            for (int L = l_pre; L <= my_last; L++) {
+                const bool own = (L & 3) == my_l0;
+                if (FIRST && own) stage_pre(L);
+                helper(L, epoch, n_past, own && FIRST, more);
+                if (own) stage_post(L);
+            }
+        }
+        // ---- final LayerNorm + lm_head (biogpt.cpp:799-811) on the XCDs that are done: four 64-row blocks per workgroup, loaded now, used when the
+        //      last layer's output arrives; the layers in between only need this workgroup's helper duty ----
+        if (!lm_mine) {
+            // ---- walk 3: the layers after the last own one ----
+            for (int L = (my_last < 0 ? n_layer : my_last + 1); L < n_layer; L++) helper(L, epoch, n_past, false, more);
+        } else {
+            Unit<WT> wl[LMS];
+            const int row0 = lm_rank * 256;
+            {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+#pragma unroll
+            for (int s = 0; s < LMS; s++) {
+                const int row = row0 + s * 2 * NW + wave * 2 + rsub;
+                if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
+                else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
+            }
+#pragma unroll
+            for (int s = 0; s < LMS; s++) xp_settle<WT, true>(wl[s]);
+        }
+            // ---- walk 3 with the lm_head rows in registers ----
+            for (int L = (my_last < 0 ? n_layer : my_last + 1); L < n_layer; L++) helper(L, epoch, n_past, false, more);
+            {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+            const bool worker = tid < 256;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
+            if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
+            if (wave < 4) {
+                uint32_t v[4];
+                xp_sweep<4, 256>(p.gran + (size_t)(n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+            ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            uint32_t ax[8];
+            const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+            ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+            const float axd = s_xd[sub];
+            const uint32_t axs = s_xs[sub];
+            float *const part = s_part + wave * 2 * LMS * DEC_PS;
+#pragma unroll
+            for (int s = 0; s < LMS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float best_val = -INFINITY;
+            int best_idx = 0x7fffffff;
+            if (lane < 2 * LMS) {
+                const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                if (row < p.n_vocab) {
+                    const float v = sum32_in_order(part + lane * DEC_PS);
+                    p.logits[row] = v;
+                    if (p.logits_host) p.logits_host[row] = v;
+                    best_val = v; best_idx = row;
+                }
+            }
+            // per-block partial arg-max (lowest index wins ties): groups of 64 / NW lanes, then the NW waves through LDS
+#pragma unroll
+            for (int off = 1; off < 64 / NW; off <<= 1) {
+                const float ov = __shfl_xor(best_val, off, 64);
+                const int oi = __shfl_xor(best_idx, off, 64);
+                if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
+            }
+            constexpr int LPB = 64 / NW;
+            if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
+            __syncthreads();
+            if (tid < 4) {
+                float bv = s_redf[tid * NW];
+                int bi = s_redi[tid * NW];
+#pragma unroll
+                for (int w = 1; w < NW; w++) {
+                    const float ov = s_redf[tid * NW + w];
+                    const int oi = s_redi[tid * NW + w];
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                const int blk = lm_rank * 4 + tid;
+                if (blk < p.lm_blocks) {
+                    p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi;
+                    if (more) {        // the sampler of the next token runs on XCD 0
+                        xp_put(p.samp + blk, epoch, __float_as_uint(bv));
+                        xp_put(p.samp + 1024 + blk, epoch, (uint32_t)bi);
+                    }
+                }
+            }
+            __syncthreads();       // s_redf / s_part / s_xq are rewritten by this workgroup's next token
+            }
+        }
+    }   // tokens
+    if (threadIdx.x == 0) {
+        if (xcd == last_xcd && slot == 0) {
+            if (epoch0 + (uint32_t)p.n_tok > 0xF0000000u) xp_fail(p, 5u);
+            __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
+            __hip_atomic_store(p.ctl + 2, __hip_atomic_load(p.ctl + 2, XP_RLX) + 1u, XP_RLX);
+        }
+        if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { p.st->n_past = n_past0 + p.n_tok; p.st->n_gen = n_gen0 + p.n_tok; }
+    }
+}
+
+template <int WT, int KR>
+__global__ __launch_bounds__(512) void dec_xlong_kernel(const XpParams p) {
+    constexpr int NT = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *const s_redi = reinterpret_cast<int *>(smem + XP_S_REDF + 256);
+    uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+    // XCD and rank inside the XCD: as in dec_xpipe_kernel (HW_REG_XCC_ID + a per-XCD arrival ticket)
+    const uint32_t epoch0 = __hip_atomic_load(p.ctl, XP_RLX);
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
+        const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
+        s_redi[0] = (int)xcc;
+        s_redi[1] = (int)(t - 32u * (__hip_atomic_load(p.ctl + 2, XP_RLX) - 1u));
+    }
+    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
+    __syncthreads();
+    if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
+    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
+    if (xcd & 1) {      // the MLP halves look GELU up in LDS
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
+        const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
+        for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
+        for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
+        xl_run<WT, KR, 2>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+        return;
+    }
+    if (slot < 16) xl_run<WT, KR, 0>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    else xl_run<WT, KR, 1>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+}
+
+}  // namespace bgk

@@ -64,6 +64,7 @@ struct XpParams {
     const XpLayer *layers;
     int32_t n_layer;
     xp_u64 *gran;              // [n_layer][XP_G_LAYER], zeroed once at allocation
+    xp_u64 *gran_l;            // [n_layer][XL_G_LAYER] (kernels_xlong.hip.h: scores and partial outputs of the key-range helpers), zeroed once; null: no long-context variant
     uint32_t *ctl;             // [0] hand-off tag of the launch's first token (starts at 1, + n_tok per launch), [1] error word, [2] launch counter (starts at 1), [8..15] per-XCD arrival tickets
     uint32_t *err_host;        // pinned mirror of the error word
     DevState *st;

@@ -1,0 +1,67 @@
+// Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys; kernels_xlong.hip.h: 257 .. 1024
+// keys): 5 block formats x (4 + 2) context variants = 30 persistent kernels, compiled apart from engine.hip so that the two build in
+// parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
+// parameter block crosses the boundary as bytes (same header, same layout; the size is checked).
+#define bgk bgk_xp
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "kernels_xlong.hip.h"
+
+namespace {
+
+template <int WT>
+hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &xp) {
+    // 8 waves per workgroup: 14-16 weight units per lane, unpacked to 9 registers each, + the head's old keys / values (<= 256 keys) or this
+    // workgroup's key range of the next layer (beyond) fit the 256-register budget
+    if (t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), dim3(256), dim3(512), sm, st, xp);
+    else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);
+    else if (t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), dim3(256), dim3(512), sm, st, xp);   // 24 instead of 32 value registers
+    else if (t_cap <= 256) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>), dim3(256), dim3(512), sm, st, xp);
+    else if (xp.gran_l == nullptr || t_cap > 1024) return hipErrorInvalidValue;
+    else if (t_cap <= 512) hipLaunchKernelGGL((bgk::dec_xlong_kernel<WT, 32>), dim3(256), dim3(512), sm, st, xp);
+    else hipLaunchKernelGGL((bgk::dec_xlong_kernel<WT, 64>), dim3(256), dim3(512), sm, st, xp);
+    return hipGetLastError();
+}
+
+template <int WT>
+hipError_t set_lds_t(size_t sm) {
+    const void *fns[6] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 32>), reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 64>)};
+    for (const void *fn : fns) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+// wt: the kernels' WType value (2, 3, 6, 7, 8); params: a bgk::XpParams
+extern "C" int bg_xpipe_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes) {
+    if (!params || params_bytes != sizeof(bgk::XpParams)) return (int)hipErrorInvalidValue;
+    const bgk::XpParams &xp = *static_cast<const bgk::XpParams *>(params);
+    switch (wt) {
+        case bgk::W_Q4_0: return (int)launch_t<bgk::W_Q4_0>(t_cap, smem_bytes, st, xp);
+        case bgk::W_Q4_1: return (int)launch_t<bgk::W_Q4_1>(t_cap, smem_bytes, st, xp);
+        case bgk::W_Q5_0: return (int)launch_t<bgk::W_Q5_0>(t_cap, smem_bytes, st, xp);
+        case bgk::W_Q5_1: return (int)launch_t<bgk::W_Q5_1>(t_cap, smem_bytes, st, xp);
+        case bgk::W_Q8_0: return (int)launch_t<bgk::W_Q8_0>(t_cap, smem_bytes, st, xp);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// > 64 KB of dynamic LDS needs the opt-in attribute (per device); set outside any stream capture
+extern "C" int bg_xpipe_set_lds(int wt, size_t smem_bytes) {
+    switch (wt) {
+        case bgk::W_Q4_0: return (int)set_lds_t<bgk::W_Q4_0>(smem_bytes);
+        case bgk::W_Q4_1: return (int)set_lds_t<bgk::W_Q4_1>(smem_bytes);
+        case bgk::W_Q5_0: return (int)set_lds_t<bgk::W_Q5_0>(smem_bytes);
+        case bgk::W_Q5_1: return (int)set_lds_t<bgk::W_Q5_1>(smem_bytes);
+        case bgk::W_Q8_0: return (int)set_lds_t<bgk::W_Q8_0>(smem_bytes);
+        default: return (int)hipErrorInvalidValue;
+    }
+}

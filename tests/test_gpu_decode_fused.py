@@ -502,3 +502,69 @@ def test_pipeline_slot_is_handed_back_and_replicas_reload(pkg, oracle, files):
         ref, _ = oracle.OracleModel(files["q4_0"], n_threads=16).generate_greedy(pa, 12, n_batch=8)
         assert list(ids[0]) == list(ref)
         r.close()
+
+
+# ---- the pipeline beyond 256 keys (csrc/kernels_xlong.hip.h): attention spread over the chip, 32 / 64 keys per helper workgroup ----------
+
+@pytest.mark.parametrize("name", XPIPE_TYPES)
+def test_xlong_step_is_bit_identical_to_the_five_launch_layer_and_the_oracle(pkg, oracle, files, monkeypatch, name):
+    """Single-token steps at 257 .. 1024 keys with the pipeline on (key-range helpers on every XCD, scores / partial outputs handed over as
+    granules) and off (five launches per layer + the three key-split attention launches): logits and the appended K / V rows identical bit
+    for bit; the oracle within the contract.  Positions around the 256 / 512 / 1024 bucket borders and around helper-range borders."""
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device (xpipe_state %d)" % g.xpipe_state())
+    o = oracle.OracleModel(files[name], n_threads=16)
+    rng = np.random.default_rng(43)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 1023)]
+    checked = [255, 256, 257, 287, 288, 320, 447, 511, 512, 513, 575, 576, 640, 831, 832, 1000, 1022, 1023]
+    n_past, worst = 0, 0.0
+    while n_past <= checked[-1]:
+        if n_past in checked:
+            _with_xpipe(g, monkeypatch, True)
+            lp = g.eval([toks[n_past]], n_past)
+            assert g.xpipe_state() == 1, "pipeline abandoned at n_past %d" % n_past
+            kp = [g.read_kv(w, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"]) for w in (0, 1)]
+            _with_xpipe(g, monkeypatch, False)
+            lf = g.eval([toks[n_past]], n_past)
+            kf = [g.read_kv(w, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"]) for w in (0, 1)]
+            lo = o.eval([toks[n_past]], n_past)
+            assert (lp == lf).all(), "%s: pipeline != five-launch layer at n_past %d (max diff %g)" % (name, n_past, np.abs(lp - lf).max())
+            assert (kp[0] == kf[0]).all() and (kp[1] == kf[1]).all(), n_past
+            worst = max(worst, float(np.abs(lp - lo).max()))
+            assert int(lp.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            g.eval_device(chunk, n_past); g.synchronize(); o.eval(chunk, n_past)
+            n_past += m
+    print("%s: long-context pipeline worst |diff| vs oracle %.2e" % (name, worst))
+    assert worst <= ATOL
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_xlong_generation_in_multi_token_launches(pkg, oracle, files10, monkeypatch, name):
+    """10 layers, greedy generation from 250 to 1024 keys: the <= 256-key launch, then ONE launch per bucket (257 .. 512, 513 .. 1024) whose
+    helpers append the K / V rows they will read back themselves for later tokens of the same launch -- ids identical with the pipeline off,
+    the first 24 the oracle's, the pipeline still on at the end; then single-token evals on top of that cache."""
+    g = pkg.BiogptModel.load(files10[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    rng = np.random.default_rng(47)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW10["n_vocab"], 249)]
+    n_predict = KW10["n_positions"] - len(prompt)
+    ids_p, _ = g.generate_greedy(prompt, n_predict=n_predict, n_batch=8)
+    assert g.xpipe_state() == 1
+    lp = g.eval([int(ids_p[-2])], KW10["n_positions"] - 1)            # the cache the long launches left, read by one more pipelined step
+    _with_xpipe(g, monkeypatch, False)
+    ids_f, _ = g.generate_greedy(prompt, n_predict=n_predict, n_batch=8)
+    assert len(ids_p) == n_predict and list(ids_p) == list(ids_f)
+    lf = g.eval([int(ids_f[-2])], KW10["n_positions"] - 1)
+    assert (lp == lf).all()
+    ids_o, _ = oracle.OracleModel(files10[name], n_threads=16).generate_greedy(prompt, n_predict=24, n_batch=8)
+    assert list(ids_p[:24]) == list(ids_o)
+    g.close()
