@@ -2190,7 +2190,27 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
     HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
     if (!xpipe_check(ctx)) return -2;
-    if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1) {
+    if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1 && bucket_tmax(ctx, b) > 256) {
+        // long-context variant (kernels_xlong.hip.h): [n_layer][32] stamps of workgroup 0 of the layer's own XCDs (it is also the first helper -- and the combiner -- of head 2 xcd)
+        const int nl = ctx->hp.n_layer;
+        std::vector<unsigned long long> w((size_t)nl * 32);
+        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp, w.size() * 8, hipMemcpyDeviceToHost));
+        const int order[18] = {0, 6, 1, 16, 17, 18, 19, 20, 21, 22, 8, 3, 9, 10, 11, 4, 12, 5};
+        const char *names[18] = {"x arrived", "LayerNorm + Q8 done", "q/k/v rows published", "helper: q row arrived", "helper: own scores published", "helper: head's scores arrived",
+                                 "helper: max / exp / sum done", "helper: partial PV published", "combiner: partials arrived", "combiner: attention output published",
+                                 "attention output arrived", "out_proj rows published", "x1 arrived", "LayerNorm + Q8 done", "fc1 rows + GELU done",
+                                 "fc1 activations published", "fc1 activations arrived", "layer output published"};
+        double seg[18] = {}, hop = 0.0;
+        for (int l = 1; l < nl; l++) {
+            for (int k = 1; k < 18; k++) seg[k] += (double)(long long)(w[(size_t)l * 32 + order[k]] - w[(size_t)l * 32 + order[k - 1]]) * 0.01;
+            hop += (double)(long long)(w[(size_t)l * 32] - w[(size_t)(l - 1) * 32 + 5]) * 0.01;
+        }
+        const double n = nl > 1 ? nl - 1 : 1;
+        fprintf(stderr, "XCD pipeline, long-context variant: wall clock of workgroup 0 of the layer's XCDs, mean over layers 1.. (us since the previous line)\n");
+        fprintf(stderr, "   %-40s %6.2f   (previous layer's output published -> seen on the next XCD)\n", names[0], hop / n);
+        for (int k = 1; k < 18; k++) fprintf(stderr, "   %-40s %6.2f\n", names[k], seg[k] / n);
+        fprintf(stderr, "   one layer = %.2f us\n", nl > 1 ? (double)(long long)(w[(size_t)(nl - 1) * 32 + 5] - w[5]) * 0.01 / n : 0.0);
+    } else if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1) {
         // XCD pipeline (build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS): wall clock (100 MHz) of workgroup 0 of each layer's XCD, last replay
         const int nl = ctx->hp.n_layer;
         std::vector<unsigned long long> w((size_t)nl * 16);

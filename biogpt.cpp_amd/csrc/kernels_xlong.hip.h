@@ -40,8 +40,10 @@ constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
 #ifdef BIOGPT_HIP_PROFILE_HOOKS
 // wall clock of workgroups 0 and 16 of the layer's own XCD ([n_layer][32] slots; workgroup 0 is also the first helper of head 2 xcd)
 #define XL_WALL(k) do { if (p.wall && tid == 0 && (slot & 15) == 0 && own_first) p.wall[L * 32 + (k)] = wall_clock64(); } while (0)
+#define XL_WALL2(k) do { if (p.wall && tid == 0 && slot == 0) p.wall[L * 32 + (k)] = wall_clock64(); } while (0)      // the MLP half's workgroup 0
 #else
 #define XL_WALL(k) do {} while (0)
+#define XL_WALL2(k) do {} while (0)
 #endif
 
 // ROLE 0: workgroups 0-15 of an even XCD (LayerNorm + the 192 q / k / v rows of head `slot`, out_proj rows); 1: workgroups 16-31 of an even
@@ -240,9 +242,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             }
             XL_WALL(20);
         }
-        // this workgroup's K / V rows for its next helper duty: the next layer of this token, or layer 0 of the next token
-        if (L + 1 < n_layer) fetch_kv(L + 1, n_past);
-        else if (more) fetch_kv(0, n_past + 1);
         if (hx_j0 < T && hx_r == 0) {
             // ---- the head's first helper adds the partials in range order (attn_split_combine_kernel), Q8, publishes for the layer's own XCD ----
             __syncthreads();                      // s_pv: the slice sums above have been read
@@ -293,6 +292,14 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             }
             XL_WALL(22);
             __syncthreads();                      // s_pv is rewritten by the next helper duty
+        }
+        // this workgroup's K / V rows for its next helper duty (the next layer of this token, or layer 0 of the next token) -- issued AFTER the combiner's
+        // polls, and on the layer's own XCD after stage C has published its rows: 32 KB of cache-missing loads occupy the compute unit's memory
+        // pipeline for ~1.5 us, and whatever is issued behind them -- a poll (a wave's loads return in order), even a hand-off store -- waits
+        // (measured: +1.9 .. 2.6 us on the chain in every earlier place)
+        if (!own_first) {
+            if (L + 1 < n_layer) fetch_kv(L + 1, n_past);
+            else if (more) fetch_kv(0, n_past + 1);
         }
     };
 
@@ -519,6 +526,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     }
                     XL_WALL(3);
+                    if (L + 1 < n_layer) fetch_kv(L + 1, n_past);      // deferred from the helper duty (see there)
+                    else if (more) fetch_kv(0, n_past + 1);
                     __syncthreads();       // s_ln / s_bias are rewritten by the next unit's load
                     if (L + 4 < n_layer) load_unit_weights(L + 4);
                 }
@@ -532,9 +541,11 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         xp_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
                         x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                         reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
+                        XL_WALL2(9);
                         lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                     }
                     ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                    XL_WALL2(10);
                     {
                         uint32_t ax[8];
                         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -561,6 +572,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     }
                     __syncthreads();
+                    XL_WALL2(11);
                     if (tid < 128) {
                         int8_t q8; float d8; uint32_t s8;
                         q8_block32(s_g[tid], TI::q81, q8, d8, s8);
@@ -569,6 +581,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), epoch, packed);
                         if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
                     }
+                    XL_WALL2(4);
                     // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
                     {
                         constexpr int NQ = 1024 / NT;
@@ -599,6 +612,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         else if (tid < 256) s_hs[tid - 128] = v[NQ];
                     }
                     __syncthreads();
+                    XL_WALL2(12);
                     {
                         float *const part = s_part + wave * F2R * DEC_PS2;
 #pragma unroll
@@ -635,6 +649,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             if (L == n_layer - 1) p.x_final[row] = v;
                         }
                     }
+                    XL_WALL2(5);
                     __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit's load
                     if (L + 4 < n_layer) load_unit_weights(L + 4);
                 }
