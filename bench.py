@@ -297,7 +297,7 @@ def main():
                                        "bytes_per_launch": sb, "us_per_launch": round(ss * 1e6, 2), "GBps": round(sb / ss / 1e9, 1)}
             # whole-token: graph replay at fixed context, HIP-event timed
             tok = {}
-            for T in (104, 1024):
+            for T in (104, 512, 1024):
                 s = model.bench_decode(T - 1, reps=30)
                 b = pkg.decode_bytes_per_token(hp, T)
                 tok["T=%d" % T] = {"us_per_token": round(s * 1e6, 2), "tokens_per_s": round(1.0 / s, 1),
@@ -305,7 +305,8 @@ def main():
                                    "bytes_per_token": int(b)}
             out["token_roofline"] = tok
             multi = os.environ.get("BIOGPT_HIP_XPIPE_MULTI", "1") != "0"
-            out["decode_path"] = (("xcd-pipeline: layers + lm_head + greedy sampler in ONE persistent launch per context bucket (64 / 128 / 256 keys)" if multi else
+            out["decode_path"] = (("xcd-pipeline: layers + lm_head + greedy sampler in ONE persistent launch per context bucket (64 / 128 / 192 / 256 keys: a head's K / V rows in its workgroup's "
+                                   "registers; 512 / 1024 keys: every head's keys spread over 16 helper workgroups of XCD head / 2, csrc/kernels_xlong.hip.h)" if multi else
                                    "xcd-pipeline: layers + lm_head in ONE persistent launch per token") if model.xpipe_state() == 1 else "five launches per layer + lm_head")
             # batched multi-sequence decode on this one GPU (biogpt_hip_generate_greedy_batch): S independent
             # 200-token continuations decoded together, weights read once per step for all S -- NOT the headline
