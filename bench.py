@@ -343,6 +343,15 @@ def main():
             out["api_loop"] = {"tokens_per_s": round(n_predict / s0, 1), "frac_of_device_loop": round(n_predict / s0 / value, 3),
                                "ids_match_device_loop": bool((np.asarray(ids0) == np.asarray(dev_ids)).all()),
                                "note": "biogpt_eval per token: 170 KB logits row to the host (PCIe) + host arg-max, C++ loop"}
+            model.bench_api_loop(pr, 8, 3)
+            ids3, s3 = model.bench_api_loop(pr, n_predict, 3)
+            _, s4 = model.bench_api_loop(pr, n_predict, 4)
+            out["api_loop_inplace"] = {"tokens_per_s": round(n_predict / s3, 1), "frac_of_device_loop": round(n_predict / s3 / value, 3),
+                                       "ids_match_device_loop": bool((np.asarray(ids3) == np.asarray(dev_ids)).all()),
+                                       "eval_only_tokens_per_s": round(n_predict / s4, 1),
+                                       "note": "biogpt_hip_eval_inplace per token (the row read where the launch wrote it in pinned host memory) + 8-lane host arg-max, C++ loop; "
+                                               "eval_only: the same calls without the arg-max (token fixed). One resident pipelined launch per context bucket serves the calls "
+                                               "(BIOGPT_HIP_RESIDENT=0: one launch per call)"}
             out["api_loop_topk"] = {"tokens_per_s": round(n_predict / s1, 1), "frac_of_device_loop": round(n_predict / s1 / value, 3),
                                     "ids_match_device_loop": bool((np.asarray(ids1) == np.asarray(dev_ids)).all()),
                                     "note": "biogpt_eval_sample-style: eval + device top-40 per token (512 B to the host), C++ loop"}

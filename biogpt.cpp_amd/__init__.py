@@ -81,6 +81,7 @@ SYMBOLS = [
     ("biogpt_hip_vocab_token", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     ("biogpt_hip_merge", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     ("biogpt_hip_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),

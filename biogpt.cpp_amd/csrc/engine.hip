@@ -168,7 +168,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -195,6 +195,9 @@ struct EngineOptions {
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
         xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
+        resident = get("BIOGPT_HIP_RESIDENT", 1);           // biogpt_hip_eval with one token: the pipelined launch stays on the device and takes the next call's token from a pinned mailbox
+        res_dbg = get("BIOGPT_HIP_RES_DBG", 0);              // measurement only (kernels_xpipe.hip.h XpParams::res_dbg)
+        resident_us = get("BIOGPT_HIP_RESIDENT_US", 1000);   // ... for at most this long without a new token (the device is not shared meanwhile)
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
@@ -273,6 +276,7 @@ struct biogpt_hip_ctx {
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
+    bool xp_in_call = false;               // guarded by g_xp_mu: an API call of this context has taken the device's pipeline slot and has not returned yet
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
     int xp_gelu_p = 0, xp_gelu_n = 0, xp_gelu_z = 0;   // the GELU table's slices every workgroup keeps in LDS (kernels_xpipe.hip.h)
     int xp_state = 0;                      // 0 not probed, 1 usable, -1 unusable on this device / model / after a failure
@@ -281,8 +285,19 @@ struct biogpt_hip_ctx {
     uint32_t *mbox_ctr = nullptr;          // device: replays consumed
     uint32_t mbox_sent = 0, mbox_synced = 0;
     int lm_blocks = 0;
+    // resident single-token evals (biogpt_hip_eval): a pipelined launch that is still on the device, fed through res_mbox
+    int32_t *res_mbox = nullptr;           // pinned ring of 64 x {n_past, causal, token, seq}
+    uint32_t *res_done = nullptr;          // pinned [256]: per lm_head workgroup, the sequence number of the last token whose logits rows it has written to logits_host
+    bool res_live = false;                 // a resident launch is (or may still be) on the device
+    uint32_t res_seq = 0;                  // sequence number of the last token / request posted
+    int res_next = 0, res_left = 0;        // position the live launch expects next; tokens it will still take
+    int res_nw = 0;                        // completion words to collect per token
+    double res_t_wait = 0.0, res_t_call = 0.0; long res_calls = 0;   // measurement only (BIOGPT_HIP_RES_DBG & 8)
+    std::chrono::steady_clock::time_point res_t_last{};
     bool ready = false;  // weights present
 };
+
+static bool resident_stop(biogpt_hip_ctx *c);   // ends a resident single-token launch (defined with the eval entry points)
 
 namespace {
 
@@ -586,6 +601,9 @@ void xpipe_release(biogpt_hip_ctx *c) {
     if (c->xp_ctl) (void)hipFree(c->xp_ctl);
     if (c->xp_samp) (void)hipFree(c->xp_samp);
     if (c->xp_err_host) (void)hipHostFree(c->xp_err_host);
+    if (c->res_mbox) (void)hipHostFree(c->res_mbox);
+    if (c->res_done) (void)hipHostFree(c->res_done);
+    c->res_mbox = nullptr; c->res_done = nullptr;
     c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_gran_l = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
 }
 
@@ -649,7 +667,7 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
         hipMemcpy(c->xp_layers, tab.data(), tab.size() * sizeof(bgk::XpLayer), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->xp_gran, 0, gbytes) != hipSuccess || hipMemset(c->xp_ctl, 0, 64) != hipSuccess ||
         hipMemcpy(c->xp_ctl, ctl0, 12, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&c->xp_samp, 2048 * 8) != hipSuccess || hipMemset(c->xp_samp, 0, 2048 * 8) != hipSuccess) {
+        hipMalloc(&c->xp_samp, 2056 * 8) != hipSuccess || hipMemset(c->xp_samp, 0, 2056 * 8) != hipSuccess) {
         (void)hipGetLastError();
         xpipe_release(c);
         return;
@@ -691,13 +709,29 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
 bool xpipe_bucket_ok(const biogpt_hip_ctx *c, int t_max) {
     return c->opt.xpipe && c->xp_state == 1 && (t_max <= 256 || (t_max <= 1024 && c->xp_gran_l != nullptr && c->opt.xpipe_long)) && c->device >= 0 && c->device < 64;
 }
-// ... and does this context hold the device's pipeline slot (taken here if it is free) ?
+// ... and does this context hold the device's pipeline slot ?  Taken here if it is free -- or if its holder is outside every API call that took it and
+// has nothing in flight (a resident launch that left after its idle time keeps the slot until its context is called again: such a holder is relieved here;
+// it notices at its next call, like any context that finds the slot taken).
 bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
     if (!xpipe_bucket_ok(c, t_max)) return false;
     std::lock_guard<std::mutex> lk(g_xp_mu);
-    if (g_xp_owner[c->device] == nullptr) g_xp_owner[c->device] = c;
-    return g_xp_owner[c->device] == c;
+    biogpt_hip_ctx *&owner = g_xp_owner[c->device];
+    if (owner != nullptr && owner != c && !owner->xp_in_call && hipStreamQuery(owner->stream) == hipSuccess) owner = nullptr;
+    (void)hipGetLastError();      // hipErrorNotReady of the query is not an error of this call
+    if (owner == nullptr) owner = c;
+    if (owner == c) c->xp_in_call = true;      // until the API call that asked returns (XpCallScope)
+    return owner == c;
 }
+// an API entry that may take the pipeline slot: while it runs, no other context may relieve this one of the slot (its launches are not enqueued yet)
+struct XpCallScope {
+    biogpt_hip_ctx *c;
+    explicit XpCallScope(biogpt_hip_ctx *ctx) : c(ctx) {}
+    ~XpCallScope() {
+        if (!c) return;
+        std::lock_guard<std::mutex> lk(g_xp_mu);
+        c->xp_in_call = false;
+    }
+};
 // the context's stream is idle (the caller just synchronised it): nothing pipelined is in flight, another context may have the slot
 void xpipe_handback(biogpt_hip_ctx *c) {
     if (c->device < 0 || c->device >= 64) return;
@@ -711,6 +745,11 @@ bool xpipe_check(biogpt_hip_ctx *c) {
     xpipe_handback(c);
     if (!c->xp_err_host || *c->xp_err_host == 0u) return true;
     const uint32_t code = *c->xp_err_host;
+    if (code == bgk::XP_QUIT) {     // a resident launch left on its own (idle) or on request: not a failure; the device-side word is cleared in stream order
+        *c->xp_err_host = 0u;
+        HIP_TRY(false, hipMemsetAsync(c->xp_ctl + 1, 0, 4, c->stream));
+        return true;
+    }
     *c->xp_err_host = 0u;
     c->xp_state = -1;
     c->xp_tripped = true;
@@ -725,14 +764,17 @@ int bucket_tmax(const biogpt_hip_ctx *c, int b);
 int fast_lm_grid(const biogpt_hip_ctx *c);
 bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max);
 // tokens one pipelined launch may generate from context T = n_past + 1 on: up to the end of T's context bucket (0: not on the pipeline)
-int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
-    if (!c->opt.xpipe_multi || !c->opt.xpipe_lm) return 0;
-    const int tmax = bucket_tmax(c, graph_bucket(T));
-    if (!fused_decode_ok(c, tmax) || !xpipe_usable(c, tmax)) return 0;
+// does the final LayerNorm + lm_head run inside the pipelined launch (its 64-row blocks four per workgroup of the XCDs that are done) ?
+bool xpipe_lm_folds(const biogpt_hip_ctx *c) {
     const auto &hp = c->hp;
     const MatSlot &m = c->plan.lm_head;
-    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));
-    if (!(m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024)) return 0;
+    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last unit's XCD take no part
+    return c->opt.xpipe_lm && m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
+}
+int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
+    if (!c->opt.xpipe_multi || !xpipe_lm_folds(c)) return 0;
+    const int tmax = bucket_tmax(c, graph_bucket(T));
+    if (!fused_decode_ok(c, tmax) || !xpipe_usable(c, tmax)) return 0;
     return tmax - T + 1;
 }
 
@@ -806,8 +848,9 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 // host_row (optional): pinned host buffer that also receives the logits row; *host_row_done tells whether the launch wrote it itself
 // pl: -1 = go through the XCD pipeline if this context can take the device's slot now; 0 / 1 = the caller decided (graph capture: the
 //     graph is replayed only in the matching state)
+struct ResidentArgs { int32_t tok0, n_past0; uint32_t seq0; };
 bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1, float *host_row = nullptr,
-                          bool *host_row_done = nullptr, int pl = -1) {
+                          bool *host_row_done = nullptr, int pl = -1, const ResidentArgs *ra = nullptr) {
     t_ctx = c;
     (void)hipGetLastError();
     const auto &hp = c->hp;
@@ -840,8 +883,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.x_final = c->x;
         {   // lm_head inside the launch: its 64-row blocks (= the stand-alone launch's workgroups) three per workgroup of 7 XCDs
             const MatSlot &m = c->plan.lm_head;
-            const int last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last unit's XCD take no part
-            const bool fold = c->opt.xpipe_lm && m.type == wt && m.K == 1024 && m.M == V && lm_parts == (V + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
+            const bool fold = xpipe_lm_folds(c);
             xp.lm = fold ? 1 : 0;
             xp.lm_blocks = lm_parts; xp.adv = fold ? advance : 0; xp.n_tok = n_tok; xp.samp = c->xp_samp;   // no lm_head in here: the lm_head launch moves the position
             xp.Wlm = dev_matrix(c, m);
@@ -849,7 +891,12 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             xp.logits = c->logits; xp.logits_host = fold ? host_row : nullptr; xp.pmax_out_val = c->pmax_val; xp.pmax_out_idx = c->pmax_idx;
             lm_in_kernel = fold;
             if (host_row_done) *host_row_done = fold && host_row != nullptr;
-            if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
+            if (ra) {     // resident launch (biogpt_hip_eval): token 0 and its position travel in the parameter block, the following ones through the mailbox
+                if (!(fold && host_row && advance == 0 && tok_src == 1 && xp.t_cap <= 256)) BG_FAIL(false, "internal: a resident launch needs the lm_head inside the <= 256-key pipeline");
+                xp.resident = 1; xp.mbox = c->res_mbox; xp.mbox_seq0 = ra->seq0; xp.done_host = c->res_done;
+                xp.idle_ticks = (uint32_t)std::max(1, c->opt.resident_us) * 100u;
+                xp.res_tok0 = ra->tok0; xp.res_n_past0 = ra->n_past0; xp.res_dbg = c->opt.res_dbg;
+            } else if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
         }
         xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
         const hipError_t e = (hipError_t)bg_xpipe_launch(wt, xp.t_cap, bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n), c->stream, &xp, sizeof(xp));
@@ -1282,6 +1329,9 @@ bool upload_weights(biogpt_hip_ctx *c, const ModelFile &mf) {
 void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)resident_stop(c);
+    if ((c->opt.res_dbg & 8) && c->res_calls > 0)
+        fprintf(stderr, "resident evals: %ld calls, %.2f us waiting for the completion words, %.2f us between a return and the next post\n", c->res_calls, c->res_t_wait / c->res_calls * 1e6, c->res_t_call / c->res_calls * 1e6);
     for (auto &pl : c->graph_step) for (auto &row : pl) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     for (auto &pl : c->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : c->graph_batch) if (g) (void)hipGraphExecDestroy(g);
@@ -1451,6 +1501,7 @@ int biogpt_hip_share_vocab(biogpt_hip_ctx *dst, const biogpt_hip_ctx *src) {
 
 int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
+    if (!resident_stop(ctx)) return -2;
     ctx->opt.load();
     // captured graphs bake launch shapes chosen from the options
     for (auto &pl : ctx->graph_step) for (auto &row : pl) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
@@ -1489,11 +1540,100 @@ int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes
     return 0;
 }
 
+// ---- resident single-token evals -------------------------------------------------------------------------------------------------------
+// biogpt_eval() is called once per token (main.cpp:91-151).  As separate launches every call pays the pipelined launch's start-up (arrival
+// tickets, first weight load exposed, GELU slice) + a graph launch + the completion poll: ~30 us of a ~300 us token.  With the device to itself
+// the launch can simply STAY: after token tk it waits -- bounded by BIOGPT_HIP_RESIDENT_US -- for the next call to drop {n_past, token, seq} into a
+// pinned mailbox, and every lm_head workgroup reports the rows it has written to the pinned logits row with a completion word.  A call then costs
+// two PCIe hops and no HIP API call.  Anything else the context is asked to do first ends the resident launch (resident_stop).
+static bool resident_stop(biogpt_hip_ctx *c) {
+    if (!c || !c->res_live) return true;
+    c->res_live = false;
+    if (c->res_left > 0 && c->res_mbox) {      // it still waits for tokens: ask it to leave (a slot whose position is not the expected one)
+        const uint32_t seq = ++c->res_seq;
+        volatile int32_t *slot = c->res_mbox + (size_t)(seq & 63u) * 8;
+        slot[0] = -1; slot[1] = 0; slot[2] = -1;
+        __atomic_store_n(const_cast<int32_t *>(slot) + 3, (int32_t)seq, __ATOMIC_RELEASE);
+    }
+    c->res_left = 0;
+    HIP_TRY(false, hipSetDevice(c->device));
+    HIP_TRY(false, hipStreamSynchronize(c->stream));
+    return xpipe_check(c);
+}
+
+// one token through a resident launch; 1 = done (row in ctx->logits_host), 0 = not applicable here (caller takes the ordinary path), -2 = failure
+static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
+    if (!ctx->opt.resident || ctx->opt.no_graph || !xpipe_lm_folds(ctx)) return 0;
+    const int tmax = bucket_tmax(ctx, graph_bucket(n_past + 1));
+    if (tmax > 256 || !fused_decode_ok(ctx, tmax) || !xpipe_bucket_ok(ctx, tmax)) return 0;
+    const size_t V = (size_t)ctx->hp.n_vocab;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (ctx->res_live && (*ctx->xp_err_host != 0u || ctx->res_left <= 0 || n_past != ctx->res_next)) {
+            if (!resident_stop(ctx)) return -2;      // it has left (idle), is used up, or the caller moved elsewhere in the sequence
+        }
+        uint32_t seq;
+        if (ctx->res_live) {      // hand the token to the launch that is waiting for it
+            seq = ++ctx->res_seq;
+            volatile int32_t *slot = ctx->res_mbox + (size_t)(seq & 63u) * 8;
+            slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = token;
+            __atomic_store_n(const_cast<int32_t *>(slot) + 3, (int32_t)seq, __ATOMIC_RELEASE);
+            ctx->res_next++; ctx->res_left--;
+        } else {
+            if (!xpipe_usable(ctx, tmax)) return 0;      // another context holds the device's pipeline slot
+            if (!ctx->res_mbox) {
+                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_mbox), 64 * 8 * 4, hipHostMallocDefault));
+                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_done), 256 * 4, hipHostMallocDefault));
+                std::memset(ctx->res_mbox, 0xff, 64 * 8 * 4);
+                std::memset(ctx->res_done, 0, 256 * 4);
+            }
+            if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), V * 4, hipHostMallocDefault));
+            seq = ++ctx->res_seq;
+            const int n_tok = tmax - n_past;          // up to the end of the context bucket
+            const ResidentArgs ra{token, n_past, seq};
+            bool row_done = false;
+            if (!enqueue_decode_fused(ctx, tmax, 1, 0, 0, -1, -1, n_tok, ctx->logits_host, &row_done, 1, &ra)) return -2;
+            if (!row_done) BG_FAIL(-2, "internal: the resident launch does not write the host row");
+            ctx->res_live = true; ctx->res_next = n_past + 1; ctx->res_left = n_tok - 1;
+            ctx->res_nw = (ctx->lm_blocks + 3) / 4;
+            ctx->mbox_synced = ctx->mbox_sent;
+        }
+        // completion: one word per lm_head workgroup, written behind its rows
+        const volatile uint32_t *done = ctx->res_done;
+        const int nw = ctx->res_nw;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (ctx->opt.res_dbg & 8) {      // time between the previous call's return and this post = the caller's own time + this function's overhead
+            if (ctx->res_calls > 0) ctx->res_t_call += std::chrono::duration<double>(t0 - ctx->res_t_last).count();
+            ctx->res_calls++;
+        }
+        bool ok = false, left = false;
+        for (uint32_t spin = 0;; spin++) {
+            int k = 0;
+            while (k < nw && done[k] == seq) k++;
+            if (k == nw) { ok = true; break; }
+            if (*reinterpret_cast<const volatile uint32_t *>(ctx->xp_err_host) != 0u) { left = true; break; }
+            if ((spin & 0xfffu) == 0xfffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+        }
+        if (ok) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (ctx->opt.res_dbg & 8) { ctx->res_t_last = std::chrono::steady_clock::now(); ctx->res_t_wait += std::chrono::duration<double>(ctx->res_t_last - t0).count(); }
+            return 1;
+        }
+        if (!left) { (void)resident_stop(ctx); BG_FAIL(-2, "a resident decode launch did not answer within 5 s"); }
+        // the launch left (idle time-out racing with this call) or failed: wait for it, then this token goes into a fresh launch -- or, after a
+        // failure, onto the five-launch layer through the ordinary path
+        if (!resident_stop(ctx)) return -2;
+        if (ctx->xp_state != 1) return 0;
+    }
+    return 0;
+}
+
 // form 0: the step; form 1: the step + a last node that writes the logits row into pinned host memory (biogpt_hip_eval)
 static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int form) {
+    XpCallScope xp_scope(ctx);
     clear_error();
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     // one token at a position of the five-launch decode step: replay its captured graph -- its first node pulls the
     // token and the position from a pinned mailbox slot -- instead of a copy command and 121 launches one by one
     if (n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(n_past + 1)))) {   // the captured step runs at the BUCKET's context bound
@@ -1585,13 +1725,30 @@ static int eval_topk_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n,
     return k;
 }
 
+// arg-max with the lowest index winning ties (what std::max_element returns), eight independent running maxima so that the compiler can keep them in
+// one vector register: ~4 us for 42 k logits against ~20 us for the scalar loop
+static int32_t argmax_first(const float *v, size_t n) {
+    float best[8]; int32_t at[8];
+    for (int j = 0; j < 8; j++) { best[j] = -INFINITY; at[j] = 0x7fffffff; }
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; j++)
+            if (v[i + j] > best[j]) { best[j] = v[i + j]; at[j] = (int32_t)(i + j); }
+    for (; i < n; i++)
+        if (v[i] > best[i & 7] ) { best[i & 7] = v[i]; at[i & 7] = (int32_t)i; }
+    float b = -INFINITY; int32_t a = 0x7fffffff;
+    for (int j = 0; j < 8; j++)
+        if (at[j] != 0x7fffffff && (best[j] > b || (best[j] == b && at[j] < a))) { b = best[j]; a = at[j]; }
+    return a == 0x7fffffff ? 0 : a;
+}
+
 // The reference's host loop (main.cpp:91-151, greedy) as a C++ caller would run it on this library -- one eval call per
 // token, the sampler on the host -- timed without any scripting-language overhead: mode 0 = biogpt_hip_eval (the whole
 // logits row crosses PCIe, host arg-max), mode 1 = biogpt_hip_eval_topk with k = 40 (the CLI's top_k; 512 bytes cross).
 int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_predict, int32_t mode, int32_t *out_ids,
                               double *seconds_out) {
     clear_error();
-    if (!ctx || !prompt || n_prompt < 1 || n_predict < 1 || mode < 0 || mode > 2) BG_FAIL(-1, "bad argument");
+    if (!ctx || !prompt || n_prompt < 1 || n_predict < 1 || mode < 0 || mode > 4) BG_FAIL(-1, "bad argument");
     if (!check_eval_args(ctx, prompt, n_prompt, 0)) return -1;
     n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);
     const size_t V = (size_t)ctx->hp.n_vocab;
@@ -1606,6 +1763,10 @@ int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_
         if (mode == 0) {
             if (biogpt_hip_eval(ctx, in, n_in, n_past, logits.data()) != 0) return -2;
             tok = (int32_t)(std::max_element(logits.begin(), logits.end()) - logits.begin());
+        } else if (mode == 3 || mode == 4) {   // the row read in place (pinned host memory the launch wrote), arg-max over 8 interleaved lanes; mode 4 (diagnostic): no arg-max, token fixed
+            const float *row = nullptr;
+            if (biogpt_hip_eval_inplace(ctx, in, n_in, n_past, &row) != 0) return -2;
+            tok = mode == 3 ? argmax_first(row, V) : 2;
         } else if (mode == 1) {
             if (biogpt_hip_eval_topk(ctx, in, n_in, n_past, 40, logits.data(), ids) < 0) return -2;
             tok = ids[0];
@@ -1627,13 +1788,23 @@ const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) { return ctx ? 
 
 int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
+    if (!resident_stop(ctx)) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
     if (!xpipe_check(ctx)) return -2;
     return 0;
 }
 
+// logits_out == nullptr: the row stays in the context's pinned host buffer (biogpt_hip_eval_inplace)
 static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
-    if (!logits_out) BG_FAIL(-1, "null logits buffer");
+    XpCallScope xp_scope(ctx);
+    if (n == 1) {      // one token: a launch that stays on the device between the calls of the caller's loop
+        clear_error();
+        if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
+        if (!ctx->res_live) HIP_TRY(-2, hipSetDevice(ctx->device));      // a live resident launch needs no HIP call at all
+        const int r = resident_eval(ctx, tokens[0], n_past);
+        if (r < 0) return r;
+        if (r == 1) { if (logits_out) std::memcpy(logits_out, ctx->logits_host, (size_t)ctx->hp.n_vocab * 4); return 0; }
+    }
     const int rc = eval_device_impl(ctx, tokens, n, n_past, 1);
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->hp.n_vocab * 4;
@@ -1649,7 +1820,7 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
     }
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
-    std::memcpy(logits_out, ctx->logits_host, bytes);
+    if (logits_out) std::memcpy(logits_out, ctx->logits_host, bytes);
     return 0;
 }
 
@@ -1658,6 +1829,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
     if (!logits_out) BG_FAIL(-1, "null logits buffer");
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     if ((size_t)n > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
         ctx->logits_all = nullptr;
@@ -1700,6 +1872,7 @@ int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
     if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
     if (!check_eval_args(ctx, tokens, n_tokens, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     if (!enqueue_prompt(ctx, tokens, n_tokens, n_past, n_batch)) return -2;
     if (logits_out) {
         HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1710,6 +1883,7 @@ int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
 
 static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_batch,
                                 int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+    XpCallScope xp_scope(ctx);
     clear_error();
     if (!ctx || !prompt || !out_ids) BG_FAIL(-1, "null argument");
     if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
@@ -1718,6 +1892,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);  // main.cpp:82
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     const bool use_graph = ctx->opt.no_graph == 0;
     // the device's pipeline slot, if it is free, is this call's until its final synchronisation
     auto pl_of = [&](int b) { return xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0; };
@@ -1776,7 +1951,15 @@ static bool xpipe_retry(biogpt_hip_ctx *ctx) {
     fprintf(stderr, "biogpt_hip: %s\n", last_error());
     return true;
 }
+int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, const float **row_out) {
+    if (!row_out) BG_FAIL(-1, "null row pointer");
+    int rc = eval_once(ctx, tokens, n, n_past, nullptr);
+    if (rc != 0 && xpipe_retry(ctx)) rc = eval_once(ctx, tokens, n, n_past, nullptr);
+    *row_out = rc == 0 ? ctx->logits_host : nullptr;
+    return rc;
+}
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
+    if (!logits_out) BG_FAIL(-1, "null logits buffer");
     int rc = eval_once(ctx, tokens, n, n_past, logits_out);
     if (rc != 0 && xpipe_retry(ctx)) rc = eval_once(ctx, tokens, n, n_past, logits_out);
     return rc;
@@ -1818,6 +2001,7 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     n_predict = std::min(n_predict, P - max_len);  // main.cpp:82, for the longest prompt
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     const size_t seq_stride = (size_t)hp.n_layer * P * D;
     if (n_seqs > ctx->batch_cap) {  // per-sequence F32 KV caches + state (192 MiB per BioGPT-base sequence)
         for (void *p : {(void *)ctx->bk, (void *)ctx->bv, (void *)ctx->seq, (void *)ctx->seq_gen}) if (p) (void)hipFree(p);
@@ -1943,6 +2127,7 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
     if (offset + count > total) BG_FAIL(-1, "KV range out of bounds");
     if (count == 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     // the device cache is head-major [layer][head][pos][dk]; the caller sees the reference's flat [layer][pos][d_model]
     // view (biogpt.cpp:331-335).  Only the requested range is gathered on the device and copied.
     float *stage = nullptr;
@@ -1959,11 +2144,13 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
 }
 
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
+    XpCallScope xp_scope(ctx);
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 11) BG_FAIL(-1, "bad argument");
     if (which >= 6 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     t_ctx = ctx;
     const auto &hp = ctx->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, P = hp.n_positions;
@@ -2130,6 +2317,7 @@ int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int ste
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (ctx->hp.d_model != 1024 || rows < 1024 || rows % 1024 || reps < 1 || steps < 2) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     t_ctx = ctx;
     const size_t nblk = (size_t)rows * 32;
     uint8_t *qs = nullptr, *sc = nullptr;
@@ -2168,10 +2356,12 @@ int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int ste
 }
 
 int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out) {
+    XpCallScope xp_scope(ctx);
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
     if (reps < 1 || n_past < 0 || n_past >= ctx->hp.n_positions) BG_FAIL(-1, "bad argument");
     HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
     const int b = graph_bucket(n_past + 1);
     if ((ctx->opt.dbg & 224) && !ctx->tstamp) {
         HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));

@@ -90,6 +90,16 @@ struct XpParams {
     float *logits;
     float *logits_host;        // optional pinned host copy of the row (biogpt_eval's output): written by the same lanes, no copy node behind the launch
     float *pmax_out_val; int32_t *pmax_out_idx;
+    // resident mode (biogpt_hip_eval, one token per API call): the launch stays on the device after its first token; token tk >= 1 is taken from the
+    // pinned mailbox slot (mbox_seq0 + tk) % 64 = {n_past, causal, token, seq} that the NEXT biogpt_eval() call fills -- workgroup 0 of XCD 0 waits for it,
+    // at most idle_ticks of the 100 MHz clock -- and every lm_head workgroup reports its share of the host logits row with a word in done_host
+    int32_t resident;
+    int32_t res_tok0, res_n_past0;   // token 0 of a resident launch and its position
+    int32_t res_dbg;                 // measurement only (BIOGPT_HIP_RES_DBG): 1 completion word without waiting for the row stores, 2 no sleep in the mailbox poll, 4 no row store
+    const int32_t *mbox;
+    uint32_t mbox_seq0;
+    uint32_t idle_ticks;
+    uint32_t *done_host;       // pinned [lm workgroups]: sequence number of the last token whose rows this workgroup has written to logits_host
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
 };
 
@@ -118,8 +128,43 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
     __hip_atomic_store(p.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
 template <int N, int S = 1>
+__device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
+
+// a clean end of a resident launch (no token from the host within the idle time, or the host asked for it): the same drain as a failure, its own code
+constexpr uint32_t XP_QUIT = 0x80000000u;
+__device__ __forceinline__ void xp_quit(const XpParams &p) {
+    uint32_t expected = 0u;
+    if (__hip_atomic_compare_exchange_strong(p.ctl + 1, &expected, XP_QUIT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_store(p.err_host, XP_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Sweep with a publishing tag: etag is the tag this wave publishes with (the token's epoch), or 0 once the wave has seen the error / quit word -- from
+// then on it polls nothing and publishes only tag 0, which no poller accepts: a draining launch can never hand valid-looking garbage downstream (the
+// host may be waiting for exactly that token's completion words).
+template <bool RES, int N, int S = 1>
+__device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t &etag) {
+    if constexpr (!RES) { xp_sweep<N, S>(g, active, epoch, v, p); return; }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = 0u;
+    if (etag == 0u) return;
+    for (uint32_t spins = 0;; spins++) {
+        bool ok = true;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                v[k] = (uint32_t)a;
+                ok &= (uint32_t)(a >> 32) == epoch;
+            }
+        }
+        if (__all(ok)) return;
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
+        if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
+template <int N, int S>
 __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p) {
     for (uint32_t spins = 0;; spins++) {
         bool ok = true;
@@ -193,7 +238,9 @@ __device__ __forceinline__ void xp_settle(Unit<WT> &u) {
 // SPLIT (Q8_0: 9 registers per weight unit, a whole layer does not fit one XCD's registers): a layer is two pipeline units -- LayerNorm,
 // q/k/v, attention, out_proj on an EVEN XCD (roles 0 / 1), LayerNorm, fc1, fc2 on the next, ODD XCD (role 2: all 32 workgroups) -- and
 // the out_proj output crosses XCDs like the layer output does.
-template <int WT, int LPK, int NW, int KCAP, int ROLE, bool SPLIT>
+// RES: a resident launch (biogpt_hip_eval): tokens from the host's mailbox, every publish / append gated by the wave's tag (see xp_sweep_q); the ordinary
+// instantiation compiles all of that away
+template <int WT, int LPK, int NW, int KCAP, int ROLE, bool SPLIT, bool RES>
 __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
                                        const int n_gen0) {
     using TI = TypeInfo<WT>;
@@ -228,6 +275,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+    uint32_t *const s_dead = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 96);      // [4] behind the 8 doubles the attention stage uses
     const int t_cap = p.t_cap;
     const int n_units = SPLIT ? 2 * p.n_layer : p.n_layer;                     // pipeline units: layers, or half layers
     const int last_xcd = (n_units - 1) & 7;
@@ -235,6 +283,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     // token t's logits, handed to XCD 0 as granules; the hand-off tag is the launch counter + the token's index in the launch.
     for (int tk = 0; tk < p.n_tok; tk++) {
     const uint32_t epoch = epoch0 + (uint32_t)tk;
+    uint32_t etag = epoch;          // publishing tag of this wave: 0 once it has seen the error / quit word (xp_sweep_q)
     const int n_past = n_past0 + tk, T = n_past + 1;
     if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;       // a disturbed launch drains token by token
     for (int U = xcd; U < n_units; U += 8) {
@@ -314,7 +363,34 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (L == 0) {
                 int tok;
-                if (tk > 0) {
+                if (RES && p.resident != 0 && tk > 0) {
+                    // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox.  Workgroup 0 waits for it -- at most
+                    // idle_ticks, then the launch ends cleanly (xp_quit) -- and hands it to the XCD's other workgroups as a granule
+                    xp_u64 *const gt = p.samp + 2048;
+                    if (slot == 0 && tid == 0 && etag != 0u) {
+                        const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
+                        const int32_t *mb = p.mbox + (size_t)(want & 63u) * 8;
+                        const unsigned long long t0 = wall_clock64();
+                        int got = -1;
+                        for (;;) {
+                            if ((uint32_t)__hip_atomic_load(mb + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want) {
+                                const int np = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                const int tv = __hip_atomic_load(mb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (np == n_past && tv >= 0 && tv < p.n_vocab) got = tv;      // anything else is the host's request to leave
+                                break;
+                            }
+                            if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) break;
+                            if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                            if (!(p.res_dbg & 2)) __builtin_amdgcn_s_sleep(4);
+                        }
+                        if (got < 0) xp_quit(p);
+                        else xp_put_local(gt, epoch, (uint32_t)got);
+                    }
+                    uint32_t v[1];
+                    xp_sweep_q<RES, 1>(gt, true, epoch, v, p, etag);
+                    tok = (int)v[0];
+                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                } else if (tk > 0) {
                     // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
                     // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024)
                     float bv = -INFINITY;
@@ -323,7 +399,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         uint32_t v[4] = {0u, 0u, 0u, 0u};
                         const bool a0 = tid < p.lm_blocks, a1 = tid + NT < p.lm_blocks;
                         const uint32_t prev = epoch - 1u;
-                        for (uint32_t spins = 0;; spins++) {
+                        for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
                             bool ok = true;
                             if (a0) {
                                 const xp_u64 x0 = __hip_atomic_load(p.samp + tid, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid, XP_RLX);
@@ -336,8 +412,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                                 ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                             }
                             if (__all(ok)) break;
-                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); break; }
-                            if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) etag = 0u; break; }
+                            if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
@@ -399,7 +475,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         tokens[0] = tok;
                     }
                 } else {
-                    tok = state_tokens(p.st)[0];
+                    tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
                 }
                 if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
                     float e[4];
@@ -410,9 +486,12 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             } else if (wave < 4) {
                 uint32_t v[4];
-                xp_sweep<4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                xp_sweep_q<RES, 4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, etag);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
+            // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
+            // read behind LayerNorm's barriers
+            if (RES && wave < 4 && lane == 0) s_dead[wave] = (etag == 0u) ? 1u : 0u;
             return xv;
         };
         if constexpr (FIRST) {
@@ -461,8 +540,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
                 const int which = jj >> 6, d = jj & 63;
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
-                xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, epoch, __float_as_uint(v));
-                if (which != 0) {                                               // KV append (biogpt.cpp:721-727), head-major cache
+                xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
+                if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                     float *cache = (which == 1) ? Y.kcache : Y.vcache;
                     cache[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
@@ -528,7 +607,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = jj >> 6, d = jj & 63;
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
-                    if (which != 0) {                                               // KV append (biogpt.cpp:721-727), head-major cache
+                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -542,7 +621,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 XP_WALL(0);
                 if (wave < 3) {
                     uint32_t v[1];
-                    xp_sweep<1>(G + XP_G_QKV + wave * 1024 + head * 64 + lane, true, epoch, v, p);
+                    xp_sweep_q<RES, 1>(G + XP_G_QKV + wave * 1024 + head * 64 + lane, true, epoch, v, p, etag);
                     s_cur[tid] = __uint_as_float(v[0]);
                 }
             }
@@ -621,15 +700,15 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 q8_block32(o, TI::q81, q8, d8, s8);
                 const uint32_t packed = xp_pack4(q8);
                 const int blk = head * 2 + (tid >> 5);
-                if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
-                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_ATT + 288 + blk, epoch, s8); }
+                if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), etag, packed);
+                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, etag, __float_as_uint(d8)); xp_put_local(G + XP_G_ATT + 288 + blk, etag, s8); }
             }
         }
         XP_WALL(2);
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if (wave < 5) {
             uint32_t v[1];
-            xp_sweep<1>(G + XP_G_ATT + tid, true, epoch, v, p);
+            xp_sweep_q<RES, 1>(G + XP_G_ATT + tid, true, epoch, v, p, etag);
             if (tid < 256) s_xq[tid] = v[0];
             else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
             else s_xs[tid - 288] = v[0];
@@ -651,8 +730,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (lane < 2 * OS) {
                 const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
-                if (SPLIT) xp_put(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
-                else xp_put_local(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));
+                if (SPLIT) xp_put(G + XP_G_X1 + xp_col_slot(row), etag, __float_as_uint(v));       // the MLP half runs on the next XCD
+                else xp_put_local(G + XP_G_X1 + xp_col_slot(row), etag, __float_as_uint(v));
             }
         }
         XP_WALL(3);
@@ -662,7 +741,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
+            xp_sweep_q<RES, 4, 256>(G + XP_G_X1 + tid, true, epoch, v, p, etag);
             x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
             XP_WALL(9);
@@ -702,17 +781,19 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             q8_block32(s_g[tid], TI::q81, q8, d8, s8);
             const uint32_t packed = xp_pack4(q8);
             const int blk = slot * 4 + (tid >> 5);
-            if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), epoch, packed);
-            if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
+            if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), etag, packed);
+            if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, etag, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, etag, s8); }
         }
         XP_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
         {   // 1024 + 128 + 128 granules in ONE poll loop: every pass has all of a lane's loads in flight together
             constexpr int NQ = 1024 / NT;
             uint32_t v[NQ + 1];
+#pragma unroll
+            for (int k = 0; k <= NQ; k++) v[k] = 0u;
             const xp_u64 *g = G + XP_G_H + tid;
             const bool tail = tid < 256;
-            for (uint32_t spins = 0;; spins++) {
+            for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
                 bool ok = true;
 #pragma unroll
                 for (int k = 0; k < NQ; k++) {
@@ -726,8 +807,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     ok &= (uint32_t)(a >> 32) == epoch;
                 }
                 if (__all(ok)) break;
-                if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); break; }
-                if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) etag = 0u; break; }
+                if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -769,7 +850,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
                 const int lr = wave * F2R + lane, row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
-                xp_put(G + XP_G_X + xp_col_slot(row), epoch, __float_as_uint(v));
+                xp_put(G + XP_G_X + xp_col_slot(row), etag, __float_as_uint(v));
                 if (L == p.n_layer - 1) p.x_final[row] = v;
             }
         }
@@ -804,7 +885,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep<4, 256>(p.gran + (size_t)(p.n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+            xp_sweep_q<RES, 4, 256>(p.gran + (size_t)(p.n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, etag);
             xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
         ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
@@ -827,7 +908,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (row < p.n_vocab) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
                 p.logits[row] = v;
-                if (p.logits_host) p.logits_host[row] = v;
+                if constexpr (RES) s_S[row - row0] = v;        // staged for the host copy below (s_S: no attention runs in this workgroup now)
+                else if (p.logits_host) p.logits_host[row] = v;
                 best_val = v; best_idx = row;
             }
         }
@@ -840,7 +922,26 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
         if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
-        __syncthreads();
+        bool row_ok = true;
+        if constexpr (RES) row_ok = __syncthreads_and(etag != 0u);
+        else __syncthreads();
+        // the host's copy of the row (biogpt_eval's output): wave 1 writes the workgroup's 256 logits as ONE kilobyte of 16-byte write-through stores
+        // (four-byte stores from the finisher lanes were one PCIe write each: 42 k per token); a resident launch follows them with the workgroup's
+        // completion word for this token -- same wave, behind its own stores (the host collects one word per lm_head workgroup)
+        if (RES && p.logits_host && wave == 1 && row_ok) {
+            const int r = row0 + 4 * lane;
+            if (p.res_dbg & 4) {
+            } else if (r + 3 < p.n_vocab) {
+                const xp_v4f v4 = *reinterpret_cast<const xp_v4f *>(s_S + 4 * lane);
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p.logits_host + r), "v"(v4) : "memory");
+            } else {
+                for (int j = r; j < p.n_vocab; j++) __hip_atomic_store(p.logits_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (p.resident != 0) {
+                if (!(p.res_dbg & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         if (tid < 4) {
             float bv = s_redf[tid * NW];
             int bi = s_redi[tid * NW];
@@ -854,8 +955,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (blk < p.lm_blocks) {
                 p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi;
                 if (tk + 1 < p.n_tok) {        // the sampler of the next token runs on XCD 0
-                    xp_put(p.samp + blk, epoch, __float_as_uint(bv));
-                    xp_put(p.samp + 1024 + blk, epoch, (uint32_t)bi);
+                    xp_put(p.samp + blk, etag, __float_as_uint(bv));
+                    xp_put(p.samp + 1024 + blk, etag, (uint32_t)bi);
                 }
             }
         }
@@ -875,7 +976,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     }
 }
 
-template <int WT, int LPK, int NW, int KCAP, bool SPLIT>
+template <int WT, int LPK, int NW, int KCAP, bool SPLIT, bool RES = false>
 __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "Q8_0 (9 registers per weight unit) runs with split layers");
@@ -922,7 +1023,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
+    const int n_past0 = (RES && p.resident != 0) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
     const int t_cap = p.t_cap;
 
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
@@ -934,10 +1035,10 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
     }
     if constexpr (SPLIT) {
-        if (xcd & 1) { xp_run<WT, LPK, NW, KCAP, 2, true>(p, smem, xcd, slot, epoch0, n_past0, n_gen0); return; }
+        if (xcd & 1) { xp_run<WT, LPK, NW, KCAP, 2, true, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0); return; }
     }
-    if (slot < 16) xp_run<WT, LPK, NW, KCAP, 0, SPLIT>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
-    else xp_run<WT, LPK, NW, KCAP, 1, SPLIT>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    if (slot < 16) xp_run<WT, LPK, NW, KCAP, 0, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    else xp_run<WT, LPK, NW, KCAP, 1, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
 }
 
 // where workgroup b of a 256-workgroup launch runs: the host checks b % 8 once per device before it trusts the pipeline

@@ -1,6 +1,6 @@
 // Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys; kernels_xlong.hip.h: 257 .. 1024
-// keys): 5 block formats x (4 + 2) context variants = 30 persistent kernels, compiled apart from engine.hip so that the two build in
-// parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
+// keys): 5 block formats x (4 + 2 long-context) variants = 30 persistent kernels here, the 20 resident ones in xpipe_res_tu.hip, compiled apart from
+// engine.hip so that the three build in parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
 // parameter block crosses the boundary as bytes (same header, same layout; the size is checked).
 #define bgk bgk_xp
 #include <hip/hip_runtime.h>
@@ -10,12 +10,16 @@
 
 #include "kernels_xlong.hip.h"
 
+extern "C" int bg_xpipe_launch_resident(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
+extern "C" int bg_xpipe_set_lds_resident(int wt, size_t smem_bytes);
+
 namespace {
 
 template <int WT>
 hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &xp) {
     // 8 waves per workgroup: 14-16 weight units per lane, unpacked to 9 registers each, + the head's old keys / values (<= 256 keys) or this
     // workgroup's key range of the next layer (beyond) fit the 256-register budget
+    if (xp.resident != 0) return (hipError_t)bg_xpipe_launch_resident(WT, t_cap, sm, st, &xp, sizeof(xp));      // its own translation unit (xpipe_res_tu.hip)
     if (t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), dim3(256), dim3(512), sm, st, xp);   // 24 instead of 32 value registers
@@ -28,6 +32,7 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
 
 template <int WT>
 hipError_t set_lds_t(size_t sm) {
+    if (bg_xpipe_set_lds_resident(WT, sm) != (int)hipSuccess) return hipErrorInvalidValue;
     const void *fns[6] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
                           reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>),
                           reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 32>), reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 64>)};

@@ -140,6 +140,14 @@ int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
                     float *logits_out);
 
+/* biogpt_eval (biogpt.cpp:812-847) without the final copy: *row_out points at the context's pinned host buffer that the launch
+ * itself wrote the n_vocab logits of the last token into (valid until the next call on this context).  A loop of single-token calls
+ * (main.cpp:91-151) -- through this entry or biogpt_hip_eval -- is served by ONE pipelined launch that stays on the device between
+ * the calls and takes each next token from a pinned mailbox; it leaves the device after BIOGPT_HIP_RESIDENT_US
+ * (default 1000) microseconds without a call, or as soon as the context is asked to do anything else. */
+int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
+                            const float **row_out);
+
 /* Same pass, logits stay in HBM (no PCIe); biogpt_hip_logits_device() returns the device pointer
  * to the n_vocab floats of the last evaluated token.  eval_device is asynchronous on the
  * context's stream; biogpt_hip_synchronize() waits for it. */

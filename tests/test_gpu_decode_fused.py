@@ -489,12 +489,20 @@ def test_pipeline_slot_is_handed_back_and_replicas_reload(pkg, oracle, files):
         got_b, sb = b.generate_greedy(pb, n_predict=40, n_batch=8)
         assert list(got_a) == list(want_a) and list(got_b) == list(want_b)
     # an un-synchronised pipelined eval of `a` keeps the slot: `b` runs that call on the five-launch layer, same logits
-    lb_ref = b.eval([11], 5)
+    lb_ref = b.eval([11], 5)               # (leaves b's resident launch on the device: b holds the slot until that launch has left)
+    b.synchronize()
     a.eval_device([12], 4)
     assert b.xpipe_state() in (0, 1)
     assert (b.eval([11], 5) == lb_ref).all()
-    a.synchronize()
+    a.synchronize(); b.synchronize()
     assert a.xpipe_state() == 1 and b.xpipe_state() == 1
+    # a holder that is outside every call with nothing in flight (its resident launch left after its idle time) is relieved by the next context that asks
+    la = a.eval([12], 4)
+    import time
+    time.sleep(0.01)
+    ids_b2, _ = b.generate_greedy(pb, n_predict=40, n_batch=8)
+    assert list(ids_b2) == list(want_b) and b.xpipe_state() == 1
+    assert (a.eval([12], 4) == la).all()
     a.close(); b.close()
     for _ in range(2):
         r = pkg.Replicas(files["q4_0"], [0])

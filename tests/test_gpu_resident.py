@@ -1,0 +1,151 @@
+"""Resident single-token evals (csrc/engine.hip resident_eval, kernels_xpipe.hip.h resident mode): biogpt_hip_eval with one token keeps the
+pipelined launch on the device and feeds the next call's token through a pinned mailbox (replaces the per-call launch of biogpt_eval,
+biogpt.cpp:812-847, in the caller's loop main.cpp:91-151).  Everything here compares with the same calls with BIOGPT_HIP_RESIDENT=0 and with
+the oracle."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(n_vocab=42384, n_layer=3, n_head=16, n_positions=1024, d_ff=4096, d_model=1024, n_merges=40000)
+
+
+@pytest.fixture(scope="module")
+def files(pkg, tmp_path_factory):
+    d = tmp_path_factory.mktemp("resident")
+    f32 = str(d / "f32.bin")
+    pkg.write_synthetic(f32, seed=77, **KW)
+    out = {}
+    for name in ("q4_0", "q5_1", "q8_0"):
+        out[name] = str(d / (name + ".bin"))
+        pkg.quantize_file(f32, out[name], name)
+    os.remove(f32)
+    return out
+
+
+def _plain(pkg, path, monkeypatch):
+    monkeypatch.setenv("BIOGPT_HIP_RESIDENT", "0")
+    g = pkg.BiogptModel.load(path)
+    monkeypatch.delenv("BIOGPT_HIP_RESIDENT")
+    return g
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_resident_eval_loop_equals_per_call_launches_and_the_oracle(pkg, oracle, files, monkeypatch, name):
+    """The reference's loop: a prompt chunk, then one biogpt_eval per token with greedy sampling on the host, 300 tokens (through the 64 / 128 /
+    192 / 256-key launches and past 256 keys, where the per-call path takes over): every logits row identical to the per-call launches', ids and
+    the first 40 rows against the oracle."""
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    u = _plain(pkg, files[name], monkeypatch)
+    o = oracle.OracleModel(files[name], n_threads=16)
+    prompt = [2, 900, 17, 4211, 8]
+    lg, lu, lo = g.eval(prompt, 0), u.eval(prompt, 0), o.eval(prompt, 0)
+    assert (lg == lu).all()
+    n_past = len(prompt)
+    for k in range(300):
+        tok = int(lg.argmax())
+        assert tok == int(lu.argmax())
+        lg, lu = g.eval([tok], n_past), u.eval([tok], n_past)
+        assert (lg == lu).all(), "%s: resident row != per-call row at n_past %d (max diff %g)" % (name, n_past, np.abs(lg - lu).max())
+        if k < 40:
+            lo = o.eval([tok], n_past)
+            assert np.abs(lg - lo).max() <= 1e-3 and int(lg.argmax()) == int(lo.argmax())
+        n_past += 1
+    assert g.xpipe_state() == 1
+    g.close(); u.close()
+
+
+def test_resident_launch_yields_to_every_other_call(pkg, oracle, files, monkeypatch):
+    """Between single-token evals: K / V read-back, a device-side eval, a prompt chunk, re-evaluation of an earlier position, an idle pause longer
+    than the launch waits (BIOGPT_HIP_RESIDENT_US), generate_greedy and a second context's work -- each must end the resident launch cleanly
+    and every row must equal the per-call path's."""
+    monkeypatch.setenv("BIOGPT_HIP_RESIDENT_US", "300")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_RESIDENT_US")
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    u = _plain(pkg, files["q4_0"], monkeypatch)
+    rng = np.random.default_rng(5)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 80)]
+
+    def both(chunk, n_past):
+        a, b = g.eval(chunk, n_past), u.eval(chunk, n_past)
+        assert (a == b).all(), (len(chunk), n_past, float(np.abs(a - b).max()))
+        return a
+
+    both(toks[:8], 0)
+    n_past = 8
+    for step in range(60):
+        both([toks[n_past]], n_past)
+        n_past += 1
+        if step == 5:
+            ka = g.read_kv(0, 3 * KW["d_model"], KW["d_model"]); kb = u.read_kv(0, 3 * KW["d_model"], KW["d_model"])
+            assert (ka == kb).all()
+        if step == 9:
+            g.eval_device([toks[n_past]], n_past); u.eval_device([toks[n_past]], n_past); n_past += 1
+            g.synchronize(); u.synchronize()
+        if step == 14:
+            both(toks[n_past:n_past + 3], n_past); n_past += 3
+        if step == 20:
+            both([toks[10]], 10)                        # back to an earlier position, then on from where we were
+        if step == 25:
+            time.sleep(0.02)                            # the launch gives up waiting after 300 us
+        if step == 30:
+            time.sleep(0.0004)                          # right around the time-out: whichever way the race goes, the row must be right
+        if step == 35:
+            va, ia = g.eval_topk([toks[n_past]], n_past, 5); vb, ib = u.eval_topk([toks[n_past]], n_past, 5)
+            assert list(ia) == list(ib) and (va == vb).all()
+            n_past += 1
+    # a second context working while the first one's resident launch is (or was just) on the device
+    v = pkg.BiogptModel.load(files["q5_1"])
+    both([toks[n_past]], n_past); n_past += 1
+    ids_v, _ = v.generate_greedy([2, 5, 6], 20, n_batch=8)
+    both([toks[n_past]], n_past); n_past += 1
+    ref, _ = oracle.OracleModel(files["q5_1"], n_threads=16).generate_greedy([2, 5, 6], 20, n_batch=8)
+    assert list(ids_v) == list(ref)
+    ids_g, _ = g.generate_greedy(toks[:6], 30, n_batch=8)
+    ids_u, _ = u.generate_greedy(toks[:6], 30, n_batch=8)
+    assert list(ids_g) == list(ids_u)
+    assert g.xpipe_state() == 1
+    v.close(); g.close(); u.close()
+
+
+def test_resident_race_with_the_idle_timeout(pkg, files, monkeypatch):
+    """Pauses swept across the launch's idle limit (100 us): the next call either finds the launch still waiting or finds it gone -- 400 tokens,
+    every row equal to the per-call path's (a stale or half-written row would show)."""
+    monkeypatch.setenv("BIOGPT_HIP_RESIDENT_US", "100")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_RESIDENT_US")
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    u = _plain(pkg, files["q4_0"], monkeypatch)
+    prompt = [2, 31, 41, 59]
+    la, lb = g.eval(prompt, 0), u.eval(prompt, 0)
+    n_past = 4
+    for k in range(200):
+        tok = int(la.argmax())
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < (k % 40) * 5e-6:      # 0 .. 195 us
+            pass
+        la, lb = g.eval([tok], n_past), u.eval([tok], n_past)
+        assert (la == lb).all(), (k, n_past)
+        n_past += 1
+    g.close(); u.close()
+
+
+def test_api_loop_through_the_resident_launch(pkg, oracle, files):
+    """biogpt_hip_bench_api_loop (the C++ form of main.cpp's loop: biogpt_hip_eval per token, host arg-max) == the device-resident loop == oracle."""
+    g = pkg.BiogptModel.load(files["q8_0"])
+    prompt = [2, 11, 12, 13]
+    ids, secs = g.bench_api_loop(prompt, 120, 0)
+    dev, _ = g.generate_greedy(prompt, 120, n_batch=8)
+    assert list(ids) == list(dev)
+    ref, _ = oracle.OracleModel(files["q8_0"], n_threads=16).generate_greedy(prompt, 40, n_batch=8)
+    assert list(ids[:40]) == list(ref)
+    print("api loop: %.0f tok/s" % (120 / secs))
+    g.close()
