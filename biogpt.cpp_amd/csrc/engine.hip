@@ -30,6 +30,7 @@
 #include "kernels_fast.hip.h"
 #include "kernels_mfma.hip.h"
 #include "kernels_decode.hip.h"
+#include "kernels_fdecode.hip.h"
 #include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
 #include "kernels_quant.hip.h"
 #include "model_file.h"
@@ -168,7 +169,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, no_fdec;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -178,6 +179,7 @@ struct EngineOptions {
         fast_steps = get("BIOGPT_HIP_FAST_STEPS", 1);
         no_fast = get("BIOGPT_HIP_NO_FAST", 0);
         no_chain = get("BIOGPT_HIP_NO_CHAIN", 0);
+        no_fdec = get("BIOGPT_HIP_NO_FDEC", 0);             // 1: float-weight decode mat-vecs on the generic kernel (A/B arm of kernels_fdecode.hip.h)
         mfma_min_cols = get("BIOGPT_HIP_MFMA_MIN_COLS", -1);      // -1: measured cross-overs (48 decode columns / 64 prompt columns)
         attn_group_min = get("BIOGPT_HIP_ATTN_GROUP_MIN", 80);
         split_min = get("BIOGPT_HIP_SPLIT_MIN", 256);
@@ -491,12 +493,35 @@ hipError_t launch_chain(ChainOp op, const bgk::MatvecParams &p, hipStream_t st, 
 }
 hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_w, size_t ln_b, int q81, hipStream_t st);
 
+// ---- float weights, one column, BioGPT-base shapes (kernels_fdecode.hip.h): the whole matrix requested at t = 0 --------------------
+template <int WT, int PRO, int EPI>
+bool try_launch_fdec(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err) {
+    if constexpr (EPI == bgk::EPI_LOGITS || EPI == bgk::EPI_GELU_Q8 || PRO == bgk::PRO_Q8IN) {
+        return false;
+    } else {
+        if (p.N != 1 || opt().no_fast || opt().no_fdec || p.seq != nullptr || (p.dbg & 0xff) != 0) return false;
+        const int K = p.W.K, M = p.W.M;
+        if (EPI == bgk::EPI_QKV && (p.D != K || p.dk <= 0)) return false;
+        if (K == 1024 && M == 3072 && PRO == bgk::PRO_LN && EPI == bgk::EPI_QKV) hipLaunchKernelGGL((bgk::fdec_kernel<WT, PRO, EPI, 1024, 3>), dim3(256), dim3(256), 0, st, p);
+        else if (K == 1024 && M == 4096 && PRO == bgk::PRO_LN && EPI == bgk::EPI_GELU) hipLaunchKernelGGL((bgk::fdec_kernel<WT, PRO, EPI, 1024, 4>), dim3(256), dim3(256), 0, st, p);
+        else if (K == 1024 && M == 1024 && PRO == bgk::PRO_PLAIN && EPI == bgk::EPI_RESID) hipLaunchKernelGGL((bgk::fdec_kernel<WT, PRO, EPI, 1024, 1>), dim3(256), dim3(256), 0, st, p);
+        else if (K == 4096 && M == 1024 && PRO == bgk::PRO_PLAIN && EPI == bgk::EPI_RESID) {
+            if constexpr (PRO == bgk::PRO_PLAIN) hipLaunchKernelGGL((bgk::fdec_kernel<WT, PRO, EPI, 4096, 1>), dim3(256), dim3(256), 0, st, p);
+        } else return false;
+        err = hipGetLastError();
+        return true;
+    }
+}
+
 template <int WT, int PRO, int EPI>
 hipError_t launch_mv_typed(const bgk::MatvecParams &p, const MvShape &s, hipStream_t st, int *grid_out) {
     if (grid_out) *grid_out = s.grid;
     if constexpr (bgk::TypeInfo<WT>::quant) {
         hipError_t err = hipSuccess;
         if (try_launch_fast<WT, PRO, EPI>(p, st, err, grid_out)) return err;
+    } else {
+        hipError_t err = hipSuccess;
+        if (try_launch_fdec<WT, PRO, EPI>(p, st, err)) return err;
     }
     return launch_mv_nc<WT, PRO, EPI>(p, s, st);
 }

@@ -317,3 +317,47 @@ def test_batched_prompts_travel_together(pkg, oracle, files, monkeypatch, name, 
         ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompts[s], 6, n_batch=4)
         assert list(ids[s]) == list(ref), (name, cols, s, lens[s])
     g.close()
+
+
+@pytest.mark.parametrize("name", ["f32", "f16"])
+def test_float_weight_decode_kernels(pkg, oracle, files, tmp_path_factory, monkeypatch, name):
+    """F32 / F16 files (biogpt.cpp:160-165) at BioGPT-base shapes: the single-token mat-vecs of csrc/kernels_fdecode.hip.h (whole matrix
+    requested at once, one workgroup per compute unit) against the generic kernel they replace (BIOGPT_HIP_NO_FDEC=1: bit-identical logits
+    and K / V rows) and the oracle (1e-3, north_star), single-token steps at short and long contexts + a greedy continuation."""
+    path = files["f32"]
+    if name == "f16":
+        path = str(tmp_path_factory.mktemp("f16") / "f16.bin")
+        pkg.write_synthetic(path, ftype=1, **KW)
+    g = pkg.BiogptModel.load(path)
+    monkeypatch.setenv("BIOGPT_HIP_NO_FDEC", "1")
+    u = pkg.BiogptModel.load(path)
+    monkeypatch.delenv("BIOGPT_HIP_NO_FDEC")
+    o = oracle.OracleModel(path, n_threads=16)
+    rng = np.random.default_rng(3)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 300)]
+    checked = [0, 1, 8, 9, 63, 64, 255, 256, 299]
+    n_past, worst = 0, 0.0
+    while n_past <= checked[-1]:
+        if n_past in checked:
+            lg, lu, lo = g.eval([toks[n_past]], n_past), u.eval([toks[n_past]], n_past), o.eval([toks[n_past]], n_past)
+            assert (lg == lu).all(), "%s: fdec != generic at n_past %d (max diff %g)" % (name, n_past, np.abs(lg - lu).max())
+            kg = g.read_kv(0, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"])
+            ku = u.read_kv(0, ((KW["n_layer"] - 1) * KW["n_positions"] + n_past) * KW["d_model"], KW["d_model"])
+            assert (kg == ku).all()
+            worst = max(worst, float(np.abs(lg - lo).max()))
+            assert int(lg.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            g.eval_device(chunk, n_past); u.eval_device(chunk, n_past); o.eval(chunk, n_past)
+            n_past += m
+    print("%s: float-weight decode kernels worst |diff| vs oracle %.2e" % (name, worst))
+    assert worst <= ATOL
+    ids_g, _ = g.generate_greedy(toks[:5], 40, n_batch=8)
+    ids_u, _ = u.generate_greedy(toks[:5], 40, n_batch=8)
+    ref, _ = oracle.OracleModel(path, n_threads=16).generate_greedy(toks[:5], 40, n_batch=8)
+    assert list(ids_g) == list(ids_u) == list(ref)
+    g.close(); u.close()
