@@ -314,56 +314,77 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         // the lm_head's 16 would not fit)
         Unit<WT> wqkv[FIRST && ROLE == 0 ? QS : 1], wo[FIRST ? OS : 1], w1[SECOND ? FS : 1], w2[SECOND ? F2R : 1][2];
         // ---- the weights of own layer L into registers (unpacked there while they wait), its small vectors into LDS ----
-        auto load_unit_weights = [&](const int L) __attribute__((always_inline)) {
+        // part -1: the whole unit (a token's first own layer).  Parts 0 / 1 / 2: a third of it each -- the next own layer's weights are fetched in the idle time
+        // behind the three helper duties in between (32 KB of key / value rows + <= 110 KB of weights per compute unit each time), never right behind the own
+        // stages: a unit's 164 (Q4_0) .. 295 KB (Q8_0) occupy the compute unit's memory pipeline for 7 .. 12 us, and every poll of the next layer's helper duty
+        // issued behind them waits -- on the chain of a layer this XCD does not even own (measured: 15.3 us per layer, Q8_0 19)
+        auto load_unit_weights = [&](const int L, const int part) __attribute__((always_inline)) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
             const XpLayer &Y = p.layers[L];
-            float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
-            if (worker) {
-                if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
-                else { l0 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
+            auto sel = [&](const int unit) -> bool {      // ROLE 0: units 0-11 q/k/v, 12-13 out_proj; ROLE 1: 12-13; ROLE 2: 0-7 fc1, 8 + 2 r + it fc2
+                if (part < 0) return true;
+                if (ROLE == 2) return part == 0 ? (unit < 4 || (unit >> 1) == 4) : part == 1 ? ((unit >= 4 && unit < 8) || (unit >> 1) == 5) : unit >= 12;
+                return part == 0 ? unit < 5 : part == 1 ? (unit >= 5 && unit < 10) : unit >= 10;
+            };
+            if (part <= 0) {      // the small vectors travel with the first part
+                float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
+                if (worker) {
+                    if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
+                    else { l0 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
+                }
+                float bv = 0.0f;
+                if (tid < 192) { if (ROLE == 0) bv = Y.bqkv[(tid >> 6) * 1024 + slot * 64 + (tid & 63)]; }
+                else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
+                else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
+                else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
+                if (worker) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
+                if (tid < 384) s_bias[tid] = bv;
             }
-            float bv = 0.0f;
-            if (tid < 192) { if (ROLE == 0) bv = Y.bqkv[(tid >> 6) * 1024 + slot * 64 + (tid & 63)]; }
-            else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
-            else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
-            else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
             if constexpr (ROLE == 0) {
 #pragma unroll
                 for (int s = 0; s < QS; s++) {
                     const int jj = s * 2 * NW + wave * 2 + rsub;
-                    load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + slot * 64 + (jj & 63)) * 32 + sub);
+                    if (sel(s)) load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + slot * 64 + (jj & 63)) * 32 + sub);
                 }
             }
             if constexpr (FIRST) {
 #pragma unroll
-                for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < OS; s++)
+                    if (sel(12 + s)) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
             }
             if constexpr (SECOND) {
 #pragma unroll
-                for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < FS; s++)
+                    if (sel(s)) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
 #pragma unroll
                 for (int r = 0; r < F2R; r++)
 #pragma unroll
-                    for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+                    for (int it = 0; it < 2; it++)
+                        if (sel(8 + 2 * r + it)) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
             }
-            if (worker) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
-            if (tid < 384) s_bias[tid] = bv;
+            // unpacked right here: the wait for the loads falls into this workgroup's idle time
             if constexpr (ROLE == 0) {
 #pragma unroll
-                for (int s = 0; s < QS; s++) xp_settle<WT, true>(wqkv[s]);
+                for (int s = 0; s < QS; s++)
+                    if (sel(s)) xp_settle<WT, true>(wqkv[s]);
             }
             if constexpr (FIRST) {
 #pragma unroll
-                for (int s = 0; s < OS; s++) xp_settle<WT, true>(wo[s]);
+                for (int s = 0; s < OS; s++)
+                    if (sel(12 + s)) xp_settle<WT, true>(wo[s]);
             }
             if constexpr (SECOND) {
 #pragma unroll
-                for (int s = 0; s < FS; s++) xp_settle<WT, true>(w1[s]);
+                for (int s = 0; s < FS; s++)
+                    if (sel(s)) xp_settle<WT, true>(w1[s]);
 #pragma unroll
-                for (int r = 0; r < F2R; r++) { xp_settle<WT, true>(w2[r][0]); xp_settle<WT, true>(w2[r][1]); }
+                for (int r = 0; r < F2R; r++)
+#pragma unroll
+                    for (int it = 0; it < 2; it++)
+                        if (sel(8 + 2 * r + it)) xp_settle<WT, true>(w2[r][it]);
             }
         };
 
@@ -529,7 +550,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (L + 1 < n_layer) fetch_kv(L + 1, n_past);      // deferred from the helper duty (see there)
                     else if (more) fetch_kv(0, n_past + 1);
                     __syncthreads();       // s_ln / s_bias are rewritten by the next unit's load
-                    if (L + 4 < n_layer) load_unit_weights(L + 4);
                 }
             }
             if constexpr (SECOND) {
@@ -651,7 +671,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     }
                     XL_WALL2(5);
                     __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit's load
-                    if (L + 4 < n_layer) load_unit_weights(L + 4);
                 }
             }
         };
@@ -661,13 +680,21 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         const int l_pre = (my_last < 0) ? n_layer : ((tk == 0) ? (my_l0 > 0 ? my_l0 - 1 : 0) : 0);
         for (int L = 0; L < l_pre; L++) helper(L, epoch, n_past, false, more);
         if (my_last >= 0) {
-            load_unit_weights(my_l0);
-            // ---- walk 2: up to the last own layer ----
-            for (int L = l_pre; L <= my_last; L++) {
-                const bool own = (L & 3) == my_l0;
-                if (FIRST && own) stage_pre(L);
-                helper(L, epoch, n_past, own && FIRST, more);
-                if (own) stage_post(L);
+            load_unit_weights(my_l0, -1);
+            for (int L = l_pre; L < my_l0; L++) helper(L, epoch, n_past, false, more);
+            // ---- walk 2: own layer, then the three layers up to the next own one -- behind each of their helper duties a third of that layer's weights ----
+            for (int Lo = my_l0; Lo <= my_last; Lo += 4) {
+                if (FIRST) stage_pre(Lo);
+                helper(Lo, epoch, n_past, FIRST, more);
+                stage_post(Lo);
+                if (Lo < my_last) {
+                    helper(Lo + 1, epoch, n_past, false, more);
+                    load_unit_weights(Lo + 4, 0);
+                    helper(Lo + 2, epoch, n_past, false, more);
+                    load_unit_weights(Lo + 4, 1);
+                    helper(Lo + 3, epoch, n_past, false, more);
+                    load_unit_weights(Lo + 4, 2);
+                }
             }
         }
         // ---- final LayerNorm + lm_head (biogpt.cpp:799-811) on the XCDs that are done: four 64-row blocks per workgroup, loaded now, used when the
