@@ -286,6 +286,7 @@ struct biogpt_hip_ctx {
     int32_t *mbox_host = nullptr;          // pinned ring of 64 x {n_past, causal, token}: inputs of the graph-replayed single-token evals
     uint32_t *mbox_ctr = nullptr;          // device: replays consumed
     uint32_t mbox_sent = 0, mbox_synced = 0;
+    int unsynced_from = -1;                // position of the first single-token eval enqueued since the stream was last synchronised (-1: none): what a tripped pipeline may have spoiled
     int lm_blocks = 0;
     // resident single-token evals (biogpt_hip_eval): a pipelined launch that is still on the device, fed through res_mbox
     int32_t *res_mbox = nullptr;           // pinned ring of 64 x {n_past, causal, token, seq}
@@ -768,7 +769,7 @@ void xpipe_handback(biogpt_hip_ctx *c) {
 // outputs of that call are garbage: report it, drop the captured graphs and never use the path again in this context.
 bool xpipe_check(biogpt_hip_ctx *c) {
     xpipe_handback(c);
-    if (!c->xp_err_host || *c->xp_err_host == 0u) return true;
+    if (!c->xp_err_host || *c->xp_err_host == 0u) { c->unsynced_from = -1; return true; }
     const uint32_t code = *c->xp_err_host;
     if (code == bgk::XP_QUIT) {     // a resident launch left on its own (idle) or on request: not a failure; the device-side word is cleared in stream order
         *c->xp_err_host = 0u;
@@ -1533,6 +1534,15 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     for (auto &pl : ctx->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     for (auto &g : ctx->graph_batch) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     ctx->graph_batch_n = 0;
+    // the pipelined path is rebuilt from the new options (GELU slice, fault hook, long-context buffers) -- which also re-arms a context that had abandoned the
+    // path after a disturbed launch: an explicit call, not an automatic cool-down
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    (void)xpipe_check(ctx);
+    ctx->xp_tripped = false;
+    xpipe_release(ctx);
+    ctx->xp_state = 0; ctx->xp_gelu_p = 0; ctx->xp_gelu_n = 0; ctx->xp_gelu_z = 0;
+    xpipe_prepare(ctx);
     return 0;
 }
 
@@ -1699,6 +1709,7 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
         }
         int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
         slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
+        if (ctx->mbox_sent == ctx->mbox_synced) ctx->unsynced_from = n_past;
         ctx->mbox_sent++;
         for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[pl][form][b][sgi], ctx->stream));
         return 0;
@@ -1815,7 +1826,13 @@ int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
     if (!resident_stop(ctx)) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-    if (!xpipe_check(ctx)) return -2;
+    if (!xpipe_check(ctx)) {      // reported to the caller here: there is no call to repeat, and a later, unrelated failure must not trigger a spurious retry
+        ctx->xp_tripped = false;
+        const int from = ctx->unsynced_from;
+        ctx->unsynced_from = -1;
+        if (from >= 0) BG_FAIL(-2, "the pipelined decode step failed; the evals from position %d on must be repeated (the context now uses the five-launch layer)", from);
+        return -2;
+    }
     return 0;
 }
 
@@ -1970,34 +1987,42 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
 // other streams or processes dispatched in between can break that (the launch then drains with an error word and garbage
 // outputs).  These calls are idempotent for given arguments, so they are simply repeated once on the five-launch layer, which the
 // context keeps from then on.
-static bool xpipe_retry(biogpt_hip_ctx *ctx) {
+// n_past: the position the failed call evaluates.  Earlier asynchronous single-token evals (biogpt_hip_eval_device) that were still in flight went through the same
+// tripped pipeline: their K / V rows are garbage and repeating only THIS call would return wrong logits with rc 0 -- then the caller is told where to resume instead.
+static bool xpipe_retry(biogpt_hip_ctx *ctx, int n_past) {
     if (!ctx || !ctx->xp_tripped) return false;
     ctx->xp_tripped = false;
+    const int from = ctx->unsynced_from;
+    ctx->unsynced_from = -1;
     fprintf(stderr, "biogpt_hip: %s\n", last_error());
+    if (from >= 0 && from < n_past) {
+        bg::set_error("biogpt_hip_eval", "the pipelined decode step failed while evals from position %d on were still in flight: their K / V rows are invalid -- re-evaluate from n_past = %d (the context now uses the five-launch layer)", from, from);
+        return false;
+    }
     return true;
 }
 int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, const float **row_out) {
     if (!row_out) BG_FAIL(-1, "null row pointer");
     int rc = eval_once(ctx, tokens, n, n_past, nullptr);
-    if (rc != 0 && xpipe_retry(ctx)) rc = eval_once(ctx, tokens, n, n_past, nullptr);
+    if (rc != 0 && xpipe_retry(ctx, n_past)) rc = eval_once(ctx, tokens, n, n_past, nullptr);
     *row_out = rc == 0 ? ctx->logits_host : nullptr;
     return rc;
 }
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
     if (!logits_out) BG_FAIL(-1, "null logits buffer");
     int rc = eval_once(ctx, tokens, n, n_past, logits_out);
-    if (rc != 0 && xpipe_retry(ctx)) rc = eval_once(ctx, tokens, n, n_past, logits_out);
+    if (rc != 0 && xpipe_retry(ctx, n_past)) rc = eval_once(ctx, tokens, n, n_past, logits_out);
     return rc;
 }
 int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int32_t k, float *vals_out, int32_t *ids_out) {
     int rc = eval_topk_once(ctx, tokens, n, n_past, k, vals_out, ids_out);
-    if (rc < 0 && xpipe_retry(ctx)) rc = eval_topk_once(ctx, tokens, n, n_past, k, vals_out, ids_out);
+    if (rc < 0 && xpipe_retry(ctx, n_past)) rc = eval_topk_once(ctx, tokens, n, n_past, k, vals_out, ids_out);
     return rc;
 }
 int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_t n_prompt, int32_t n_batch, int32_t n_predict, int32_t *out_ids,
                                double *seconds_out) {
     int rc = generate_greedy_once(ctx, prompt, n_prompt, n_batch, n_predict, out_ids, seconds_out);
-    if (rc < 0 && xpipe_retry(ctx)) rc = generate_greedy_once(ctx, prompt, n_prompt, n_batch, n_predict, out_ids, seconds_out);
+    if (rc < 0 && xpipe_retry(ctx, 0)) rc = generate_greedy_once(ctx, prompt, n_prompt, n_batch, n_predict, out_ids, seconds_out);
     return rc;
 }
 
@@ -2445,6 +2470,16 @@ int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, doubl
         fprintf(stderr, "   %-36s %6.2f   (previous layer's output published -> seen on the next XCD)\n", names[0], hop / n);
         for (int k = 1; k < 16; k++) fprintf(stderr, "   %-36s %6.2f\n", names[k], seg[k] / n);
         fprintf(stderr, "   one layer = %.2f us\n", nl > 1 ? (double)(long long)(w[(size_t)(nl - 1) * 16 + 5] - w[5]) * 0.01 / n : 0.0);
+        {   // the two cross-XCD hops by the XCD they arrive on: x (layer l-1's MLP half on XCD 2l-1 -> layer l's attention half on XCD 2l mod 8), x1 (XCD 2l -> 2l+1)
+            double hx[4] = {}, hx1[4] = {}; int cnt[4] = {};
+            for (int l = 1; l < nl; l++) {
+                hx[l & 3] += (double)(long long)(w[(size_t)l * 16] - w[(size_t)(l - 1) * 16 + 5]) * 0.01;
+                hx1[l & 3] += (double)(long long)(w[(size_t)l * 16 + 9] - w[(size_t)l * 16 + 3]) * 0.01;
+                cnt[l & 3]++;
+            }
+            for (int k = 0; k < 4; k++)
+                if (cnt[k]) fprintf(stderr, "   hops onto XCD %d / %d: x %.2f us (from XCD %d), x1 %.2f us\n", 2 * k, 2 * k + 1, hx[k] / cnt[k], (2 * k + 7) & 7, hx1[k] / cnt[k]);
+        }
         // the last layer, every workgroup of its XCD: us since workgroup 0 saw the layer input
         std::vector<unsigned long long> ws((size_t)32 * 16);
         HIP_TRY(-2, hipMemcpy(ws.data(), ctx->tstamp + (size_t)nl * 16, ws.size() * 8, hipMemcpyDeviceToHost));

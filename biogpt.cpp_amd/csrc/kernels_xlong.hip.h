@@ -492,17 +492,26 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         const float axd = s_xd[sub];
                         const uint32_t axs = s_xs[sub];
                         float *const part = s_part + wave * 2 * QS * DEC_PS;
+                        // the q rows first (units 0-3 = rows 0-63 of the head): all 16 helpers of the head wait for them, the k / v rows are needed by ONE helper and later
 #pragma unroll
-                        for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+                        for (int s = 0; s < 4; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (lane < 2 * QS) {
+                        if (lane < 8) {
+                            const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);      // < 64
+                            const float v = __fmul_rn(__fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS)), p.q_scale);      // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                            xp_put(G + XP_G_QKV + slot * 64 + jj, epoch, __float_as_uint(v));
+                        }
+#pragma unroll
+                        for (int s = 4; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, true>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane >= 8 && lane < 2 * QS) {
                             const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
-                            float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
-                            const int which = jj >> 6, d = jj & 63;
-                            if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
-                            xp_put(G + XP_G_QKV + which * 1024 + slot * 64 + d, epoch, __float_as_uint(v));
+                            const float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
+                            xp_put(G + XP_G_QKV + (jj >> 6) * 1024 + slot * 64 + (jj & 63), epoch, __float_as_uint(v));
                         }
                         XL_WALL(1);
                     }
@@ -705,21 +714,33 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         } else {
             Unit<WT> wl[LMS];
             const int row0 = lm_rank * 256;
+            // the lm_head rows in thirds, behind the (up to three) helper duties that are left -- like the unit weights, never right behind the own stages
+            auto load_lm = [&](const int s0, const int s1) __attribute__((always_inline)) {
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+#pragma unroll
+                for (int s = 0; s < LMS; s++) {
+                    if (s < s0 || s >= s1) continue;
+                    const int row = row0 + s * 2 * NW + wave * 2 + rsub;
+                    if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
+                    else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
+                }
+#pragma unroll
+                for (int s = 0; s < LMS; s++)
+                    if (s >= s0 && s < s1) xp_settle<WT, true>(wl[s]);
+            };
+            // ---- walk 3 with the lm_head rows arriving ----
             {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
-#pragma unroll
-            for (int s = 0; s < LMS; s++) {
-                const int row = row0 + s * 2 * NW + wave * 2 + rsub;
-                if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
-                else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
+                int L = (my_last < 0 ? n_layer : my_last + 1);
+                for (; L + 3 < n_layer; L++) helper(L, epoch, n_past, false, more);
+                if (L < n_layer) { helper(L, epoch, n_past, false, more); L++; }
+                load_lm(0, 6);
+                if (L < n_layer) { helper(L, epoch, n_past, false, more); L++; }
+                load_lm(6, 11);
+                if (L < n_layer) { helper(L, epoch, n_past, false, more); L++; }
+                load_lm(11, LMS);
             }
-#pragma unroll
-            for (int s = 0; s < LMS; s++) xp_settle<WT, true>(wl[s]);
-        }
-            // ---- walk 3 with the lm_head rows in registers ----
-            for (int L = (my_last < 0 ? n_layer : my_last + 1); L < n_layer; L++) helper(L, epoch, n_past, false, more);
             {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
