@@ -576,3 +576,25 @@ def test_xlong_generation_in_multi_token_launches(pkg, oracle, files10, monkeypa
     ids_o, _ = oracle.OracleModel(files10[name], n_threads=16).generate_greedy(prompt, n_predict=24, n_batch=8)
     assert list(ids_p[:24]) == list(ids_o)
     g.close()
+
+
+def test_tripped_pipeline_with_evals_in_flight_says_where_to_resume(pkg, files, monkeypatch):
+    """A pipelined launch that is disturbed while EARLIER asynchronous single-token evals are still in flight has spoiled their K / V rows too: the synchronising
+    call must not silently repeat only itself -- it fails and names the position to resume from; resuming there gives the undisturbed logits."""
+    ref = pkg.BiogptModel.load(files["q4_0"])
+    if ref.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 100, 200, 300]
+    ref.eval_device(prompt, 0); ref.eval_device([7], 4); want = ref.eval([8], 5)
+    ref.close()
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    g.eval_device(prompt, 0)
+    g.eval_device([7], 4)                     # pipelined, not synchronised: drains with garbage rows
+    with pytest.raises(pkg.BiogptError, match="n_past = 4"):
+        g.eval([8], 5)
+    assert g.xpipe_state() == -1
+    g.eval_device([7], 4)                     # resume where told, now on the five-launch layer
+    assert (g.eval([8], 5) == want).all()
+    g.close()
