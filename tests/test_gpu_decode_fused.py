@@ -598,3 +598,46 @@ def test_tripped_pipeline_with_evals_in_flight_says_where_to_resume(pkg, files, 
     g.eval_device([7], 4)                     # resume where told, now on the five-launch layer
     assert (g.eval([8], 5) == want).all()
     g.close()
+
+
+def test_xlong_with_a_position_table_that_is_no_multiple_of_the_key_ranges(pkg, oracle, tmp_path, monkeypatch):
+    """n_positions = 600 (biogpt.h:25-35 allows any): the 513 .. 600-key bucket runs the 64-key-range variant with its last ranges cut off at the table's end,
+    the 257 .. 512 bucket the 32-key one; 2 layers (every XCD beyond the fourth owns no unit and is a pure helper + lm_head workgroup), vocabulary 5000."""
+    kw = dict(KW, n_layer=2, n_positions=600, n_vocab=5000, n_merges=100)
+    f32, q = str(tmp_path / "f32.bin"), str(tmp_path / "q5_0.bin")
+    pkg.write_synthetic(f32, seed=600, **kw)
+    pkg.quantize_file(f32, q, "q5_0")
+    g = pkg.BiogptModel.load(q)
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    o = oracle.OracleModel(q, n_threads=16)
+    rng = np.random.default_rng(6)
+    toks = [2] + [int(v) for v in rng.integers(4, kw["n_vocab"], 599)]
+    checked = [256, 300, 511, 512, 575, 576, 598, 599]
+    n_past = 0
+    mp = monkeypatch
+    if True:
+        while n_past <= checked[-1]:
+            if n_past in checked:
+                _with_xpipe(g, mp, True)
+                lp = g.eval([toks[n_past]], n_past)
+                assert g.xpipe_state() == 1
+                _with_xpipe(g, mp, False)
+                lf = g.eval([toks[n_past]], n_past)
+                lo = o.eval([toks[n_past]], n_past)
+                assert (lp == lf).all(), n_past
+                assert np.abs(lp - lo).max() <= ATOL and int(lp.argmax()) == int(lo.argmax())
+                n_past += 1
+            else:
+                m = 1
+                while (n_past + m) not in checked and m < 8:
+                    m += 1
+                g.eval_device(toks[n_past:n_past + m], n_past); g.synchronize(); o.eval(toks[n_past:n_past + m], n_past)
+                n_past += m
+        _with_xpipe(g, mp, True)
+        ids_p, _ = g.generate_greedy(toks[:250], 350, n_batch=8)
+        assert g.xpipe_state() == 1
+        _with_xpipe(g, mp, False)
+        ids_f, _ = g.generate_greedy(toks[:250], 350, n_batch=8)
+        assert len(ids_p) == 350 and list(ids_p) == list(ids_f)
+    g.close()
