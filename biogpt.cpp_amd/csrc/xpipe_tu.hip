@@ -1,6 +1,6 @@
-// Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys; kernels_xlong.hip.h: 257 .. 1024
-// keys): 5 block formats x (4 + 2 long-context) variants = 30 persistent kernels here, the 20 resident ones in xpipe_res_tu.hip, compiled apart from
-// engine.hip so that the three build in parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
+// Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys): 5 block formats x 4 context variants = 20
+// persistent kernels here, the 20 resident ones in xpipe_res_tu.hip, the 10 long-context ones (kernels_xlong.hip.h) in xlong_tu.hip, compiled apart from
+// engine.hip so that the four build in parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
 // parameter block crosses the boundary as bytes (same header, same layout; the size is checked).
 #define bgk bgk_xp
 #include <hip/hip_runtime.h>
@@ -8,10 +8,12 @@
 #include <cmath>
 #include <cstdint>
 
-#include "kernels_xlong.hip.h"
+#include "kernels_xpipe.hip.h"
 
 extern "C" int bg_xpipe_launch_resident(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
 extern "C" int bg_xpipe_set_lds_resident(int wt, size_t smem_bytes);
+extern "C" int bg_xpipe_launch_long(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
+extern "C" int bg_xpipe_set_lds_long(int wt, size_t smem_bytes);
 
 namespace {
 
@@ -24,18 +26,15 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), dim3(256), dim3(512), sm, st, xp);   // 24 instead of 32 value registers
     else if (t_cap <= 256) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>), dim3(256), dim3(512), sm, st, xp);
-    else if (xp.gran_l == nullptr || t_cap > 1024) return hipErrorInvalidValue;
-    else if (t_cap <= 512) hipLaunchKernelGGL((bgk::dec_xlong_kernel<WT, 32>), dim3(256), dim3(512), sm, st, xp);
-    else hipLaunchKernelGGL((bgk::dec_xlong_kernel<WT, 64>), dim3(256), dim3(512), sm, st, xp);
+    else return (hipError_t)bg_xpipe_launch_long(WT, t_cap, sm, st, &xp, sizeof(xp));      // beyond 256 keys: xlong_tu.hip
     return hipGetLastError();
 }
 
 template <int WT>
 hipError_t set_lds_t(size_t sm) {
-    if (bg_xpipe_set_lds_resident(WT, sm) != (int)hipSuccess) return hipErrorInvalidValue;
-    const void *fns[6] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>),
-                          reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 32>), reinterpret_cast<const void *>(bgk::dec_xlong_kernel<WT, 64>)};
+    if (bg_xpipe_set_lds_resident(WT, sm) != (int)hipSuccess || bg_xpipe_set_lds_long(WT, sm) != (int)hipSuccess) return hipErrorInvalidValue;
+    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>)};
     for (const void *fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
