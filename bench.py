@@ -304,6 +304,7 @@ def main():
                                    "GBps": round(b / s / 1e9, 1), "frac_of_peak": round(b / s / 1e9 / HBM_PEAK_GBS, 4),
                                    "bytes_per_token": int(b)}
             out["token_roofline"] = tok
+            out["xpipe_state"] = model.xpipe_state()   # 1: the pipelined launches are in use (a hand-off time-out or a disturbed launch would have left -1 and the five-launch layer)
             multi = os.environ.get("BIOGPT_HIP_XPIPE_MULTI", "1") != "0"
             out["decode_path"] = (("xcd-pipeline: layers + lm_head + greedy sampler in ONE persistent launch per context bucket (64 / 128 / 192 / 256 keys: a head's K / V rows in its workgroup's "
                                    "registers; 512 / 1024 keys: every head's keys spread over 16 helper workgroups of XCD head / 2, csrc/kernels_xlong.hip.h)" if multi else
