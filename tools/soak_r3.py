@@ -1,0 +1,41 @@
+"""Round-3 soak (GPU box): for SECONDS (default 120) alternate (a) a 250 -> 1024-key greedy continuation (the long-context pipelined launches, K / V rows appended and re-read
+inside multi-token launches), (b) the C++ api loop through the resident launch (200 tokens, ids), (c) 64 single-token biogpt_hip_eval calls whose full logits rows are
+compared bit for bit with the rows of the first round (a row that reached the host before its completion word would show here).  Any difference, fallback or error fails."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import _pkg
+pkg = _pkg.load()
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+q = os.path.join(os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"), "synthetic-L24-q4_0.bin")
+g = pkg.BiogptModel.load(q, verbosity=0)
+assert g.xpipe_state() == 1, "pipeline not available"
+rng = np.random.default_rng(99)
+long_prompt = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 249)]
+pr = [2, 100, 200, 300]
+want_long = want_api = want_rows = None
+rounds = toks = 0
+slowest = 0.0
+t_end = time.time() + secs
+while time.time() < t_end:
+    t0 = time.time()
+    ids, _ = g.generate_greedy(long_prompt, 1024 - 250, n_batch=8)
+    if want_long is None: want_long = ids.copy()
+    assert (ids == want_long).all(), "long-context ids differ in round %d" % rounds
+    api, _ = g.bench_api_loop(pr, 200, 0)
+    if want_api is None: want_api = api.copy()
+    assert (api == want_api).all(), "api-loop ids differ in round %d" % rounds
+    rows = []
+    lg = g.eval(pr, 0); n_past = 4
+    for k in range(64):
+        t = int(lg.argmax())
+        lg = g.eval([t], n_past); n_past += 1
+        rows.append(lg.copy())
+        if rounds % 2 and k % 16 == 7: time.sleep(0.0015)      # let the resident launch leave now and then
+    rows = np.stack(rows)
+    if want_rows is None: want_rows = rows
+    assert (rows == want_rows).all(), "a logits row differs in round %d" % rounds
+    assert g.xpipe_state() == 1, "the pipeline was abandoned in round %d" % rounds
+    rounds += 1; toks += len(ids) + len(api) + 64
+    slowest = max(slowest, time.time() - t0)
+print("soak ok: %d rounds, %d tokens in %.0f s, slowest round %.3f s, pipeline state %d" % (rounds, toks, secs, slowest, g.xpipe_state()))
