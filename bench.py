@@ -343,7 +343,10 @@ def main():
             dev_ids, _ = model.generate_greedy(pr, n_predict, n_batch=8)
             out["api_loop"] = {"tokens_per_s": round(n_predict / s0, 1), "frac_of_device_loop": round(n_predict / s0 / value, 3),
                                "ids_match_device_loop": bool((np.asarray(ids0) == np.asarray(dev_ids)).all()),
-                               "note": "biogpt_eval per token: 170 KB logits row to the host (PCIe) + host arg-max, C++ loop"}
+                               "speculation": model.resident_stats(),
+                               "note": "biogpt_eval per token: 170 KB logits row to the host (PCIe) + host arg-max (std::max_element), C++ loop; a greedy caller's next "
+                                       "position is started by the resident launch from its own arg-max while the host still reads the row, the call then only confirms the "
+                                       "token (speculation.hits of the calls; BIOGPT_HIP_SPEC=0: eval_only_tokens_per_s below is that rate)"}
             model.bench_api_loop(pr, 8, 3)
             ids3, s3 = model.bench_api_loop(pr, n_predict, 3)
             _, s4 = model.bench_api_loop(pr, n_predict, 4)
@@ -351,7 +354,7 @@ def main():
                                        "ids_match_device_loop": bool((np.asarray(ids3) == np.asarray(dev_ids)).all()),
                                        "eval_only_tokens_per_s": round(n_predict / s4, 1),
                                        "note": "biogpt_hip_eval_inplace per token (the row read where the launch wrote it in pinned host memory) + 8-lane host arg-max, C++ loop; "
-                                               "eval_only: the same calls without the arg-max (token fixed). One resident pipelined launch per context bucket serves the calls "
+                                               "eval_only: the same calls without the arg-max (token fixed: what a caller that samples gets, the launch waits for every token). One resident pipelined launch per context bucket serves the calls "
                                                "(BIOGPT_HIP_RESIDENT=0: one launch per call)"}
             out["api_loop_topk"] = {"tokens_per_s": round(n_predict / s1, 1), "frac_of_device_loop": round(n_predict / s1 / value, 3),
                                     "ids_match_device_loop": bool((np.asarray(ids1) == np.asarray(dev_ids)).all()),

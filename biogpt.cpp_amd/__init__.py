@@ -82,9 +82,11 @@ SYMBOLS = [
     ("biogpt_hip_merge", C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
     ("biogpt_hip_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
+    ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
+    ("biogpt_hip_read_logits", C.c_int, [_P, _P]),
     ("biogpt_hip_synchronize", C.c_int, [_P]),
     ("biogpt_hip_eval_all", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_eval_prompt", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -340,6 +342,20 @@ class BiogptModel:
         toks = np.ascontiguousarray(tokens, dtype=np.int32)
         if lib().biogpt_hip_eval_device(self._h, toks.ctypes.data, toks.size, int(n_past)) != 0:
             raise BiogptError(_err())
+
+    def read_logits(self):
+        """The device-side logits row of the last evaluated token (biogpt_hip_logits_device), copied to host memory."""
+        out = np.empty(self.n_vocab, dtype=np.float32)
+        if lib().biogpt_hip_read_logits(self._h, out.ctypes.data) != 0:
+            raise BiogptError(_err())
+        return out
+
+    def resident_stats(self):
+        """{hits, misses, streak, need} of the resident launch's speculative continuation (biogpt_hip_resident_stats)."""
+        out = (C.c_int64 * 4)()
+        if lib().biogpt_hip_resident_stats(self._h, out) != 0:
+            raise BiogptError(_err())
+        return dict(hits=int(out[0]), misses=int(out[1]), streak=int(out[2]), need=int(out[3]))
 
     def synchronize(self):
         if lib().biogpt_hip_synchronize(self._h) != 0:

@@ -169,7 +169,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, no_fdec;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -199,6 +199,7 @@ struct EngineOptions {
         xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
         resident = get("BIOGPT_HIP_RESIDENT", 1);           // biogpt_hip_eval with one token: the pipelined launch stays on the device and takes the next call's token from a pinned mailbox
         res_dbg = get("BIOGPT_HIP_RES_DBG", 0);              // measurement only (kernels_xpipe.hip.h XpParams::res_dbg)
+        res_spec = get("BIOGPT_HIP_SPEC", 1);                // a resident launch may start the next token from its own arg-max (greedy callers; resident_eval)
         resident_us = get("BIOGPT_HIP_RESIDENT_US", 1000);   // ... for at most this long without a new token (the device is not shared meanwhile)
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
@@ -289,12 +290,22 @@ struct biogpt_hip_ctx {
     int unsynced_from = -1;                // position of the first single-token eval enqueued since the stream was last synchronised (-1: none): what a tripped pipeline may have spoiled
     int lm_blocks = 0;
     // resident single-token evals (biogpt_hip_eval): a pipelined launch that is still on the device, fed through res_mbox
-    int32_t *res_mbox = nullptr;           // pinned ring of 64 x {n_past, causal, token, seq}
+    int32_t *res_mbox = nullptr;           // pinned ring of 64 x 32 bytes, the first 8 = bgk::xp_post(seq, n_past, token, speculate-next)
     uint32_t *res_done = nullptr;          // pinned [256]: per lm_head workgroup, the sequence number of the last token whose logits rows it has written to logits_host
     bool res_live = false;                 // a resident launch is (or may still be) on the device
     uint32_t res_seq = 0;                  // sequence number of the last token / request posted
     int res_next = 0, res_left = 0;        // position the live launch expects next; tokens it will still take
     int res_nw = 0;                        // completion words to collect per token
+    // speculative continuation (XpParams::spec_rec): passes with an odd sequence number write the *_alt row / partial buffers
+    float *logits_alt = nullptr, *pmax_val_alt = nullptr;      // device
+    int32_t *pmax_idx_alt = nullptr;
+    float *logits_host_alt = nullptr;      // pinned
+    unsigned long long *res_spec = nullptr;    // pinned: {sequence number << 32 | the device's arg-max of the token before}
+    const float *row_cur = nullptr;        // the pinned row that holds the logits of the last biogpt_hip_eval / eval_inplace
+    uint32_t res_acc = 0;                  // sequence number of the last pass the caller asked for (its parity says which buffers hold its results)
+    bool spec_pending = false;             // the live launch starts the next position on its own account
+    int spec_streak = 0, spec_need = 4;    // consecutive calls whose token was the device's arg-max; how many it takes to speculate (doubles with every miss)
+    long spec_hits = 0, spec_misses = 0;
     double res_t_wait = 0.0, res_t_call = 0.0; long res_calls = 0;   // measurement only (BIOGPT_HIP_RES_DBG & 8)
     std::chrono::steady_clock::time_point res_t_last{};
     bool ready = false;  // weights present
@@ -874,7 +885,7 @@ int fast_lm_grid(const biogpt_hip_ctx *c) {
 // host_row (optional): pinned host buffer that also receives the logits row; *host_row_done tells whether the launch wrote it itself
 // pl: -1 = go through the XCD pipeline if this context can take the device's slot now; 0 / 1 = the caller decided (graph capture: the
 //     graph is replayed only in the matching state)
-struct ResidentArgs { int32_t tok0, n_past0; uint32_t seq0; };
+struct ResidentArgs { int32_t tok0, n_past0; uint32_t seq0; int32_t spec0; };
 bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance, int l0 = 0, int l1 = -1, int only = -1, int n_tok = 1, float *host_row = nullptr,
                           bool *host_row_done = nullptr, int pl = -1, const ResidentArgs *ra = nullptr) {
     t_ctx = c;
@@ -922,9 +933,12 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
                 xp.resident = 1; xp.mbox = c->res_mbox; xp.mbox_seq0 = ra->seq0; xp.done_host = c->res_done;
                 xp.idle_ticks = (uint32_t)std::max(1, c->opt.resident_us) * 100u;
                 xp.res_tok0 = ra->tok0; xp.res_n_past0 = ra->n_past0; xp.res_dbg = c->opt.res_dbg;
+                xp.res_spec0 = ra->spec0; xp.spec_rec = c->res_spec;
+                xp.logits_alt = c->logits_alt; xp.logits_host_alt = c->logits_host_alt; xp.pmax_alt_val = c->pmax_val_alt; xp.pmax_alt_idx = c->pmax_idx_alt;
+                if (!xp.spec_rec || !xp.logits_alt || !xp.logits_host_alt || !xp.pmax_alt_val || !xp.pmax_alt_idx) BG_FAIL(false, "internal: a resident launch without its alternate buffers");
             } else if (n_tok > 1 && !(fold && advance == 1 && tok_src == 2)) BG_FAIL(false, "internal: a multi-token launch needs the lm_head inside the pipeline");
         }
-        xp.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
+        xp.wall = ((c->opt.dbg & 128) || (ra && (c->opt.res_dbg & 32))) ? c->tstamp : nullptr;
         const hipError_t e = (hipError_t)bg_xpipe_launch(wt, xp.t_cap, bgk::xpipe_smem_bytes(xp.gelu_p + xp.gelu_n), c->stream, &xp, sizeof(xp));
         HIP_TRY(false, e);
     }
@@ -1356,6 +1370,43 @@ void destroy(biogpt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)resident_stop(c);
+    if ((c->opt.res_dbg & 32) && c->tstamp && c->res_seq > 8) {      // device-side stamps: token seen by XCD 0's poller [s][0], lm_head workgroup 0's completion word [s][1]
+        std::vector<unsigned long long> w(8192);
+        if (hipMemcpy(w.data(), c->tstamp, w.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double proc = 0.0, turn = 0.0; int np = 0, nt = 0;
+            const uint32_t hi = c->res_seq < 4000u ? c->res_seq : 4000u;
+            for (uint32_t q = 2; q + 1 < hi; q++) {
+                const unsigned long long a = w[2 * q], b = w[2 * q + 1], a2 = w[2 * q + 2];
+                if (a && b && b > a && b - a < 100000ull) { proc += (double)(b - a) * 0.01; np++; }
+                if (b && a2 && a2 > b && a2 - b < 100000ull) { turn += (double)(a2 - b) * 0.01; nt++; }
+            }
+            fprintf(stderr, "resident launch, device clock: token seen -> completion word %.2f us (%d), completion word -> next token seen %.2f us (%d)\n", np ? proc / np : 0.0, np, nt ? turn / nt : 0.0, nt);
+            std::vector<unsigned long long> e(4096 * 4);
+            if (hipMemcpy(e.data(), c->tstamp + 32768, e.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                // [q][0] XCD 0's workgroup 0 is ready for the next token, [1] it has the arg-max of token q - 1, [2] token out (and the post of q - 1 checked), [3] lm workgroup 0 published its partials of token q
+                double s01 = 0, s12 = 0, sp = 0, sdone = 0, sready = 0; int n = 0;
+                for (uint32_t q = 3; q + 1 < hi; q++) {
+                    const unsigned long long t0 = e[4 * q], t1 = e[4 * q + 1], t2 = e[4 * q + 2], pp = e[4 * (q - 1) + 3], dn = w[2 * (q - 1) + 1];
+                    if (!t0 || !t1 || !t2 || !pp || !dn || t2 < t0 || t2 - t0 > 100000ull) continue;
+                    s01 += (double)(long long)(t1 - t0) * 0.01; s12 += (double)(long long)(t2 - t1) * 0.01; sp += (double)(long long)(t1 - pp) * 0.01;
+                    sdone += (double)(long long)(pp - dn) * 0.01; sready += (double)(long long)(t0 - dn) * 0.01; n++;
+                }
+                if (n) fprintf(stderr, "   XCD 0, workgroup 0: ready for the next token %.2f us after lm workgroup 0's completion word (its partials went out %.2f us after that word), arg-max %.2f us after ready = %.2f us after those partials, token out + post checked %.2f us later (%d)\n",
+                               sready / n, sdone / n, s01 / n, sp / n, s12 / n, n);
+            }
+            std::vector<unsigned long long> d(64 * 256);
+            if (hipMemcpy(d.data(), c->tstamp + 8192, d.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double spread = 0.0, last_after_first = 0.0; int ns = 0; int late[8] = {};
+                for (int q = 0; q < 64; q++) {
+                    unsigned long long lo = ~0ull, hi2 = 0; int arg = -1;
+                    for (int k = 0; k < c->res_nw && k < 256; k++) { const unsigned long long t = d[(size_t)q * 256 + k]; if (!t) continue; if (t < lo) lo = t; if (t > hi2) { hi2 = t; arg = k; } }
+                    if (hi2 > lo && hi2 - lo < 100000ull) { spread += (double)(hi2 - lo) * 0.01; ns++; if (arg >= 0) late[(arg / 32) & 7]++; last_after_first += (double)(hi2 - d[(size_t)q * 256]) * 0.01; }
+                }
+                fprintf(stderr, "   completion words of one token: first -> last %.2f us, workgroup 0 -> last %.2f us (%d tokens); XCD group of the last one: %d %d %d %d %d %d\n",
+                        ns ? spread / ns : 0.0, ns ? last_after_first / ns : 0.0, ns, late[0], late[1], late[2], late[3], late[4], late[5]);
+            }
+        }
+    }
     if ((c->opt.res_dbg & 8) && c->res_calls > 0)
         fprintf(stderr, "resident evals: %ld calls, %.2f us waiting for the completion words, %.2f us between a return and the next post\n", c->res_calls, c->res_t_wait / c->res_calls * 1e6, c->res_t_call / c->res_calls * 1e6);
     for (auto &pl : c->graph_step) for (auto &row : pl) for (auto &g : row) if (g) (void)hipGraphExecDestroy(g);
@@ -1375,6 +1426,9 @@ void destroy(biogpt_hip_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->state_host) (void)hipHostFree(c->state_host);
     if (c->logits_host) (void)hipHostFree(c->logits_host);
+    if (c->logits_host_alt) (void)hipHostFree(c->logits_host_alt);
+    if (c->res_spec) (void)hipHostFree(c->res_spec);
+    for (void *p : {(void *)c->logits_alt, (void *)c->pmax_val_alt, (void *)c->pmax_idx_alt}) if (p) (void)hipFree(p);
     if (c->tstamp) (void)hipFree(c->tstamp);
     if (c->tok_vocab) bg::drop_vocab(c->tok_vocab);
     delete c;
@@ -1586,33 +1640,72 @@ static bool resident_stop(biogpt_hip_ctx *c) {
     c->res_live = false;
     if (c->res_left > 0 && c->res_mbox) {      // it still waits for tokens: ask it to leave (a slot whose position is not the expected one)
         const uint32_t seq = ++c->res_seq;
-        volatile int32_t *slot = c->res_mbox + (size_t)(seq & 63u) * 8;
-        slot[0] = -1; slot[1] = 0; slot[2] = -1;
-        __atomic_store_n(const_cast<int32_t *>(slot) + 3, (int32_t)seq, __ATOMIC_RELEASE);
+        __atomic_store_n(reinterpret_cast<unsigned long long *>(c->res_mbox + (size_t)(seq & 63u) * 8), bgk::xp_post(seq, 0x1fff, 0xffffff, 0), __ATOMIC_RELEASE);
     }
     c->res_left = 0;
+    c->spec_pending = false;
     HIP_TRY(false, hipSetDevice(c->device));
-    HIP_TRY(false, hipStreamSynchronize(c->stream));
-    return xpipe_check(c);
+    HIP_TRY(false, hipStreamSynchronize(c->stream));      // a pass the launch started on its own account finishes first (at most one token's time)
+    const bool ok = xpipe_check(c);
+    if (c->res_acc & 1u) {      // the last pass the caller asked for wrote the alternate buffers: everything outside the resident launch reads the ordinary ones
+        const size_t V = (size_t)c->hp.n_vocab;
+        HIP_TRY(false, hipMemcpyAsync(c->logits, c->logits_alt, V * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(false, hipMemcpyAsync(c->pmax_val, c->pmax_val_alt, (size_t)c->pmax_cap * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(false, hipMemcpyAsync(c->pmax_idx, c->pmax_idx_alt, (size_t)c->pmax_cap * 4, hipMemcpyDeviceToDevice, c->stream));
+        c->res_acc = 0;
+    }
+    return ok;
 }
 
-// one token through a resident launch; 1 = done (row in ctx->logits_host), 0 = not applicable here (caller takes the ordinary path), -2 = failure
+// Speculation policy: a launch runs ahead of the caller only after spec_need consecutive calls whose token WAS the device's arg-max of the row before (a greedy
+// caller: always; a sampling caller: rarely for long), and every miss doubles spec_need -- a miss costs the pass that was started in vain plus a fresh launch.
+static bool spec_wanted(const biogpt_hip_ctx *c) { return c->opt.res_spec != 0 && c->spec_streak >= c->spec_need; }
+
+// one token through a resident launch; 1 = done (row in ctx->row_cur), 0 = not applicable here (caller takes the ordinary path), -2 = failure
 static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
     if (!ctx->opt.resident || ctx->opt.no_graph || !xpipe_lm_folds(ctx)) return 0;
     const int tmax = bucket_tmax(ctx, graph_bucket(n_past + 1));
     if (tmax > 256 || !fused_decode_ok(ctx, tmax) || !xpipe_bucket_ok(ctx, tmax)) return 0;
+    if (ctx->hp.n_vocab >= 0xffffff || ctx->hp.n_positions >= 0x1fff) return 0;      // the mailbox word's fields (xp_post)
     const size_t V = (size_t)ctx->hp.n_vocab;
-    for (int attempt = 0; attempt < 3; attempt++) {
-        if (ctx->res_live && (*ctx->xp_err_host != 0u || ctx->res_left <= 0 || n_past != ctx->res_next)) {
+    const volatile uint32_t *const err = reinterpret_cast<const volatile uint32_t *>(ctx->xp_err_host);
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (ctx->res_live && (*err != 0u || ctx->res_left <= 0 || n_past != ctx->res_next)) {
             if (!resident_stop(ctx)) return -2;      // it has left (idle), is used up, or the caller moved elsewhere in the sequence
         }
         uint32_t seq;
-        if (ctx->res_live) {      // hand the token to the launch that is waiting for it
-            seq = ++ctx->res_seq;
-            volatile int32_t *slot = ctx->res_mbox + (size_t)(seq & 63u) * 8;
-            slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = token;
-            __atomic_store_n(const_cast<int32_t *>(slot) + 3, (int32_t)seq, __ATOMIC_RELEASE);
+        if (ctx->res_live) {      // hand the token to the launch that is waiting for it -- or that has already started this position with its own arg-max
+            seq = ctx->res_seq + 1u;
+            // the device's arg-max of the previous row, written when that row was complete (a few microseconds before the caller could have read it)
+            bool have = false, gone = false;
+            int32_t guess = -1;
+            for (uint32_t spin = 0; spin < (ctx->spec_pending ? 0x40000000u : 1u); spin++) {
+                const unsigned long long rec = __atomic_load_n(ctx->res_spec, __ATOMIC_ACQUIRE);
+                if ((uint32_t)(rec >> 32) == seq) { have = true; guess = (int32_t)(uint32_t)rec; break; }
+                if (*err != 0u) { gone = true; break; }
+            }
+            if (ctx->spec_pending && !have) {      // the launch left before it got here (idle time-out, failure): a fresh launch takes the token
+                (void)gone;
+                if (!resident_stop(ctx)) return -2;
+                if (ctx->xp_state != 1) return 0;
+                continue;
+            }
+            if (have) ctx->spec_streak = (guess == token) ? ctx->spec_streak + 1 : 0;
+            if (ctx->spec_pending) {
+                if (guess != token) {      // the pass in flight is not the one the caller wants: it ends the launch (the post below would not match), a fresh one follows
+                    ctx->spec_misses++;
+                    ctx->spec_need = std::min(ctx->spec_need * 2, 1 << 20);
+                    if (!resident_stop(ctx)) return -2;
+                    if (ctx->xp_state != 1) return 0;
+                    continue;
+                }
+                ctx->spec_hits++;
+            }
+            ctx->res_seq = seq;
             ctx->res_next++; ctx->res_left--;
+            const bool spec_next = ctx->res_left > 0 && spec_wanted(ctx);
+            __atomic_store_n(reinterpret_cast<unsigned long long *>(ctx->res_mbox + (size_t)(seq & 63u) * 8), bgk::xp_post(seq, n_past, token, spec_next ? 1 : 0), __ATOMIC_RELEASE);
+            ctx->spec_pending = spec_next;
         } else {
             if (!xpipe_usable(ctx, tmax)) return 0;      // another context holds the device's pipeline slot
             if (!ctx->res_mbox) {
@@ -1621,35 +1714,57 @@ static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
                 std::memset(ctx->res_mbox, 0xff, 64 * 8 * 4);
                 std::memset(ctx->res_done, 0, 256 * 4);
             }
+            if (!ctx->res_spec) {
+                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_spec), 64, hipHostMallocDefault));
+                std::memset(ctx->res_spec, 0, 64);
+                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host_alt), V * 4, hipHostMallocDefault));
+                HIP_TRY(-2, hipMalloc(&ctx->logits_alt, V * 4));
+                HIP_TRY(-2, hipMalloc(&ctx->pmax_val_alt, (size_t)ctx->pmax_cap * 4));
+                HIP_TRY(-2, hipMalloc(&ctx->pmax_idx_alt, (size_t)ctx->pmax_cap * 4));
+            }
             if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), V * 4, hipHostMallocDefault));
+            if ((ctx->opt.res_dbg & 32) && !ctx->tstamp) {
+                HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
+                HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
+            }
             seq = ++ctx->res_seq;
             const int n_tok = tmax - n_past;          // up to the end of the context bucket
-            const ResidentArgs ra{token, n_past, seq};
+            const bool spec_next = n_tok > 1 && spec_wanted(ctx);
+            const ResidentArgs ra{token, n_past, seq, spec_next ? 1 : 0};
             bool row_done = false;
             if (!enqueue_decode_fused(ctx, tmax, 1, 0, 0, -1, -1, n_tok, ctx->logits_host, &row_done, 1, &ra)) return -2;
             if (!row_done) BG_FAIL(-2, "internal: the resident launch does not write the host row");
             ctx->res_live = true; ctx->res_next = n_past + 1; ctx->res_left = n_tok - 1;
             ctx->res_nw = (ctx->lm_blocks + 3) / 4;
             ctx->mbox_synced = ctx->mbox_sent;
+            ctx->spec_pending = spec_next;
         }
-        // completion: one word per lm_head workgroup, written behind its rows
+        // completion: one word per lm_head workgroup, written behind its rows (a launch that runs ahead may already have moved a word on to the next number)
         const volatile uint32_t *done = ctx->res_done;
         const int nw = ctx->res_nw;
-        const auto t0 = std::chrono::steady_clock::now();
+        // no clock on the fast path (a clock read is a system call on some virtualised hosts: microseconds): the 5 s guard starts counting after ~10^6 polls
+        std::chrono::steady_clock::time_point t0{};
         if (ctx->opt.res_dbg & 8) {      // time between the previous call's return and this post = the caller's own time + this function's overhead
+            t0 = std::chrono::steady_clock::now();
             if (ctx->res_calls > 0) ctx->res_t_call += std::chrono::duration<double>(t0 - ctx->res_t_last).count();
             ctx->res_calls++;
         }
-        bool ok = false, left = false;
+        bool ok = false, left = false, timing = false;
+        std::chrono::steady_clock::time_point tg{};
+        int k = 0;                       // completion words seen so far
         for (uint32_t spin = 0;; spin++) {
-            int k = 0;
-            while (k < nw && done[k] == seq) k++;
+            while (k < nw && (int32_t)(done[k] - seq) >= 0) k++;
             if (k == nw) { ok = true; break; }
-            if (*reinterpret_cast<const volatile uint32_t *>(ctx->xp_err_host) != 0u) { left = true; break; }
-            if ((spin & 0xfffu) == 0xfffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+            if (*err != 0u) { left = true; break; }
+            if ((spin & 0xfffffu) == 0xfffffu) {
+                if (!timing) { tg = std::chrono::steady_clock::now(); timing = true; }
+                else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count() > 5.0) break;
+            }
         }
         if (ok) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            ctx->res_acc = seq;
+            ctx->row_cur = (seq & 1u) ? ctx->logits_host_alt : ctx->logits_host;
             if (ctx->opt.res_dbg & 8) { ctx->res_t_last = std::chrono::steady_clock::now(); ctx->res_t_wait += std::chrono::duration<double>(ctx->res_t_last - t0).count(); }
             return 1;
         }
@@ -1822,6 +1937,16 @@ int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_
 
 const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) { return ctx ? ctx->logits : nullptr; }
 
+int biogpt_hip_read_logits(biogpt_hip_ctx *ctx, float *out) {
+    if (!ctx || !out) BG_FAIL(-1, "null argument");
+    clear_error();
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
+    HIP_TRY(-2, hipMemcpyAsync(out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    return xpipe_check(ctx) ? 0 : -2;
+}
+
 int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
     if (!ctx) BG_FAIL(-1, "null context");
     if (!resident_stop(ctx)) return -2;
@@ -1845,7 +1970,7 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
         if (!ctx->res_live) HIP_TRY(-2, hipSetDevice(ctx->device));      // a live resident launch needs no HIP call at all
         const int r = resident_eval(ctx, tokens[0], n_past);
         if (r < 0) return r;
-        if (r == 1) { if (logits_out) std::memcpy(logits_out, ctx->logits_host, (size_t)ctx->hp.n_vocab * 4); return 0; }
+        if (r == 1) { if (logits_out) std::memcpy(logits_out, ctx->row_cur, (size_t)ctx->hp.n_vocab * 4); return 0; }
     }
     const int rc = eval_device_impl(ctx, tokens, n, n_past, 1);
     if (rc) return rc;
@@ -1862,6 +1987,7 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
     }
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
+    ctx->row_cur = ctx->logits_host;
     if (logits_out) std::memcpy(logits_out, ctx->logits_host, bytes);
     return 0;
 }
@@ -2005,8 +2131,13 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     if (!row_out) BG_FAIL(-1, "null row pointer");
     int rc = eval_once(ctx, tokens, n, n_past, nullptr);
     if (rc != 0 && xpipe_retry(ctx, n_past)) rc = eval_once(ctx, tokens, n, n_past, nullptr);
-    *row_out = rc == 0 ? ctx->logits_host : nullptr;
+    *row_out = rc == 0 ? ctx->row_cur : nullptr;
     return rc;
+}
+int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4) {
+    if (!ctx || !out4) return -1;
+    out4[0] = ctx->spec_hits; out4[1] = ctx->spec_misses; out4[2] = ctx->spec_streak; out4[3] = ctx->spec_need;
+    return 0;
 }
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
     if (!logits_out) BG_FAIL(-1, "null logits buffer");

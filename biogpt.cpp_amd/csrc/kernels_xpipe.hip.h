@@ -96,10 +96,19 @@ struct XpParams {
     int32_t resident;
     int32_t res_tok0, res_n_past0;   // token 0 of a resident launch and its position
     int32_t res_dbg;                 // measurement only (BIOGPT_HIP_RES_DBG): 1 completion word without waiting for the row stores, 2 no sleep in the mailbox poll, 4 no row store
-    const int32_t *mbox;
+    const int32_t *mbox;             // 64 slots of 32 bytes, the first 8 of each = xp_post(...)
     uint32_t mbox_seq0;
     uint32_t idle_ticks;
     uint32_t *done_host;       // pinned [lm workgroups]: sequence number of the last token whose rows this workgroup has written to logits_host
+    // Speculative continuation (greedy callers): when the post of token tk - 1 carried the "speculate" flag, token tk starts from the device's OWN arg-max of
+    // token tk - 1 as soon as those logits exist -- while the host is still reading that row -- and the host's post of token tk, checked when token tk + 1 is due,
+    // must name the same token and position (anything else ends the launch).  A resident pass with an odd sequence number writes the *_alt buffers, an even one
+    // the ordinary ones, so a pass the host never asked for overwrites nothing the host (or a later launch) still reads.  spec_rec = {sequence number << 32 |
+    // arg-max of the previous token}: written at the start of every pass tk >= 1, the host compares its token with it.
+    int32_t res_spec0;               // speculate token 1 of this launch
+    unsigned long long *spec_rec;    // pinned
+    float *logits_alt, *logits_host_alt;
+    float *pmax_alt_val; int32_t *pmax_alt_idx;
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16, then [32][16] of every workgroup of the last layer
 };
 
@@ -131,6 +140,10 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
 template <int N, int S = 1>
 __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
 
+// a post of the host in the resident launch's mailbox: one word, one PCIe read.  token 24 bits (0xffffff: leave), position 13 bits, speculate-next 1 bit, sequence number 24 bits
+__host__ __device__ inline xp_u64 xp_post(uint32_t seq, int n_past, int token, int spec) {
+    return ((xp_u64)(seq & 0xffffffu) << 40) | ((xp_u64)(spec & 1) << 37) | ((xp_u64)((uint32_t)n_past & 0x1fffu) << 24) | (xp_u64)((uint32_t)token & 0xffffffu);
+}
 // a clean end of a resident launch (no token from the host within the idle time, or the host asked for it): the same drain as a failure, its own code
 constexpr uint32_t XP_QUIT = 0x80000000u;
 __device__ __forceinline__ void xp_quit(const XpParams &p) {
@@ -276,6 +289,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
     uint32_t *const s_dead = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 96);      // [4] behind the 8 doubles the attention stage uses
+    uint32_t *const s_spec = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 112);     // [3] resident launch, workgroup 0 of XCD 0: {speculate the next token, the token the current pass was started with unasked (-1: none)}
     const int t_cap = p.t_cap;
     const int n_units = SPLIT ? 2 * p.n_layer : p.n_layer;                     // pipeline units: layers, or half layers
     const int last_xcd = (n_units - 1) & 7;
@@ -363,36 +377,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (L == 0) {
                 int tok;
-                if (RES && p.resident != 0 && tk > 0) {
-                    // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox.  Workgroup 0 waits for it -- at most
-                    // idle_ticks, then the launch ends cleanly (xp_quit) -- and hands it to the XCD's other workgroups as a granule
-                    xp_u64 *const gt = p.samp + 2048;
-                    if (slot == 0 && tid == 0 && etag != 0u) {
-                        const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
-                        const int32_t *mb = p.mbox + (size_t)(want & 63u) * 8;
-                        const unsigned long long t0 = wall_clock64();
-                        int got = -1;
-                        for (;;) {
-                            if ((uint32_t)__hip_atomic_load(mb + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want) {
-                                const int np = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                const int tv = __hip_atomic_load(mb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                if (np == n_past && tv >= 0 && tv < p.n_vocab) got = tv;      // anything else is the host's request to leave
-                                break;
-                            }
-                            if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) break;
-                            if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
-                            if (!(p.res_dbg & 2)) __builtin_amdgcn_s_sleep(4);
-                        }
-                        if (got < 0) xp_quit(p);
-                        else xp_put_local(gt, epoch, (uint32_t)got);
-                    }
-                    uint32_t v[1];
-                    xp_sweep_q<RES, 1>(gt, true, epoch, v, p, etag);
-                    tok = (int)v[0];
-                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
-                } else if (tk > 0) {
-                    // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
-                    // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024)
+                // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
+                // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024); every thread returns the arg-max
+                auto sample_prev = [&]() __attribute__((always_inline)) -> int {
                     float bv = -INFINITY;
                     int bi = 0x7fffffff;
                     {
@@ -435,8 +422,72 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                     for (int w = 1; w < NW; w++)
                         if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
-                    tok = bi;
+                    if (bi < 0 || bi >= p.n_vocab) bi = 0;
+                    return bi;
+                };
+                if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                if (RES && p.resident != 0 && tk > 0) {
+                    // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox -- or, speculating, the device's own
+                    // arg-max of the previous one, which that post must then confirm.  Workgroup 0 decides and hands the token to the XCD's other workgroups
+                    // as a granule; a wait for the host lasts at most idle_ticks, then the launch ends cleanly (xp_quit)
+                    xp_u64 *const gt = p.samp + 2048;
+                    if (slot == 0) {
+                        unsigned long long *const wl4 = ((p.res_dbg & 32) && p.wall && tid == 0) ? p.wall + 32768 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 4 : nullptr;
+                        if (wl4) wl4[0] = wall_clock64();
+                        const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
+                        // the post with sequence number seq, for position np (ONE 8-byte word, xp_post): its token (>= 0) and "speculate the token after this one",
+                        // or -1: time-out / the host asks the launch to leave / the launch is failing
+                        auto wait_post = [&](uint32_t seq, int np, int &spec) __attribute__((always_inline)) -> int {
+                            const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(p.mbox) + (size_t)(seq & 63u) * 4;
+                            const unsigned long long t0 = wall_clock64();
+                            for (;;) {
+                                const xp_u64 w = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if ((uint32_t)(w >> 40) == (seq & 0xffffffu)) {
+                                    const int tv = (int)(w & 0xffffffu), pn = (int)((w >> 24) & 0x1fffu);
+                                    spec = (int)((w >> 37) & 1u);
+                                    return (pn == np && tv < p.n_vocab) ? tv : -1;      // anything else is the host's request to leave
+                                }
+                                if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) return -1;
+                                if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return -1;
+                                if (!(p.res_dbg & 2)) __builtin_amdgcn_s_sleep(4);
+                            }
+                        };
+                        // A pass that was started unasked (from the device's own arg-max): the host's post for it -- made while that pass was running, long ago
+                        // when the host keeps up -- is read NOW, while this workgroup waits for the pass to end anyway: behind the logits rows, which are about
+                        // to go out, a PCIe read queues for microseconds.  It must name the same token and position; it also says that the host is done
+                        // with the buffers the coming pass will write.
+                        if (tid == 0) {
+                            const int pending = (int)s_spec[1];
+                            int unused = 0;
+                            s_spec[2] = (etag != 0u && (pending < 0 || wait_post(want - 1u, n_past - 1, unused) == pending)) ? 1u : 0u;
+                        }
+                        const int guess = sample_prev();       // arg-max of the previous token's logits (barriers inside: the whole workgroup)
+                        __syncthreads();                       // s_redf is reused by the attention stage
+                        if (wl4) wl4[1] = wall_clock64();
+                        if (tid == 0 && etag != 0u) {
+                            int spec = (int)s_spec[0];
+                            // once a pass has been started unasked the following ones are too: the host asks for that as long as its tokens match, and a mismatch ends the launch
+                            const bool ahead = (int)s_spec[1] >= 0 || spec != 0;
+                            int got = -1;
+                            if (s_spec[2] != 0u) {
+                                if (p.spec_rec) __hip_atomic_store(p.spec_rec, ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                got = ahead ? guess : wait_post(want, n_past, spec);
+                            }
+                            if (got >= 0) {
+                                xp_put_local(gt, epoch, (uint32_t)got);
+                                xp_put(gt + 1, epoch, 1u);      // the lm_head workgroups write this pass's rows only behind this word
+                                s_spec[0] = (uint32_t)spec; s_spec[1] = ahead ? (uint32_t)guess : 0xffffffffu;
+                            } else xp_quit(p);
+                            if ((p.res_dbg & 32) && p.wall) p.wall[(size_t)(want & 4095u) * 2] = wall_clock64();
+                            if (wl4) wl4[2] = wall_clock64();
+                        }
+                    }
+                    uint32_t v[1];
+                    xp_sweep_q<RES, 1>(gt, true, epoch, v, p, etag);
+                    tok = (int)v[0];
                     if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                } else if (tk > 0) {
+                    tok = sample_prev();
                     if (slot == 0 && tid == 0) {
                         int32_t *tokens = state_tokens(p.st);
                         const int g = n_gen0 + tk;
@@ -872,6 +923,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         const bool worker = tid < 256;
         constexpr int LMS = 128 / NW;                                         // 2-row steps per wave: 256 rows per workgroup
         const int row0 = lm_rank * 256;
+        // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
+        const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
+        float *const lg_dev = alt ? p.logits_alt : p.logits;
+        float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
         Unit<WT> wl[LMS];
 #pragma unroll
         for (int s = 0; s < LMS; s++) {
@@ -883,6 +938,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         for (int s = 0; s < LMS; s++) xp_settle<WT, EXPAND>(wl[s]);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
         if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
+        if (RES && p.resident != 0 && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
+            uint32_t go[1];
+            xp_sweep_q<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, etag);
+        }
         if (wave < 4) {
             uint32_t v[4];
             xp_sweep_q<RES, 4, 256>(p.gran + (size_t)(p.n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, etag);
@@ -907,9 +966,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
             if (row < p.n_vocab) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
-                p.logits[row] = v;
-                if constexpr (RES) s_S[row - row0] = v;        // staged for the host copy below (s_S: no attention runs in this workgroup now)
-                else if (p.logits_host) p.logits_host[row] = v;
+                if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
+                else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
                 best_val = v; best_idx = row;
             }
         }
@@ -928,18 +986,21 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         // the host's copy of the row (biogpt_eval's output): wave 1 writes the workgroup's 256 logits as ONE kilobyte of 16-byte write-through stores
         // (four-byte stores from the finisher lanes were one PCIe write each: 42 k per token); a resident launch follows them with the workgroup's
         // completion word for this token -- same wave, behind its own stores (the host collects one word per lm_head workgroup)
-        if (RES && p.logits_host && wave == 1 && row_ok) {
+        if (RES && lg_host && wave == 1 && row_ok) {
             const int r = row0 + 4 * lane;
             if (p.res_dbg & 4) {
             } else if (r + 3 < p.n_vocab) {
                 const xp_v4f v4 = *reinterpret_cast<const xp_v4f *>(s_S + 4 * lane);
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p.logits_host + r), "v"(v4) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(lg_host + r), "v"(v4) : "memory");
+                *reinterpret_cast<xp_v4f *>(lg_dev + r) = v4;
             } else {
-                for (int j = r; j < p.n_vocab; j++) __hip_atomic_store(p.logits_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int j = r; j < p.n_vocab; j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
             }
             if (p.resident != 0) {
                 if (!(p.res_dbg & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((p.res_dbg & 32) && p.wall && lane == 0 && lm_rank == 0) p.wall[(size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 2 + 1] = wall_clock64();
+                if ((p.res_dbg & 32) && p.wall && lane == 0) p.wall[8192 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 63u) * 256 + lm_rank] = wall_clock64();
             }
         }
         if (tid < 4) {
@@ -953,11 +1014,16 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             const int blk = lm_rank * 4 + tid;
             if (blk < p.lm_blocks) {
-                p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi;
+                // the device row and the partials, like the host row, only from a pass that really ran (a draining launch -- the host asked it to leave, or it gave up
+                // waiting -- still walks through the pass it was about to start, with nothing valid in its hands)
+                if (RES && !row_ok) {}
+                else if (RES && alt) { p.pmax_alt_val[blk] = bv; p.pmax_alt_idx[blk] = bi; }
+                else { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
                 if (tk + 1 < p.n_tok) {        // the sampler of the next token runs on XCD 0
                     xp_put(p.samp + blk, etag, __float_as_uint(bv));
                     xp_put(p.samp + 1024 + blk, etag, (uint32_t)bi);
                 }
+                if (RES && (p.res_dbg & 32) && p.wall && blk == 0) p.wall[32768 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 4 + 3] = wall_clock64();
             }
         }
         __syncthreads();       // s_redf / s_part / s_xq are rewritten by this workgroup's next layer

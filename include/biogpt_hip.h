@@ -143,16 +143,25 @@ int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens
 /* biogpt_eval (biogpt.cpp:812-847) without the final copy: *row_out points at the context's pinned host buffer that the launch
  * itself wrote the n_vocab logits of the last token into (valid until the next call on this context).  A loop of single-token calls
  * (main.cpp:91-151) -- through this entry or biogpt_hip_eval -- is served by ONE pipelined launch that stays on the device between
- * the calls and takes each next token from a pinned mailbox (DESIGN.md 4.1c); it leaves the device after BIOGPT_HIP_RESIDENT_US
+ * the calls and takes each next token from a pinned mailbox (DESIGN.md 4.1d); it leaves the device after BIOGPT_HIP_RESIDENT_US
  * (default 1000) microseconds without a call, or as soon as the context is asked to do anything else. */
 int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
                             const float **row_out);
+
+/* The launch behind a loop of single-token evals may run AHEAD of a greedy caller: once four consecutive calls have named exactly the
+ * arg-max of the row before (lowest id on ties -- what std::max_element over the logits returns, main.cpp:109-128 with top_k = 1), the
+ * launch starts the next position from its own arg-max while the caller still reads the row, and the next call only confirms the token
+ * (any other token / position ends that launch, costs one token's time, and doubles the number of matching calls needed before the
+ * next attempt; BIOGPT_HIP_SPEC=0 switches it off).  Results are the same either way.  out4 = {calls served by a pass that was already
+ * running, calls that named a different token than the running pass, current run of matching calls, matches needed}. */
+int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4);
 
 /* Same pass, logits stay in HBM (no PCIe); biogpt_hip_logits_device() returns the device pointer
  * to the n_vocab floats of the last evaluated token.  eval_device is asynchronous on the
  * context's stream; biogpt_hip_synchronize() waits for it. */
 int          biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past);
 const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx);
+int          biogpt_hip_read_logits(biogpt_hip_ctx *ctx, float *out);   /* waits for the context's work, then copies that device row (n_vocab floats) to host memory */
 int          biogpt_hip_synchronize(biogpt_hip_ctx *ctx);
 
 /* biogpt_eval + the top-k selection of biogpt_sample_top_k_top_p (biogpt.cpp:929-936) on the device: evaluates like

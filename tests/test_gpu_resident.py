@@ -149,3 +149,89 @@ def test_api_loop_through_the_resident_launch(pkg, oracle, files):
     assert list(ids[:40]) == list(ref)
     print("api loop: %.0f tok/s" % (120 / secs))
     g.close()
+
+
+def _run(model, prompt, n, pick, hook=None):
+    """prompt, then n single-token evals; pick(k, row, n_past) -> (token, n_past) of call k; returns the rows and the (token, n_past) of every call"""
+    rows, calls = [model.eval(prompt, 0)], []
+    n_past = len(prompt)
+    for k in range(n):
+        tok, n_past = pick(k, rows[-1], n_past)
+        rows.append(model.eval([tok], n_past))
+        calls.append((tok, n_past))
+        n_past += 1
+        if hook:
+            hook(k, rows[-1])
+    return rows, calls
+
+
+def test_speculative_continuation_greedy_caller(pkg, files, monkeypatch):
+    """A greedy caller (main.cpp:109-128 with top_k = 1) with the device to itself: after four calls that named the device's own arg-max the launch runs
+    one position ahead of the caller.  250 tokens through the 64 / 128 / 192 / 256-key launches: every row equal to the per-call path's, nearly every
+    call served by a pass that was already running, and -- the launch is stopped with such a pass in flight -- the device-side row read back afterwards
+    is the LAST ASKED token's."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 77, 1234, 9]
+    greedy = lambda k, row, n_past: (int(row.argmax()), n_past)
+
+    def hook(k, row):
+        if k in (20, 21, 90):      # odd and even sequence numbers: the device row after the launch was asked to leave mid-speculation
+            assert (g.read_logits() == row).all(), k
+
+    rows, calls = _run(g, prompt, 250, greedy, hook)
+    st = g.resident_stats()
+    print("speculation:", st)
+    assert g.xpipe_state() == 1
+    g.close()
+    u = _plain(pkg, files["q4_0"], monkeypatch)
+    rows_u, calls_u = _run(u, prompt, 250, greedy)
+    assert calls == calls_u
+    for k, (a, b) in enumerate(zip(rows, rows_u)):
+        assert (a == b).all(), (k, float(np.abs(a - b).max()))
+    u.close()
+    assert st["misses"] == 0 and st["hits"] >= 200, st
+    monkeypatch.setenv("BIOGPT_HIP_SPEC", "0")
+    h = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_SPEC")
+    rows_h, _ = _run(h, prompt, 12, greedy)
+    assert h.resident_stats()["hits"] == 0 and all((a == b).all() for a, b in zip(rows_h, rows))
+    h.close()
+
+
+def test_speculative_continuation_wrong_guesses(pkg, files, monkeypatch):
+    """A caller that follows the arg-max for a while and then does not (a sampled token, a step back, a repeated position): the pass that was started
+    in vain must leave nothing behind -- rows and K / V rows equal to the per-call path's -- and every miss doubles the run of matching calls it takes
+    to speculate again."""
+    g = pkg.BiogptModel.load(files["q5_1"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 5, 6, 7, 8]
+
+    def pick(k, row, n_past):
+        tok = int(row.argmax())
+        if k in (9, 30, 31, 75):
+            tok = int(np.argsort(row)[-2])         # second best: not what the launch went ahead with
+        if k == 50:
+            n_past -= 3                            # step back: the position the running pass assumed is not the one asked for
+        return tok, n_past
+
+    need = [g.resident_stats()["need"]]
+    rows, calls = _run(g, prompt, 140, pick, lambda k, row: need.append(g.resident_stats()["need"]))
+    st = g.resident_stats()
+    print("speculation:", st, sorted(set(need)))
+    D = KW["d_model"]
+    n_past = calls[-1][1] + 1
+    kv = [g.read_kv(which, 0, n_past * D) for which in (0, 1)]      # layer 0, every position written so far
+    assert g.xpipe_state() == 1
+    g.close()
+    u = _plain(pkg, files["q5_1"], monkeypatch)
+    rows_u, calls_u = _run(u, prompt, 140, pick)
+    assert calls == calls_u
+    for k, (a, b) in enumerate(zip(rows, rows_u)):
+        assert (a == b).all(), (k, float(np.abs(a - b).max()))
+    for which in (0, 1):
+        assert (kv[which] == u.read_kv(which, 0, n_past * D)).all()
+    u.close()
+    assert st["misses"] >= 2 and st["hits"] >= 20 and need[-1] >= 4 * need[0], st
