@@ -78,6 +78,47 @@ def make_prompt(n_vocab, unit):
     return [2] + [int(v) for v in rng.integers(4, n_vocab, 3)]   # 4 ids, first is </s> = 2 (biogpt.cpp:859)
 
 
+def pmc_traffic(model_path):
+    """FETCH_SIZE and WRITE_SIZE of dec_xpipe_kernel, one rocprofv3 --pmc pass each (MI355X_MICROARCH.md, HBM: the two do not fit one pass; kernel-trace only beside
+    them).  Units: the counters are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read (the guide's correction: x 2); WRITE_SIZE is uncalibrated and
+    reported as it is.  Returns (bytes per launch = 2 x FETCH + WRITE, detail)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"):
+        raise RuntimeError("this run is itself under a profiler")
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="biogpt_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(here, "tools", "pmc_target.py"), model_path, "xpipe"]
+            subprocess.run(cmd, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), check=False)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                raise RuntimeError("no rocprofv3 database for " + counter)
+            con = sqlite3.connect(dbs[0])
+            vals = [r[0] for r in con.execute("select value from counters_collection where counter_name = ? and kernel_name like '%dec_xpipe_kernel%'", (counter,))]
+            con.close()
+            if not vals:
+                raise RuntimeError("no dec_xpipe_kernel dispatch in the " + counter + " pass")
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_b = got["FETCH_SIZE"][0] * 1024.0 * 2.0
+    write_b = got["WRITE_SIZE"][0] * 1024.0
+    detail = {"FETCH_SIZE_KiB": round(got["FETCH_SIZE"][0], 1), "WRITE_SIZE_KiB": round(got["WRITE_SIZE"][0], 1), "dispatches": got["FETCH_SIZE"][1],
+              "how": "two rocprofv3 --pmc passes (one counter each, --kernel-trace only) over tools/pmc_target.py <model> xpipe: single-token launches of dec_xpipe_kernel at 104 keys; "
+                     "bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a wide coalesced read at half, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024 (uncalibrated)"}
+    return round(fetch_b + write_b, 0), detail
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +132,7 @@ def main():
                     help="decode = headline (configs[1]); prefill = configs[2]: 512-token prompt in chunks of n_batch=8")
     ap.add_argument("--n-prompt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded cpu_baseline sample")
     args = ap.parse_args()
 
@@ -279,8 +321,8 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                # HBM bytes from PMC counters need their own rocprofv3 --pmc pass (never inside this run): the summaries of those
-                # passes are committed under profiles/ (pmc_*_r2.txt); the line itself carries no borrowed constant
+                # HBM bytes from PMC counters need their own rocprofv3 --pmc passes: two child processes after the timed work (pmc_traffic below; null when
+                # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r3.txt)
                 "traffic": None,
                 "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
                 "method": (method if quant and method else
@@ -422,6 +464,16 @@ def main():
             }
         except Exception as e:
             out["cpu_baseline_error"] = str(e)
+
+    # ---- roofline.traffic: HBM-side bytes per launch of the dominant kernel from the PMC counters, each counter in its OWN rocprofv3 pass over a small child
+    #      process (tools/pmc_target.py: 24 single-token launches of the pipelined kernel at 104 keys), after everything that is timed
+    if world == 1 and args.ftype.startswith("q") and not prefill and not args.no_pmc and "roofline" in out and "dec_xpipe" in out["roofline"].get("kernel", ""):
+        try:
+            t, detail = pmc_traffic(path)
+            out["roofline"]["traffic"] = t
+            out["roofline"]["traffic_detail"] = detail
+        except Exception as e:
+            out["roofline"]["traffic_detail"] = {"error": str(e)[:300]}
 
     if dist is not None:
         dist.barrier()

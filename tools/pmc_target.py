@@ -13,6 +13,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "prefill":
     g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
 elif len(sys.argv) > 2 and sys.argv[2] == "long":      # the pipelined launch of a 1024-key step (kernels_xlong.hip.h): graph replays at n_past = 1023
     print("T=1024", round(g.bench_decode(1023, 40) * 1e6, 2), "us per token", flush=True)
+elif len(sys.argv) > 2 and sys.argv[2] == "xpipe":     # only the XCD-pipelined single-token launch at 104 keys (bench.py's roofline.traffic pass)
+    if g.xpipe_state() == 1:
+        s, b = g.bench_matvec(11, 0, 24)
+        print(11, round(s * 1e6, 2), "us", b, "bytes", flush=True)
 else:
     for which in (6, 7, 8, 9, 10, 4) + ((11,) if g.xpipe_state() == 1 else ()):   # 11: the XCD-pipelined launch (all layers + lm_head)
         s, b = g.bench_matvec(which, 0, 48)
