@@ -398,6 +398,17 @@ def main():
                                        "note": "biogpt_hip_eval_inplace per token (the row read where the launch wrote it in pinned host memory) + 8-lane host arg-max, C++ loop; "
                                                "eval_only: the same calls without the arg-max (token fixed: what a caller that samples gets, the launch waits for every token). One resident pipelined launch per context bucket serves the calls "
                                                "(BIOGPT_HIP_RESIDENT=0: one launch per call)"}
+            # the same loop beyond 256 keys (the long-context launch in its resident form): a 300-token prompt, then 200 single-token calls at 301 .. 500 keys
+            rngl = np.random.default_rng(11)
+            prl = [2] + [int(v) for v in rngl.integers(4, hp.n_vocab, 299)]
+            model.generate_greedy(prl, n_predict, n_batch=8)
+            _, sdl = model.generate_greedy(prl, n_predict, n_batch=8)
+            model.bench_api_loop(prl, 8, 0)
+            _, sal = model.bench_api_loop(prl, n_predict, 0)
+            out["api_loop_long"] = {"contexts": "301 .. %d keys" % (300 + n_predict), "us_per_token": round(sal / n_predict * 1e6, 1),
+                                    "device_loop_us_per_token": round(sdl / n_predict * 1e6, 1), "frac_of_device_loop": round(sdl / sal, 3),
+                                    "note": "biogpt_eval per token + host arg-max as in api_loop, after a 300-token prompt (both figures include their prompt pass: one 300-token "
+                                            "eval here, 38 chunks of n_batch = 8 in the device loop -- different chunking, so the ids are not compared)"}
             out["api_loop_topk"] = {"tokens_per_s": round(n_predict / s1, 1), "frac_of_device_loop": round(n_predict / s1 / value, 3),
                                     "ids_match_device_loop": bool((np.asarray(ids1) == np.asarray(dev_ids)).all()),
                                     "note": "biogpt_eval_sample-style: eval + device top-40 per token (512 B to the host), C++ loop"}

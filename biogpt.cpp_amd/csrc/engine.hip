@@ -929,7 +929,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             lm_in_kernel = fold;
             if (host_row_done) *host_row_done = fold && host_row != nullptr;
             if (ra) {     // resident launch (biogpt_hip_eval): token 0 and its position travel in the parameter block, the following ones through the mailbox
-                if (!(fold && host_row && advance == 0 && tok_src == 1 && xp.t_cap <= 256)) BG_FAIL(false, "internal: a resident launch needs the lm_head inside the <= 256-key pipeline");
+                if (!(fold && host_row && advance == 0 && tok_src == 1 && xp.t_cap <= 1024 && (xp.t_cap <= 256 || xp.gran_l != nullptr))) BG_FAIL(false, "internal: a resident launch needs the lm_head inside the pipelined launch");
                 xp.resident = 1; xp.mbox = c->res_mbox; xp.mbox_seq0 = ra->seq0; xp.done_host = c->res_done;
                 xp.idle_ticks = (uint32_t)std::max(1, c->opt.resident_us) * 100u;
                 xp.res_tok0 = ra->tok0; xp.res_n_past0 = ra->n_past0; xp.res_dbg = c->opt.res_dbg;
@@ -1665,7 +1665,7 @@ static bool spec_wanted(const biogpt_hip_ctx *c) { return c->opt.res_spec != 0 &
 static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
     if (!ctx->opt.resident || ctx->opt.no_graph || !xpipe_lm_folds(ctx)) return 0;
     const int tmax = bucket_tmax(ctx, graph_bucket(n_past + 1));
-    if (tmax > 256 || !fused_decode_ok(ctx, tmax) || !xpipe_bucket_ok(ctx, tmax)) return 0;
+    if (!fused_decode_ok(ctx, tmax) || !xpipe_bucket_ok(ctx, tmax)) return 0;      // up to 256 keys kernels_xpipe.hip.h, beyond (<= 1024) kernels_xlong.hip.h, each in its resident form
     if (ctx->hp.n_vocab >= 0xffffff || ctx->hp.n_positions >= 0x1fff) return 0;      // the mailbox word's fields (xp_post)
     const size_t V = (size_t)ctx->hp.n_vocab;
     const volatile uint32_t *const err = reinterpret_cast<const volatile uint32_t *>(ctx->xp_err_host);

@@ -46,11 +46,48 @@ constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
 #define XL_WALL2(k) do {} while (0)
 #endif
 
+// RES (the resident instantiation, biogpt_hip_eval's loop: kernels_xpipe.hip.h, XpParams::resident): a launch that is asked to leave -- or gives up waiting, or
+// fails -- must not hand anything downstream that looks like a result, append a K / V row or write a logits row.  Here a wave whose poll fails simply ENDS
+// (s_endpgm) after raising a flag in LDS; a barrier releases the surviving waves of the workgroup (tools/microbench15.hip), and they look at the flag behind
+// every barrier that stands between a poll and something they publish (xl_live).  Nothing is ever published from data that did not arrive.
+__device__ __forceinline__ void xl_die(uint32_t *s_dead) {
+    __hip_atomic_store(s_dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (an atomic, not a volatile access: the LDS address space is inferred through it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_endpgm();
+}
+// the launch's error / quit word, as a wave-uniform value (one scalar branch, no lane masks)
+__device__ __forceinline__ bool xl_err(const XpParams &p) { return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p.ctl + 1, XP_RLX)) != 0; }
+template <bool RES>
+__device__ __forceinline__ void xl_live(uint32_t *s_dead) {
+    if constexpr (RES) {
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(s_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0) __builtin_amdgcn_endpgm();
+    }
+}
+template <bool RES, int N, int S = 1>
+__device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t *s_dead) {
+    if constexpr (!RES) { xp_sweep<N, S>(g, active, epoch, v, p); return; }
+    for (uint32_t spins = 0;; spins++) {
+        bool ok = true;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                v[k] = (uint32_t)a;
+                ok &= (uint32_t)(a >> 32) == epoch;
+            }
+        }
+        if (__all(ok)) return;
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); xl_die(s_dead); }
+        if ((spins & 255u) == 255u && xl_err(p)) xl_die(s_dead);
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // ROLE 0: workgroups 0-15 of an even XCD (LayerNorm + the 192 q / k / v rows of head `slot`, out_proj rows); 1: workgroups 16-31 of an even
 // XCD (out_proj rows only); 2: the 32 workgroups of an odd XCD (LayerNorm, fc1, fc2).  Every role is a helper for every layer.
-template <int WT, int KR, int ROLE>
+template <int WT, int KR, int ROLE, bool RES>
 __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, const int xcd, const int slot, const uint32_t epoch0, const int n_past0,
-                                       const int n_gen0) {
+                                       const int n_gen0, const uint32_t launch0) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
     static_assert(KR == 32 || KR == 64, "keys per helper: 16 ranges cover 512 / 1024 keys");
@@ -78,6 +115,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
+    uint32_t *const s_dead = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 96);      // RES: a wave of this workgroup has ended (xl_die); zeroed by the kernel
+    uint32_t *const s_spec = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 112);     // RES, workgroup 0 of XCD 0: kernels_xpipe.hip.h's s_spec
     const int n_layer = p.n_layer, n_units = 2 * n_layer, last_xcd = (n_units - 1) & 7;
     const int P = p.P;
     // helper duty: head and key range of this workgroup, the same for every layer and token
@@ -121,7 +160,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         const int T = n_past + 1;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
         if (hx_j0 < T) {
             const XpLayer &Y = p.layers[L];
             xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
@@ -130,7 +169,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             // ---- the head's query row; the new key / value rows where they belong to this range (also appended to the cache: biogpt.cpp:721-727) ----
             if (wave == 0 || (has_new && wave < 3)) {
                 uint32_t v[1];
-                xp_sweep<1>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p);
+                xl_sweep<RES, 1>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p, s_dead);
                 s_cur[tid] = __uint_as_float(v[0]);
                 if (wave != 0) {
                     float *cache = (wave == 1) ? Y.kcache : Y.vcache;
@@ -138,6 +177,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             __syncthreads();
+            xl_live<RES>(s_dead);
             XL_WALL(16);
             // ---- scores of the own keys ----
             const int ksub = tid & (LPK - 1), kidx = tid / LPK, j = hx_j0 + kidx;
@@ -177,8 +217,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     }
                     if (__all(ok)) break;
-                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 6u); break; }
-                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 6u); if (RES) xl_die(s_dead); break; }
+                    if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
@@ -231,6 +271,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 s_pv[tid] = a0 + a1;
             }
             __syncthreads();
+            xl_live<RES>(s_dead);
             if (tid < DK) {
                 double t0 = 0.0, t1 = 0.0;
 #pragma unroll
@@ -265,14 +306,15 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
                     }
                     if (__all(ok)) break;
-                    if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); break; }
-                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                    if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); if (RES) xl_die(s_dead); break; }
+                    if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
                 s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
             }
             __syncthreads();
+            xl_live<RES>(s_dead);
             XL_WALL(21);
             if (tid < DK) {
                 double t0 = 0.0, t1 = 0.0;
@@ -308,7 +350,10 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         const int n_past = n_past0 + tk;
         const int n_gen = n_gen0 + tk;
         const bool more = tk + 1 < p.n_tok;
-        if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;       // a disturbed launch drains token by token
+        if (tk > 0 && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) {       // a disturbed launch drains token by token -- a resident one ends on the spot
+            if (RES) __builtin_amdgcn_endpgm();
+            break;
+        }
         if (tk == 0) fetch_kv(0, n_past);
         // the unit weights are per-token objects: nothing of them is carried from one token to the next (register budget: 14-16 units beside
         // the lm_head's 16 would not fit)
@@ -321,7 +366,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         auto load_unit_weights = [&](const int L, const int part) __attribute__((always_inline)) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+            const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
             const XpLayer &Y = p.layers[L];
             auto sel = [&](const int unit) -> bool {      // ROLE 0: units 0-11 q/k/v, 12-13 out_proj; ROLE 1: 12-13; ROLE 2: 0-7 fc1, 8 + 2 r + it fc2
@@ -393,7 +438,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         auto stage_pre = [&](const int L) __attribute__((always_inline)) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, wave = tid >> 6;
+            const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
             const int sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
             constexpr bool own_first = FIRST;
@@ -404,9 +449,9 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (L == 0) {
                         int tok;
-                        if (tk > 0 || p.tok_src == 2) {
-                            // greedy sampler of the previous token (main.cpp:109-128, top_k = 1): arg-max over the per-block partials of its logits --
-                            // granules from the lm_head XCDs inside a multi-token launch, else the partials the previous launch left; lowest id wins ties
+                        // greedy sampler of the previous token (main.cpp:109-128, top_k = 1): arg-max over the per-block partials of its logits --
+                        // granules from the lm_head XCDs inside a multi-token launch, else the partials the previous launch left; lowest id wins ties
+                        auto sample_prev = [&]() __attribute__((always_inline)) -> int {
                             float bv = -INFINITY;
                             int bi = 0x7fffffff;
                             if (tk > 0) {
@@ -426,8 +471,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                         ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                                     }
                                     if (__all(ok)) break;
-                                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); break; }
-                                    if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                                    if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) xl_die(s_dead); break; }
+                                    if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
                                     __builtin_amdgcn_s_sleep(1);
                                 }
                                 if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
@@ -451,12 +496,71 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             }
                             if (lane == 0) { s_redf[wave] = bv; s_redi[wave] = bi; }
                             __syncthreads();
+                            xl_live<RES>(s_dead);
                             bv = s_redf[0]; bi = s_redi[0];
 #pragma unroll
                             for (int w = 1; w < NW; w++)
                                 if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
-                            tok = bi;
+                            if (bi < 0 || bi >= p.n_vocab) bi = 0;
+                            return bi;
+                        };
+                        if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                        if (RES && p.resident != 0 && tk > 0) {
+                            // resident launch (kernels_xpipe.hip.h, the same protocol): the token of this pass is the one the next biogpt_eval() call posts in the
+                            // pinned mailbox -- or, running ahead of a greedy caller, the device's own arg-max, which that post must then confirm.  Workgroup 0
+                            // decides and hands the token to the XCD's other workgroups; a wait for the host lasts at most idle_ticks, then the launch ends
+                            xp_u64 *const gt = p.samp + 2048;
+                            if (slot == 0) {
+                                const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
+                                auto wait_post = [&](uint32_t seq, int np, int &spec) __attribute__((always_inline)) -> int {
+                                    const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(p.mbox) + (size_t)(seq & 63u) * 4;
+                                    const unsigned long long t0 = wall_clock64();
+                                    for (;;) {
+                                        const xp_u64 w = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                        if ((uint32_t)(w >> 40) == (seq & 0xffffffu)) {
+                                            const int tv = (int)(w & 0xffffffu), pn = (int)((w >> 24) & 0x1fffu);
+                                            spec = (int)((w >> 37) & 1u);
+                                            return (pn == np && tv < p.n_vocab) ? tv : -1;      // anything else is the host's request to leave
+                                        }
+                                        if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) return -1;
+                                        if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return -1;
+                                        __builtin_amdgcn_s_sleep(4);
+                                    }
+                                };
+                                // a pass that was started unasked: the host's post for it is read NOW, while this workgroup waits for the pass to end anyway
+                                if (tid == 0) {
+                                    const int pending = (int)s_spec[1];
+                                    int unused = 0;
+                                    s_spec[2] = (pending < 0 || wait_post(want - 1u, n_past - 1, unused) == pending) ? 1u : 0u;
+                                }
+                                const int guess = sample_prev();       // arg-max of the previous token's logits (barriers inside: the whole workgroup)
+                                __syncthreads();                       // s_redf is reused by the helper duty
+                                if (tid == 0) {
+                                    int spec = (int)s_spec[0];
+                                    const bool ahead = (int)s_spec[1] >= 0 || spec != 0;
+                                    int got = -1;
+                                    if (s_spec[2] != 0u) {
+                                        if (p.spec_rec) __hip_atomic_store(p.spec_rec, ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                        got = ahead ? guess : wait_post(want, n_past, spec);
+                                    }
+                                    if (got >= 0) {
+                                        xp_put_local(gt, epoch, (uint32_t)got);
+                                        xp_put(gt + 1, epoch, 1u);      // the lm_head workgroups write this pass's rows only behind this word
+                                        s_spec[0] = (uint32_t)spec; s_spec[1] = ahead ? (uint32_t)guess : 0xffffffffu;
+                                    } else {
+                                        // leaving: the two words the launch's end would have written (the workgroups below end inside their polls), then the quit word
+                                        __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
+                                        __hip_atomic_store(p.ctl + 2, launch0 + 1u, XP_RLX);
+                                        xp_quit(p);
+                                    }
+                                }
+                            }
+                            uint32_t v[1];
+                            xl_sweep<RES, 1>(gt, lane == 0, epoch, v, p, s_dead);
+                            tok = __builtin_amdgcn_readfirstlane((int)v[0]);
                             if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                        } else if (tk > 0 || p.tok_src == 2) {
+                            tok = sample_prev();
                             if (slot == 0 && tid == 0) {
                                 int32_t *tokens = state_tokens(p.st);
                                 if (n_gen < p.n_positions) tokens[p.n_positions + n_gen] = tok;
@@ -464,7 +568,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             }
                             __syncthreads();       // s_redf is reused by the helper duty
                         } else {
-                            tok = state_tokens(p.st)[0];
+                            tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
                         }
                         if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
                             float e[4];
@@ -475,7 +579,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     } else if (wave < 4) {
                         uint32_t v[4];
-                        xp_sweep<4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                        xl_sweep<RES, 4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, s_dead);
                         xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                     }
                     if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;      // residual of stage C
@@ -485,6 +589,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         float4 lnw = xv, lnb = xv;
                         if (worker) { lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid]; }
                         ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                        xl_live<RES>(s_dead);
                         XL_WALL(6);
                         uint32_t ax[8];
                         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -521,7 +626,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         auto stage_post = [&](const int L) __attribute__((always_inline)) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, wave = tid >> 6;
+            const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
             const int sub = lane & 31, rsub = lane >> 5;
             constexpr bool own_first = FIRST;
             xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
@@ -530,12 +635,13 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
                     if (wave < 5) {
                         uint32_t v[1];
-                        xp_sweep<1>(G + XP_G_ATT + tid, true, epoch, v, p);
+                        xl_sweep<RES, 1>(G + XP_G_ATT + tid, true, epoch, v, p, s_dead);
                         if (tid < 256) s_xq[tid] = v[0];
                         else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
                         else s_xs[tid - 288] = v[0];
                     }
                     __syncthreads();
+                    xl_live<RES>(s_dead);
                     XL_WALL(8);
                     {
                         uint32_t ax[8];
@@ -567,13 +673,14 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
                     if (wave < 4) {
                         uint32_t v[4];
-                        xp_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
+                        xl_sweep<RES, 4, 256>(G + XP_G_X1 + tid, true, epoch, v, p, s_dead);
                         x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                         reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
                         XL_WALL2(9);
                         lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                     }
                     ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                    xl_live<RES>(s_dead);
                     XL_WALL2(10);
                     {
                         uint32_t ax[8];
@@ -631,8 +738,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                 ok &= (uint32_t)(a >> 32) == epoch;
                             }
                             if (__all(ok)) break;
-                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); break; }
-                            if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) break;
+                            if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) xl_die(s_dead); break; }
+                            if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
 #pragma unroll
@@ -641,6 +748,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         else if (tid < 256) s_hs[tid - 128] = v[NQ];
                     }
                     __syncthreads();
+                    xl_live<RES>(s_dead);
                     XL_WALL2(12);
                     {
                         float *const part = s_part + wave * F2R * DEC_PS2;
@@ -718,7 +826,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             auto load_lm = [&](const int s0, const int s1) __attribute__((always_inline)) {
                 int tid = threadIdx.x;
                 asm volatile("" : "+v"(tid));
-                const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+                const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), sub = lane & 31, rsub = lane >> 5;
 #pragma unroll
                 for (int s = 0; s < LMS; s++) {
                     if (s < s0 || s >= s1) continue;
@@ -744,16 +852,25 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
+            const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
             if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
+            // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
+            const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
+            float *const lg_dev = alt ? p.logits_alt : p.logits;
+            float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
+            if (RES && p.resident != 0 && tk > 0) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
+                uint32_t go[1];
+                xl_sweep<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, s_dead);
+            }
             if (wave < 4) {
                 uint32_t v[4];
-                xp_sweep<4, 256>(p.gran + (size_t)(n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
+                xl_sweep<RES, 4, 256>(p.gran + (size_t)(n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, s_dead);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            xl_live<RES>(s_dead);
             uint32_t ax[8];
             const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
             ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
@@ -771,8 +888,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
                 if (row < p.n_vocab) {
                     const float v = sum32_in_order(part + lane * DEC_PS);
-                    p.logits[row] = v;
-                    if (p.logits_host) p.logits_host[row] = v;
+                    if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: this workgroup's helper duties of the token are over)
+                    else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
                     best_val = v; best_idx = row;
                 }
             }
@@ -786,6 +903,22 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             constexpr int LPB = 64 / NW;
             if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
             __syncthreads();
+            if (RES && wave == 1) {
+                // the workgroup's 256 logits as ONE kilobyte of 16-byte stores each: the host's copy (write-through, pinned memory) and the device row; behind
+                // its own stores the completion word of this token (kernels_xpipe.hip.h, the same lines)
+                const int r = row0 + 4 * lane;
+                if (r + 3 < p.n_vocab) {
+                    const xp_v4f v4 = *reinterpret_cast<const xp_v4f *>(s_S + 4 * lane);
+                    if (lg_host) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(lg_host + r), "v"(v4) : "memory");
+                    *reinterpret_cast<xp_v4f *>(lg_dev + r) = v4;
+                } else {
+                    for (int j = r; j < p.n_vocab; j++) { if (lg_host) __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
+                }
+                if (p.resident != 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
             if (tid < 4) {
                 float bv = s_redf[tid * NW];
                 int bi = s_redi[tid * NW];
@@ -797,7 +930,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 }
                 const int blk = lm_rank * 4 + tid;
                 if (blk < p.lm_blocks) {
-                    p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi;
+                    if (RES && alt) { p.pmax_alt_val[blk] = bv; p.pmax_alt_idx[blk] = bi; }
+                    else { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
                     if (more) {        // the sampler of the next token runs on XCD 0
                         xp_put(p.samp + blk, epoch, __float_as_uint(bv));
                         xp_put(p.samp + 1024 + blk, epoch, (uint32_t)bi);
@@ -812,13 +946,13 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         if (xcd == last_xcd && slot == 0) {
             if (epoch0 + (uint32_t)p.n_tok > 0xF0000000u) xp_fail(p, 5u);
             __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
-            __hip_atomic_store(p.ctl + 2, __hip_atomic_load(p.ctl + 2, XP_RLX) + 1u, XP_RLX);
+            __hip_atomic_store(p.ctl + 2, launch0 + 1u, XP_RLX);      // (a resident launch that leaves early has written the same two words: XCD 0's workgroup 0)
         }
         if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { p.st->n_past = n_past0 + p.n_tok; p.st->n_gen = n_gen0 + p.n_tok; }
     }
 }
 
-template <int WT, int KR>
+template <int WT, int KR, bool RES = false>
 __global__ __launch_bounds__(512) void dec_xlong_kernel(const XpParams p) {
     constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -829,24 +963,28 @@ __global__ __launch_bounds__(512) void dec_xlong_kernel(const XpParams p) {
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
         const uint32_t t = __hip_atomic_fetch_add(p.ctl + 8 + xcc, 1u, XP_RLX);
+        const uint32_t launch = __hip_atomic_load(p.ctl + 2, XP_RLX);
         s_redi[0] = (int)xcc;
-        s_redi[1] = (int)(t - 32u * (__hip_atomic_load(p.ctl + 2, XP_RLX) - 1u));
+        s_redi[1] = (int)(t - 32u * (launch - 1u));
+        s_redi[2] = (int)launch;
+        *reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 96) = 0u;      // xl_run's s_dead
     }
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
+    const uint32_t launch0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_redi[2]);
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past0 = p.st->n_past, n_gen0 = p.st->n_gen;
+    const int n_past0 = (RES && p.resident != 0) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
     if (xcd & 1) {      // the MLP halves look GELU up in LDS
         const uint4 *src = reinterpret_cast<const uint4 *>(p.gelu_tab);
         const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
-        xl_run<WT, KR, 2>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+        xl_run<WT, KR, 2, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0, launch0);
         return;
     }
-    if (slot < 16) xl_run<WT, KR, 0>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
-    else xl_run<WT, KR, 1>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+    if (slot < 16) xl_run<WT, KR, 0, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0, launch0);
+    else xl_run<WT, KR, 1, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0, launch0);
 }
 
 }  // namespace bgk

@@ -235,3 +235,45 @@ def test_speculative_continuation_wrong_guesses(pkg, files, monkeypatch):
         assert (kv[which] == u.read_kv(which, 0, n_past * D)).all()
     u.close()
     assert st["misses"] >= 2 and st["hits"] >= 20 and need[-1] >= 4 * need[0], st
+
+
+def test_resident_launch_beyond_256_keys(pkg, files, monkeypatch):
+    """The same loop where the attention is spread over the chip (kernels_xlong.hip.h, its resident instantiation): a 290-token prompt chunk, then single-token
+    evals through 291 .. 530 keys (the 512-key launch, then the 1024-key one) -- greedy, so that the launch runs ahead of the caller -- with a deviation, a step back
+    and an idle pause on the way; rows and K / V rows equal to the per-call launches'."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    rng = np.random.default_rng(21)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 289)]
+
+    def pick(k, row, n_past):
+        tok = int(row.argmax())
+        if k in (40, 41):
+            tok = int(np.argsort(row)[-2])
+        if k == 100:
+            n_past -= 5
+        if k == 150:
+            time.sleep(0.01)
+        return tok, n_past
+
+    rows, calls = _run(g, prompt, 240, pick)
+    st = g.resident_stats()
+    print("speculation:", st)
+    D = KW["d_model"]
+    n_past = calls[-1][1] + 1
+    assert n_past > 512
+    kv = [g.read_kv(which, 0, n_past * D) for which in (0, 1)]
+    dev_row = g.read_logits()
+    assert (dev_row == rows[-1]).all()
+    assert g.xpipe_state() == 1
+    g.close()
+    u = _plain(pkg, files["q4_0"], monkeypatch)
+    rows_u, calls_u = _run(u, prompt, 240, pick)
+    assert calls == calls_u
+    for k, (a, b) in enumerate(zip(rows, rows_u)):
+        assert (a == b).all(), (k, calls[k - 1] if k else None, float(np.abs(a - b).max()))
+    for which in (0, 1):
+        assert (kv[which] == u.read_kv(which, 0, n_past * D)).all()
+    u.close()
+    assert st["hits"] >= 150 and st["misses"] >= 1, st
