@@ -305,7 +305,7 @@ struct biogpt_hip_ctx {
     uint32_t res_acc = 0;                  // sequence number of the last pass the caller asked for (its parity says which buffers hold its results)
     bool spec_pending = false;             // the live launch starts the next position on its own account
     int spec_streak = 0, spec_need = 4;    // consecutive calls whose token was the device's arg-max; how many it takes to speculate (doubles with every miss)
-    long spec_hits = 0, spec_misses = 0;
+    long spec_hits = 0, spec_misses = 0, spec_run = 0;
     double res_t_wait = 0.0, res_t_call = 0.0; long res_calls = 0;   // measurement only (BIOGPT_HIP_RES_DBG & 8)
     std::chrono::steady_clock::time_point res_t_last{};
     bool ready = false;  // weights present
@@ -1658,7 +1658,8 @@ static bool resident_stop(biogpt_hip_ctx *c) {
 }
 
 // Speculation policy: a launch runs ahead of the caller only after spec_need consecutive calls whose token WAS the device's arg-max of the row before (a greedy
-// caller: always; a sampling caller: rarely for long), and every miss doubles spec_need -- a miss costs the pass that was started in vain plus a fresh launch.
+// caller: always; a sampling caller: rarely for long), and every miss doubles spec_need (up to 64; 256 hits in a row halve it again) -- a miss costs the pass
+// that was started in vain plus a fresh launch.
 static bool spec_wanted(const biogpt_hip_ctx *c) { return c->opt.res_spec != 0 && c->spec_streak >= c->spec_need; }
 
 // one token through a resident launch; 1 = done (row in ctx->row_cur), 0 = not applicable here (caller takes the ordinary path), -2 = failure
@@ -1694,12 +1695,14 @@ static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
             if (ctx->spec_pending) {
                 if (guess != token) {      // the pass in flight is not the one the caller wants: it ends the launch (the post below would not match), a fresh one follows
                     ctx->spec_misses++;
-                    ctx->spec_need = std::min(ctx->spec_need * 2, 1 << 20);
+                    ctx->spec_need = std::min(ctx->spec_need * 2, 64);      // (0.6 ^ 64 ~ 6e-15: a sampling caller does not get there; a greedy one is back after 64 tokens)
+                    ctx->spec_run = 0;
                     if (!resident_stop(ctx)) return -2;
                     if (ctx->xp_state != 1) return 0;
                     continue;
                 }
                 ctx->spec_hits++;
+                if (++ctx->spec_run % 256 == 0) ctx->spec_need = std::max(4, ctx->spec_need / 2);      // a long run ahead of the caller earns the trust back
             }
             ctx->res_seq = seq;
             ctx->res_next++; ctx->res_left--;

@@ -152,7 +152,7 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
  * arg-max of the row before (lowest id on ties -- what std::max_element over the logits returns, main.cpp:109-128 with top_k = 1), the
  * launch starts the next position from its own arg-max while the caller still reads the row, and the next call only confirms the token
  * (any other token / position ends that launch, costs one token's time, and doubles the number of matching calls needed before the
- * next attempt; BIOGPT_HIP_SPEC=0 switches it off).  Results are the same either way.  out4 = {calls served by a pass that was already
+ * next attempt -- up to 64; BIOGPT_HIP_SPEC=0 switches it off).  Results are the same either way.  out4 = {calls served by a pass that was already
  * running, calls that named a different token than the running pass, current run of matching calls, matches needed}. */
 int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4);
 
