@@ -235,15 +235,46 @@ biogpt_vocab::id sample_from_top(std::vector<scored> &cand, double top_p, std::m
 }
 }  // namespace
 
+// biogpt.cpp:908-980.  The reference copies all n logits into (score, id) pairs and std::partial_sort's them (~0.3 ms for 42 k entries: more than a decode
+// step takes on the MI355X).  Same selection in ONE pass over the floats: the k best so far are kept in descending order (equal values: lower id first, the
+// rule of oracle/sampler.py and of the device-side top-k; the reference's partial_sort leaves ties unspecified), a block of 16 logits is only looked at when
+// its maximum beats the current k-th value.  Scaling by 1 / temp is monotone, so it is applied to the k survivors only.
 biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
                                            double temp, std::mt19937 &rng) {
     const int n = (int)vocab.id_to_token.size();
-    std::vector<scored> cand((size_t)n);
-    const double inv_t = 1.0 / temp;
-    for (int i = 0; i < n; i++) cand[(size_t)i] = scored(logits[i] * inv_t, i);
     top_k = std::max(1, std::min(top_k, n));
-    std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(), [](const scored &a, const scored &b) { return a.first > b.first; });
-    cand.resize((size_t)top_k);
+    const double inv_t = 1.0 / temp;
+    if (!(inv_t > 0.0) || top_k > 256) {      // temp <= 0 / NaN reverses or destroys the order, large k: the reference's own way
+        std::vector<scored> cand((size_t)n);
+        for (int i = 0; i < n; i++) cand[(size_t)i] = scored(logits[i] * inv_t, i);
+        std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(), [](const scored &a, const scored &b) { return a.first > b.first; });
+        cand.resize((size_t)top_k);
+        return sample_from_top(cand, top_p, rng);
+    }
+    float bv[256];
+    int bi[256];
+    int have = 0;
+    float thr = -INFINITY;      // value of the k-th best once k are held; a later (higher-id) logit must be strictly greater to enter
+    auto offer = [&](float v, int i) {
+        if (have == top_k && !(v > thr)) return;
+        if (v != v) return;      // NaN never compares greater (as in the reference's comparator)
+        int pos = have < top_k ? have : top_k - 1;
+        while (pos > 0 && bv[pos - 1] < v) { bv[pos] = bv[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
+        bv[pos] = v; bi[pos] = i;
+        if (have < top_k) have++;
+        if (have == top_k) thr = bv[top_k - 1];
+    };
+    int i = 0;
+    for (; i < n && have < top_k; i++) offer(logits[i], i);
+    for (; i + 16 <= n; i += 16) {
+        float m = logits[i];
+        for (int j = 1; j < 16; j++) m = logits[i + j] > m ? logits[i + j] : m;
+        if (m > thr)
+            for (int j = 0; j < 16; j++) offer(logits[i + j], i + j);
+    }
+    for (; i < n; i++) offer(logits[i], i);
+    std::vector<scored> cand((size_t)have);
+    for (int k = 0; k < have; k++) cand[(size_t)k] = scored(bv[k] * inv_t, bi[k]);
     return sample_from_top(cand, top_p, rng);
 }
 
