@@ -2,7 +2,7 @@
 set -x
 OUT=$PWD/gpurun_out/final_r3
 mkdir -p $OUT
-python bench.py --steps 5 --warmup 1 > $OUT/bench_r3_n1.json 2> $OUT/bench.err
+timeout 900 python bench.py --steps 5 --warmup 1 > $OUT/bench_r3_n1.json 2> $OUT/bench.err < /dev/null
 M=/tmp/biogpt_amd_bench/synthetic-L24-q4_0.bin
 export R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,6 @@ BIOGPT_BENCH_CHUNK_CALLS=1 python bench.py --workload prefill --no-cpu-baseline 
 for n in 40 103 200 300 1023; do BIOGPT_HIP_DBG=128 BIOGPT_HIP_LIB=$PWD/biogpt.cpp_amd/libbiogpt_hip_prof.so python tools/decode_timeline.py $M $n; done > $OUT/xpipe_timeline_r3.txt 2>&1
 python tools/long_context_sweep.py 63 103 255 256 300 511 512 700 1023 > $OUT/long_context_sweep_r3.txt 2>&1
 BIOGPT_HIP_XPIPE_LONG=0 python tools/long_context_sweep.py 300 511 1023 > $OUT/long_context_sweep_r3_five_launch.txt 2>&1
-python tools/api_loop_modes.py > $OUT/api_loop_modes_r3.txt 2>&1
-BIOGPT_HIP_RESIDENT=0 python tools/api_loop_modes.py > $OUT/api_loop_modes_r3_per_call_launches.txt 2>&1
+bash tools/collect_api_loop_r3.sh > /dev/null 2>&1; timeout 200 python tools/api_loop_long.py 300 200 > $OUT/api_loop_long_r3.txt 2>&1; timeout 200 python tools/api_loop_long.py 700 200 >> $OUT/api_loop_long_r3.txt 2>&1
+BIOGPT_HIP_RESIDENT=0 timeout 200 python tools/api_loop_long.py 700 200 > $OUT/api_loop_long_r3_per_call_launches.txt 2>&1
 ls -la $OUT
