@@ -8,7 +8,7 @@ res = {l: [] for l in libs}
 for r in range(reps):
     for l in libs:
         env = dict(os.environ, BIOGPT_HIP_LIB=os.path.join(root, l), BIOGPT_BENCH_SKIP_TYPES="1")
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"], env=env, capture_output=True, text=True)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res[l].append((d["value"], d["token_roofline"]["T=104"]["us_per_token"], d["api_loop"]["tokens_per_s"]))
 for l in libs:
