@@ -237,11 +237,12 @@ def test_speculative_continuation_wrong_guesses(pkg, files, monkeypatch):
     assert st["misses"] >= 2 and st["hits"] >= 20 and need[-1] >= 4 * need[0], st
 
 
-def test_resident_launch_beyond_256_keys(pkg, files, monkeypatch):
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_resident_launch_beyond_256_keys(pkg, files, monkeypatch, name):
     """The same loop where the attention is spread over the chip (kernels_xlong.hip.h, its resident instantiation): a 290-token prompt chunk, then single-token
     evals through 291 .. 530 keys (the 512-key launch, then the 1024-key one) -- greedy, so that the launch runs ahead of the caller -- with a deviation, a step back
     and an idle pause on the way; rows and K / V rows equal to the per-call launches'."""
-    g = pkg.BiogptModel.load(files["q4_0"])
+    g = pkg.BiogptModel.load(files[name])
     if g.xpipe_state() != 1:
         pytest.skip("XCD pipeline not available on this device")
     rng = np.random.default_rng(21)
@@ -268,7 +269,7 @@ def test_resident_launch_beyond_256_keys(pkg, files, monkeypatch):
     assert (dev_row == rows[-1]).all()
     assert g.xpipe_state() == 1
     g.close()
-    u = _plain(pkg, files["q4_0"], monkeypatch)
+    u = _plain(pkg, files[name], monkeypatch)
     rows_u, calls_u = _run(u, prompt, 240, pick)
     assert calls == calls_u
     for k, (a, b) in enumerate(zip(rows, rows_u)):
