@@ -411,7 +411,7 @@ def main():
                                             "eval here, 38 chunks of n_batch = 8 in the device loop -- different chunking, so the ids are not compared)"}
             out["api_loop_topk"] = {"tokens_per_s": round(n_predict / s1, 1), "frac_of_device_loop": round(n_predict / s1 / value, 3),
                                     "ids_match_device_loop": bool((np.asarray(ids1) == np.asarray(dev_ids)).all()),
-                                    "note": "biogpt_eval_sample-style: eval + device top-40 per token (512 B to the host), C++ loop"}
+                                    "note": "biogpt_eval_sample-style: biogpt_hip_eval_topk(k = 40) per token, C++ loop, next token = the first id: the resident launch + a one-pass top-40 selection over the pinned row on the host"}
         except Exception as e:  # keep the headline line even if a side measurement fails
             out["roofline_error"] = str(e)
         # configs[3]: the same workload on the other block formats (same synthetic weights, quantized by the build's own quantizer), 3

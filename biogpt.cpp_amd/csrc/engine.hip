@@ -1839,11 +1839,50 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
 
 int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) { return eval_device_impl(ctx, tokens, n, n_past, 0); }
 
+// the k largest values of a row, descending, equal values: lower index first (topk_kernel's order) -- ONE pass: a block of 16 values is only looked at when its
+// maximum beats the current k-th value.  Returns how many were found (< k only when the row holds NaNs)
+static int host_topk(const float *row, int n, int k, float *vals, int32_t *ids) {
+    int have = 0;
+    float thr = -INFINITY;
+    auto offer = [&](float v, int i) {
+        if ((have == k && !(v > thr)) || v != v) return;
+        int pos = have < k ? have : k - 1;
+        while (pos > 0 && vals[pos - 1] < v) { vals[pos] = vals[pos - 1]; ids[pos] = ids[pos - 1]; pos--; }
+        vals[pos] = v; ids[pos] = i;
+        if (have < k) have++;
+        if (have == k) thr = vals[k - 1];
+    };
+    int i = 0;
+    for (; i < n && have < k; i++) offer(row[i], i);
+    for (; i + 16 <= n; i += 16) {
+        float m = row[i];
+        for (int j = 1; j < 16; j++) m = row[i + j] > m ? row[i + j] : m;
+        if (m > thr)
+            for (int j = 0; j < 16; j++) offer(row[i + j], i + j);
+    }
+    for (; i < n; i++) offer(row[i], i);
+    return have;
+}
+
 static int eval_topk_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int32_t k, float *vals_out, int32_t *ids_out) {
     if (!vals_out || !ids_out) BG_FAIL(-1, "null output buffer");
     if (!ctx) BG_FAIL(-1, "null context");
     if (k < 1 || k > 64) BG_FAIL(-1, "k must be in [1, 64]");
     k = std::min<int32_t>(k, ctx->hp.n_vocab);
+    if (n == 1 && ctx->opt.resident && !ctx->opt.no_graph) {
+        // a loop of single-token calls: the resident launch serves it (no launch per call -- the selection kernel could not run beside it anyway), the selection
+        // runs over the pinned row on the host; the same k pairs in the same order as topk_kernel's
+        XpCallScope xp_scope(ctx);
+        clear_error();
+        if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
+        if (!ctx->res_live) HIP_TRY(-2, hipSetDevice(ctx->device));
+        const int r = resident_eval(ctx, tokens[0], n_past);
+        if (r < 0) return r;
+        if (r == 1) {
+            if (host_topk(ctx->row_cur, ctx->hp.n_vocab, k, vals_out, ids_out) == k) return k;
+            // NaNs in the row: the device path below has a defined answer for it (the position is evaluated again: same inputs, same K / V row)
+        }
+    }
     const int rc = biogpt_hip_eval_device(ctx, tokens, n, n_past);
     if (rc) return rc;
     if (!ctx->topk_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->topk_host), 64 * 8 + 16, hipHostMallocDefault));

@@ -166,8 +166,9 @@ int          biogpt_hip_synchronize(biogpt_hip_ctx *ctx);
 
 /* biogpt_eval + the top-k selection of biogpt_sample_top_k_top_p (biogpt.cpp:929-936) on the device: evaluates like
  * biogpt_hip_eval and returns the k <= 64 largest logits of the last token (descending; equal logits: lower id first)
- * and their ids -- 512 bytes over PCIe instead of the 170 KB logits row (main.cpp:98-128 only ever samples from the
- * top_k = 40 candidates).  Returns k (clamped to n_vocab) or < 0. */
+ * and their ids (main.cpp:98-128 only ever samples from the top_k = 40 candidates).  A prompt chunk: the selection runs on the device and
+ * 512 bytes instead of the 170 KB row cross PCIe.  A single token -- the caller's loop: the resident launch of biogpt_hip_eval_inplace serves
+ * the call and the same selection runs in one pass over the pinned row on the host (no launch per call).  Returns k (clamped to n_vocab) or < 0. */
 int biogpt_hip_eval_topk(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t k,
                          float *vals_out, int32_t *ids_out);
 
