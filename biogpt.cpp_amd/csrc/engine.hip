@@ -31,6 +31,7 @@
 #include "kernels_mfma.hip.h"
 #include "kernels_decode.hip.h"
 #include "kernels_fdecode.hip.h"
+#include "kernels_lmhead.hip.h"
 #include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
 #include "kernels_quant.hip.h"
 #include "model_file.h"
@@ -169,7 +170,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -199,6 +200,7 @@ struct EngineOptions {
         xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
         resident = get("BIOGPT_HIP_RESIDENT", 1);           // biogpt_hip_eval with one token: the pipelined launch stays on the device and takes the next call's token from a pinned mailbox
         res_dbg = get("BIOGPT_HIP_RES_DBG", 0);              // measurement only (kernels_xpipe.hip.h XpParams::res_dbg)
+        lm_stream = get("BIOGPT_HIP_LM_STREAM", 1);          // the stand-alone lm_head as lm_stream_kernel (0: matvec_fast_kernel<PRO_LN, EPI_LOGITS>)
         res_spec = get("BIOGPT_HIP_SPEC", 1);                // a resident launch may start the next token from its own arg-max (greedy callers; resident_eval)
         resident_us = get("BIOGPT_HIP_RESIDENT_US", 1000);   // ... for at most this long without a new token (the device is not shared meanwhile)
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
@@ -404,6 +406,17 @@ bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err
     if (p.N != 1 || opt().no_fast) return false;
     const int K = p.W.K;
     if (EPI == bgk::EPI_QKV && p.D != K) return false;
+    if constexpr (EPI == bgk::EPI_LOGITS && PRO == bgk::PRO_LN) {
+        // the single-token lm_head as one pass with all loads up front (kernels_lmhead.hip.h), when the partials are the 64-row blocks its consumers expect
+        if (WT != bgk::W_Q8_0 && K == 1024 && opt().lm_stream && opt().lm_steps == 8 && p.W.M >= 64 * 128 && (p.dbg & 0xff) == 0) {      // (Q8_0: 10.5 against 9.8 us -- stays)
+            constexpr int NB = 3;      // 64-row blocks per workgroup of 8 waves (2 x 8 and 3 / 4 x 16 waves measured: 8.9 / 6.8 / 8.4 us)
+            const int blocks = (p.W.M + 63) / 64;
+            hipLaunchKernelGGL((bgk::lm_stream_kernel<WT, NB, 8>), dim3((blocks + NB - 1) / NB), dim3(512), bgk::lm_stream_smem_bytes<NB>(), st, p);
+            err = hipGetLastError();
+            if (grid_out) *grid_out = blocks;
+            return true;
+        }
+    }
     if (K == 1024) {
         err = launch_fast_k<WT, PRO, EPI, 1024>(p, st);
     } else if (K == 4096) {

@@ -641,3 +641,27 @@ def test_xlong_with_a_position_table_that_is_no_multiple_of_the_key_ranges(pkg, 
         ids_f, _ = g.generate_greedy(toks[:250], 350, n_batch=8)
         assert len(ids_p) == 350 and list(ids_p) == list(ids_f)
     g.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q4_1", "q5_0", "q5_1"])
+def test_lm_head_stream_kernel_equals_the_block_kernel(pkg, files, monkeypatch, name):
+    """kernels_lmhead.hip.h (three 64-row blocks per workgroup, all loads up front) against matvec_fast_kernel<PRO_LN, EPI_LOGITS> (BIOGPT_HIP_LM_STREAM=0), where the
+    lm_head is a launch of its own: the five-launch decode layer (BIOGPT_HIP_XPIPE=0) -- logits rows, the top-5 selection (it reads the per-block partials) and greedy
+    ids (the sampler reads them too) -- and the last row of a prompt chunk."""
+    if name not in files:
+        pytest.skip("format not in the fixture")
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE", "0")
+    a = pkg.BiogptModel.load(files[name])
+    monkeypatch.setenv("BIOGPT_HIP_LM_STREAM", "0")
+    b = pkg.BiogptModel.load(files[name])
+    monkeypatch.delenv("BIOGPT_HIP_LM_STREAM"); monkeypatch.delenv("BIOGPT_HIP_XPIPE")
+    rng = np.random.default_rng(4)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 40)]
+    assert (a.eval(toks[:8], 0) == b.eval(toks[:8], 0)).all()
+    for n_past in range(8, 20):
+        assert (a.eval([toks[n_past]], n_past) == b.eval([toks[n_past]], n_past)).all(), n_past
+    va, ia = a.eval_topk(toks[20:23], 20, 5); vb, ib = b.eval_topk(toks[20:23], 20, 5)
+    assert list(ia) == list(ib) and (va == vb).all()
+    ga, _ = a.generate_greedy(toks[:6], 40, n_batch=8); gb, _ = b.generate_greedy(toks[:6], 40, n_batch=8)
+    assert list(ga) == list(gb)
+    a.close(); b.close()
