@@ -13,8 +13,8 @@
 
 namespace bgk {
 
-template <int NB>
-__host__ __device__ constexpr size_t lm_stream_smem_bytes() { return (size_t)NB * 64 * DEC_PS * 4; }
+// dynamic LDS: the block terms [NB * 64 rows][DEC_PS] f32, then the workgroup's weight scales [NB * 64 rows][32] (fp16 d, or half2 {d, m})
+__host__ __device__ constexpr size_t lm_stream_smem_bytes(int nb, bool q81) { return (size_t)nb * 64 * DEC_PS * 4 + (size_t)nb * 64 * 32 * (q81 ? 4 : 2); }
 
 template <int WT, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p) {
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
     constexpr int LMS = NB * 64 / (2 * NW);       // block units per lane: rows 2 NW s + 2 wave + (lane >> 5), s < LMS
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
     float *const s_part = reinterpret_cast<float *>(lm_smem);      // [NW][2 LMS rows][DEC_PS]
+    unsigned char *const s_sc = lm_smem + (size_t)NB * 64 * DEC_PS * 4;
     __shared__ double s_red[8];
     __shared__ __attribute__((aligned(16))) uint32_t s_xq[256];
     __shared__ float s_xd[32];
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
     const bool worker = tid < 256;
     const int M = p.W.M, row0 = blockIdx.x * NB * 64;
+    BG_STAMP(0);
     // ---- the column and the LayerNorm vectors FIRST (a wave's loads return in order: behind 100 KB of weights they would arrive last, and the LayerNorm -- 0.9 us of
     //      barriers and double sums -- would start when the stream is over instead of running beside it) ----
     float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
@@ -41,16 +43,41 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
         lnw = reinterpret_cast<const float4 *>(p.ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.ln_b)[tid];
     }
     asm volatile("" : "+v"(xv.x), "+v"(lnw.x), "+v"(lnb.x));      // keep them in front of the weight loads
+    // the rows' scales: one contiguous piece of the scale array (12 / 24 KB), 16 bytes per lane, through LDS -- a 2-byte load per unit costs the compute unit's
+    // memory pipeline as much as the unit's 16 weight bytes (measured: 4500 cycles until a wave's 24 loads are issued, 3300 with 12 + 2)
+    constexpr int SB = TI::q81 ? 4 : 2, NSL = (NB * 64 * 32 * SB / 16 + NW * 64 - 1) / (NW * 64);
+    const int n16 = min(NB * 64, M - row0) * 32 * SB / 16;
+    uint4 sc_stage[NSL];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.W.sc) + (size_t)row0 * 32 * SB);
+#pragma unroll
+        for (int j = 0; j < NSL; j++) {
+            sc_stage[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid + j * NW * 64 < n16) sc_stage[j] = src[tid + j * NW * 64];
+        }
+    }
+    asm volatile("" : "+v"(sc_stage[0].x));
     // ---- then every weight byte of this workgroup's rows ----
     Unit<WT> wl[LMS];
 #pragma unroll
     for (int s = 0; s < LMS; s++) {
         const int row = row0 + s * 2 * NW + wave * 2 + rsub;
-        if (row < M) load_unit<WT>(wl[s], p.W, (int64_t)row * 32 + sub);
-        else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
+        wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u;
+        if (row < M) {
+            const int64_t idx = (int64_t)row * 32 + sub;
+            wl[s].q0 = *reinterpret_cast<const uint4 *>(p.W.qs + idx * TI::qbytes);
+            if (WT == W_Q5_0 || WT == W_Q5_1) wl[s].qh = p.W.qh[idx];
+        }
     }
+    // (the scales were requested before the weights -- a wave's loads return in order, so writing them to LDS now waits for them only)
+#pragma unroll
+    for (int j = 0; j < NSL; j++)
+        if (tid + j * NW * 64 < n16) reinterpret_cast<uint4 *>(s_sc)[tid + j * NW * 64] = sc_stage[j];
+    BG_STAMP(1);
     // ---- final LayerNorm + Q8 (waves 0-3; ends with a workgroup barrier) ----
+    if (p.dbg & 32) { asm volatile("" :: "v"(xv.x)); BG_STAMP(2); }
     ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+    BG_STAMP(3);
     uint32_t ax[8];
     const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
     ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
@@ -58,21 +85,26 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
     const uint32_t axs = s_xs[sub];
     float *const part = s_part + wave * 2 * LMS * DEC_PS;
 #pragma unroll
-    for (int s = 0; s < LMS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
+    for (int s = 0; s < LMS; s++) {
+        const int lr = s * 2 * NW + wave * 2 + rsub;
+        if (TI::q81) wl[s].sc = reinterpret_cast<const uint32_t *>(s_sc)[lr * 32 + sub];
+        else wl[s].sc = reinterpret_cast<const uint16_t *>(s_sc)[lr * 32 + sub];
+        part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wl[s], ax, axd, __uint_as_float(axs), (int)axs);
+    }
+    BG_STAMP(4);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // lane < 2 LMS finishes local row (lane >> 1) 2 NW + 2 wave + (lane & 1): lanes 8 j .. 8 j + 7 hold rows of block j
-    float best_val = -INFINITY;
+    float best_val = -INFINITY, my_val = 0.0f;
     int best_idx = 0x7fffffff;
-    if (lane < 2 * LMS) {
-        const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
-        if (row < M) {
-            const float v = sum32_in_order(part + lane * DEC_PS);
-            p.out[row] = v;
-            best_val = v; best_idx = row;
-        }
+    const int my_row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+    const bool mine = lane < 2 * LMS && my_row < M;
+    if (mine) {
+        my_val = sum32_in_order(part + lane * DEC_PS);
+        best_val = my_val; best_idx = my_row;
     }
+    BG_STAMP(5);
     constexpr int LPB = 64 / NW;      // finisher lanes per 64-row block in one wave
 #pragma unroll
     for (int off = 1; off < LPB; off <<= 1) {
@@ -80,9 +112,10 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
         const int oi = __shfl_xor(best_idx, off, 64);
         if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
     }
-    if (p.pmax_val == nullptr) return;
+    if (p.pmax_val == nullptr) { if (mine) p.out[my_row] = my_val; return; }
     if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
     __syncthreads();
+    if (mine) p.out[my_row] = my_val;      // behind the barrier: in front of it the barrier would wait for the stores to land
     if (tid < NB) {
         float bv = s_redf[tid * NW];
         int bi = s_redi[tid * NW];
@@ -97,6 +130,7 @@ __global__ __launch_bounds__(NW * 64) void lm_stream_kernel(const MatvecParams p
         // fused decode step (kernels_decode.hip.h): every kernel of this step has read the position by now
         if (blk == 0 && p.st_adv != nullptr && p.adv != 0) { p.st_adv->n_past += p.adv; p.st_adv->n_gen += p.adv; }
     }
+    BG_STAMP(6);
 }
 
 }  // namespace bgk
