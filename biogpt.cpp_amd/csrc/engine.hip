@@ -408,10 +408,10 @@ bool try_launch_fast(const bgk::MatvecParams &p, hipStream_t st, hipError_t &err
     if (EPI == bgk::EPI_QKV && p.D != K) return false;
     if constexpr (EPI == bgk::EPI_LOGITS && PRO == bgk::PRO_LN) {
         // the single-token lm_head as one pass with all loads up front (kernels_lmhead.hip.h), when the partials are the 64-row blocks its consumers expect
-        if (WT != bgk::W_Q8_0 && K == 1024 && opt().lm_stream && opt().lm_steps == 8 && p.W.M >= 64 * 128 && (p.dbg & 0xff & ~32) == 0) {      // (Q8_0: 10.5 against 9.8 us -- stays)
+        if (K == 1024 && opt().lm_stream && opt().lm_steps == 8 && p.W.M >= 64 * 128 && (p.dbg & 0xff & ~32) == 0) {
             constexpr int NB = 3;      // 64-row blocks per workgroup of 8 waves (2 x 8 and 3 / 4 x 16 waves measured: 8.9 / 6.8 / 8.4 us)
             const int blocks = (p.W.M + 63) / 64;
-            hipLaunchKernelGGL((bgk::lm_stream_kernel<WT, NB, 8>), dim3((blocks + NB - 1) / NB), dim3(512), bgk::lm_stream_smem_bytes(NB, bgk::TypeInfo<WT>::q81), st, p);
+            hipLaunchKernelGGL((bgk::lm_stream_kernel<WT>), dim3((blocks + NB - 1) / NB), dim3(512), bgk::lm_stream_smem_bytes(bgk::TypeInfo<WT>::q81), st, p);
             err = hipGetLastError();
             if (grid_out) *grid_out = blocks;
             return true;
@@ -2502,7 +2502,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
         const MatSlot *mm = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
                           : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
         int grid = mv_shape(mm->type, mm->M, mm->K, tw).grid;
-        if (which == 4 && ctx->opt.lm_stream && ctx->opt.lm_steps == 8 && mm->K == 1024 && mm->type != T_Q8_0 && is_quantized(mm->type) && !ctx->opt.no_fast) grid = ((mm->M + 63) / 64 + 2) / 3;      // lm_stream_kernel's
+        if (which == 4 && ctx->opt.lm_stream && ctx->opt.lm_steps == 8 && mm->K == 1024 && is_quantized(mm->type) && !ctx->opt.no_fast) grid = ((mm->M + 63) / 64 + 2) / 3;      // lm_stream_kernel's
         std::vector<unsigned long long> h(2 * (size_t)grid * 8);
         HIP_TRY(-2, hipMemcpy(h.data(), ctx->tstamp, h.size() * 8, hipMemcpyDeviceToHost));
         const int pb = ctx->launch_parity, pa = pb ^ 1;  // B = last launch, A = the one before

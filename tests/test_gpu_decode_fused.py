@@ -643,7 +643,7 @@ def test_xlong_with_a_position_table_that_is_no_multiple_of_the_key_ranges(pkg, 
     g.close()
 
 
-@pytest.mark.parametrize("name", ["q4_0", "q4_1", "q5_0", "q5_1"])
+@pytest.mark.parametrize("name", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_lm_head_stream_kernel_equals_the_block_kernel(pkg, files, monkeypatch, name):
     """kernels_lmhead.hip.h (three 64-row blocks per workgroup, all loads up front) against matvec_fast_kernel<PRO_LN, EPI_LOGITS> (BIOGPT_HIP_LM_STREAM=0), where the
     lm_head is a launch of its own: the five-launch decode layer (BIOGPT_HIP_XPIPE=0) -- logits rows, the top-5 selection (it reads the per-block partials) and greedy
