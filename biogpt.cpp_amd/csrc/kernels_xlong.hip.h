@@ -156,7 +156,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
     };
 
     // ================= helper duty for layer L (every workgroup, every layer): biogpt.cpp:729-764 for keys [hx_j0, hx_j0 + KR) of head hx_head =================
-    auto helper = [&](const int L, const uint32_t epoch, const int n_past, const bool own_first, const bool more) __attribute__((always_inline)) {
+    auto helper = [&](const int L, const uint32_t epoch, const int n_past, const bool own_first, const bool more, const bool defer_fetch = false) __attribute__((always_inline)) {
         const int T = n_past + 1;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -339,7 +339,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         // polls, and on the layer's own XCD after stage C has published its rows: 32 KB of cache-missing loads occupy the compute unit's memory
         // pipeline for ~1.5 us, and whatever is issued behind them -- a poll (a wave's loads return in order), even a hand-off store -- waits
         // (measured: +1.9 .. 2.6 us on the chain in every earlier place)
-        if (!own_first) {
+        if (!own_first && !defer_fetch) {
             if (L + 1 < n_layer) fetch_kv(L + 1, n_past);
             else if (more) fetch_kv(0, n_past + 1);
         }
@@ -787,6 +787,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     }
                     XL_WALL2(5);
+                    if (L + 1 < n_layer) fetch_kv(L + 1, n_past);      // deferred from the helper duty: in front of the x1 poll it cost that poll 0.16 us
+                    else if (more) fetch_kv(0, n_past + 1);
                     __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit's load
                 }
             }
@@ -802,7 +804,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             // ---- walk 2: own layer, then the three layers up to the next own one -- behind each of their helper duties a third of that layer's weights ----
             for (int Lo = my_l0; Lo <= my_last; Lo += 4) {
                 if (FIRST) stage_pre(Lo);
-                helper(Lo, epoch, n_past, FIRST, more);
+                helper(Lo, epoch, n_past, FIRST, more, SECOND);      // the MLP half fetches its K / V rows behind stage E (its x1 poll comes first)
                 stage_post(Lo);
                 if (Lo < my_last) {
                     helper(Lo + 1, epoch, n_past, false, more);
