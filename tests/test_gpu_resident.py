@@ -221,6 +221,13 @@ def test_speculative_continuation_wrong_guesses(pkg, files, monkeypatch):
     rows, calls = _run(g, prompt, 140, pick, lambda k, row: need.append(g.resident_stats()["need"]))
     st = g.resident_stats()
     print("speculation:", st, sorted(set(need)))
+    # ... and a long run ahead of the caller earns the trust back: 560 more greedy calls (through the 256-, 512- and 1024-key launches) halve the threshold twice
+    row, n_more = rows[-1], calls[-1][1] + 1
+    for k in range(560):
+        row = g.eval([int(row.argmax())], n_more + k)
+    st2 = g.resident_stats()
+    print("after 560 greedy calls:", st2)
+    assert st2["misses"] == st["misses"] and st2["need"] <= st["need"] // 4 and st2["hits"] >= st["hits"] + 500, (st, st2)
     D = KW["d_model"]
     n_past = calls[-1][1] + 1
     kv = [g.read_kv(which, 0, n_past * D) for which in (0, 1)]      # layer 0, every position written so far
