@@ -9,7 +9,7 @@ import numpy as np
 import _pkg
 pkg = _pkg.load()
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-q = os.path.join(os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"), "synthetic-L24-q4_0.bin")
+q = os.path.join(os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"), "synthetic-L24-%s.bin" % (sys.argv[2] if len(sys.argv) > 2 else "q4_0"))
 g = pkg.BiogptModel.load(q, verbosity=0)
 assert g.xpipe_state() == 1, "pipeline not available"
 rng = np.random.default_rng(99)
@@ -55,4 +55,5 @@ while time.time() < t_end:
     rounds += 1; toks += len(ids) + len(api) + 64 + len(apil) + 48
     slowest = max(slowest, time.time() - t0)
 print("speculation:", g.resident_stats())
+print("format", os.path.basename(q))
 print("soak ok: %d rounds, %d tokens in %.0f s, slowest round %.3f s, pipeline state %d" % (rounds, toks, secs, slowest, g.xpipe_state()))
