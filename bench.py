@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- decode tokens/sec of the MI355X-native BioGPT engine (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W                 (N > 1 without a launcher: re-executes itself under the next line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W            (N > 1: one rank per GPU)
 
@@ -72,6 +72,21 @@ def usable_cores():
     return max(1, n)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N` turns itself into when no launcher started it (WORLD_SIZE unset): one rank per GPU of this node
+    under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Replaces the ONE biogpt_model_load of
+    main.cpp:38 by N replicas.  Returned as a list so that tests can look at it without executing it."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port if port is not None else free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def make_prompt(n_vocab, unit):
     import numpy as np
     rng = np.random.default_rng(1000 + unit)
@@ -136,6 +151,20 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded cpu_baseline sample")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher (no WORLD_SIZE in the environment): become the launcher.  BIOGPT_BENCH_SELF_LAUNCH=1 takes
+    # this branch for N = 1 too (tests on the one-GPU box); =print shows the command and stops.
+    forced = os.environ.get("BIOGPT_BENCH_SELF_LAUNCH", "")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or forced in ("1", "print")):
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        if forced == "print":
+            print(json.dumps({"self_launch": cmd}))
+            return
+        log("bench: no launcher in the environment -- starting %d rank(s): %s" % (args.gpus, " ".join(cmd)))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BIOGPT_BENCH_LAUNCHED="self")
+        env.pop("BIOGPT_BENCH_SELF_LAUNCH", None)
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)     # the ranks inherit this stdout: rank 0's JSON line stays the last line on it
+
     import numpy as np
     import torch
     import _pkg
@@ -147,15 +176,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("BIOGPT_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path on one GPU (tests)
-    if world > 1 or force_dist:
+    if world > 1 or force_dist or os.environ.get("BIOGPT_BENCH_LAUNCHED") == "self":
         dist = replicas.init_process_group("nccl")
+        # "did RCCL see N ranks": every rank says which device it bound and what the communicator reports
+        log("bench: rank %d / %d bound cuda:%d (%s), %d device(s) visible, backend %s, communicator size %d" % (
+            dist.get_rank(), world, torch.cuda.current_device(), torch.cuda.get_device_name(torch.cuda.current_device()),
+            torch.cuda.device_count(), dist.get_backend(), dist.get_world_size()))
+        force_dist = True
 
     # ---- model: rank 0 loads the file; the packed arena is broadcast (RCCL over xGMI) ----------------
     t_load0 = time.time()
@@ -401,14 +434,15 @@ def main():
             # the same loop beyond 256 keys (the long-context launch in its resident form): a 300-token prompt, then 200 single-token calls at 301 .. 500 keys
             rngl = np.random.default_rng(11)
             prl = [2] + [int(v) for v in rngl.integers(4, hp.n_vocab, 299)]
-            model.generate_greedy(prl, n_predict, n_batch=8)
-            _, sdl = model.generate_greedy(prl, n_predict, n_batch=8)
+            model.generate_greedy(prl, n_predict, n_batch=len(prl))
+            idl, sdl = model.generate_greedy(prl, n_predict, n_batch=len(prl))
             model.bench_api_loop(prl, 8, 0)
-            _, sal = model.bench_api_loop(prl, n_predict, 0)
+            ial, sal = model.bench_api_loop(prl, n_predict, 0)
             out["api_loop_long"] = {"contexts": "301 .. %d keys" % (300 + n_predict), "us_per_token": round(sal / n_predict * 1e6, 1),
                                     "device_loop_us_per_token": round(sdl / n_predict * 1e6, 1), "frac_of_device_loop": round(sdl / sal, 3),
-                                    "note": "biogpt_eval per token + host arg-max as in api_loop, after a 300-token prompt (both figures include their prompt pass: one 300-token "
-                                            "eval here, 38 chunks of n_batch = 8 in the device loop -- different chunking, so the ids are not compared)"}
+                                    "ids_match_device_loop": bool((np.asarray(ial) == np.asarray(idl)).all()),
+                                    "note": "biogpt_eval per token + host arg-max as in api_loop, after a 300-token prompt (both figures include their prompt pass; both feed the "
+                                            "prompt as ONE 300-token eval -- the device loop with n_batch = 300 -- so the ids are comparable)"}
             out["api_loop_topk"] = {"tokens_per_s": round(n_predict / s1, 1), "frac_of_device_loop": round(n_predict / s1 / value, 3),
                                     "ids_match_device_loop": bool((np.asarray(ids1) == np.asarray(dev_ids)).all()),
                                     "note": "biogpt_eval_sample-style: biogpt_hip_eval_topk(k = 40) per token, C++ loop, next token = the first id: the resident launch + a one-pass top-40 selection over the pinned row on the host"}

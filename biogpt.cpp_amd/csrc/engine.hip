@@ -2118,10 +2118,15 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     if (!resident_stop(ctx)) return -2;
     const bool use_graph = ctx->opt.no_graph == 0;
     // the device's pipeline slot, if it is free, is this call's until its final synchronisation
-    auto pl_of = [&](int b) { return xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0; };
+    // Decided ONCE per bucket, here: xpipe_usable() can take the slot over from a holder that has gone idle in the meantime, so asking again at replay
+    // time could name a graph that was never captured.  The graph replayed for a bucket is the one instantiated for it.
+    int pl_bucket[6] = {0, 0, 0, 0, 0, 0};
+    auto pl_of = [&](int b) { return pl_bucket[b]; };
     if (use_graph)  // instantiate every bucket this run will touch before the clock starts
-        for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++)
-            if (!ensure_graph(ctx, 1, b, pl_of(b))) return -2;
+        for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++) {
+            pl_bucket[b] = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;
+            if (!ensure_graph(ctx, 1, b, pl_bucket[b])) return -2;
+        }
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();

@@ -138,19 +138,17 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         if (hx_j0 <= n_past) {          // the range is, or becomes, active with this token
             const XpLayer &Y = p.layers[L];
             const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
+            // agent-scope loads (kernels_xpipe.hip.h, xp_kv_load*): the rows this workgroup appended itself come back from the XCD's L2
+            const float *kb = Y.kcache + (size_t)hx_head * P * DK, *vb = Y.vcache + (size_t)hx_head * P * DK;
+            const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, P * DK * 4), vrs = xp_kv_rsrc(vb, P * DK * 4);
             if (hx_j0 + kidx < P) {
-                const float4 *kbase = reinterpret_cast<const float4 *>(Y.kcache + (size_t)hx_head * P * DK) + (size_t)(hx_j0 + kidx) * (DK / 4) + ksub;
 #pragma unroll
-                for (int m = 0; m < NF4; m++) {
-                    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(kbase + LPK * m));
-                    kr[m] = make_float4(t4.x, t4.y, t4.z, t4.w);
-                }
+                for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4(krs, kb, ((hx_j0 + kidx) * (DK / 4) + ksub + LPK * m) * 4);
             }
-            const float *vbase = Y.vcache + (size_t)hx_head * P * DK + dd;
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int j = hx_j0 + sl + NW * k;
-                if (j < P) vr[k] = __builtin_nontemporal_load(vbase + (size_t)j * DK);
+                if (j < P) vr[k] = xp_kv_load1(vrs, vb, j * DK + dd);
             }
         }
     };

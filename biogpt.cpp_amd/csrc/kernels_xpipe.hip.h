@@ -196,6 +196,36 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
     }
 }
 
+// K / V cache rows inside a persistent launch: rows appended by EARLIER tokens of the same launch were written by another compute unit of the XCD (the
+// 192- / 256-key variants: workgroup 16 + h appends what workgroup h reads) and rows >= T are requested every token before they exist, so a line of them
+// may sit, stale, in this compute unit's L1.  The loads therefore carry agent scope (sc1: L1 is not consulted, the XCD's L2 -- where every store of the
+// launch lands -- answers), which is what a relaxed agent-scope atomic load compiles to; as buffer loads so that 16 bytes stay one instruction and the
+// compiler still counts them (vmcnt).  `nt` (what __builtin_nontemporal_load gives) is only a replacement hint: an L1 hit on a stale line stays possible.
+#ifndef XP_KV_SC1
+#define XP_KV_SC1 1
+#endif
+typedef uint32_t xp_v4u __attribute__((ext_vector_type(4)));
+constexpr int XP_CPOL_SC1 = 16;                   // gfx940+ cache-policy bits of the buffer intrinsics: 1 = sc0, 2 = nt, 16 = sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xp_kv_rsrc(const float *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00027000);      // raw buffer, 32-bit data format, offsets beyond `bytes` read 0
+}
+__device__ __forceinline__ float4 xp_kv_load4(__amdgpu_buffer_rsrc_t r, const float *base, int elem) {
+#if XP_KV_SC1
+    const xp_v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, XP_CPOL_SC1);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+#else
+    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(base + elem));
+    return make_float4(t4.x, t4.y, t4.z, t4.w);
+#endif
+}
+__device__ __forceinline__ float xp_kv_load1(__amdgpu_buffer_rsrc_t r, const float *base, int elem) {
+#if XP_KV_SC1
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, XP_CPOL_SC1));
+#else
+    return __builtin_nontemporal_load(base + elem);
+#endif
+}
+
 // a lane's 4 x int8 and the three lanes above it packed into one word (valid in lanes with lane % 4 == 0)
 __device__ __forceinline__ uint32_t xp_pack4(int8_t q) {
     const int b = (int)(uint8_t)q;
@@ -606,20 +636,17 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             float vr[NV];
             const int ksub = tid & (LPK - 1), kidx = tid / LPK;
             const int dd = tid & (DK - 1), sl = tid >> 6;
-            if (kidx < t_cap) {
-                const float4 *kbase = reinterpret_cast<const float4 *>(Y.kcache + (size_t)head * p.P * DK) + (size_t)kidx * (DK / 4) + ksub;
+            {       // agent-scope loads (xp_kv_load*): rows appended by earlier tokens of this launch are taken from the XCD's L2, never from a stale L1 line
+                const float *kb = Y.kcache + (size_t)head * p.P * DK, *vb = Y.vcache + (size_t)head * p.P * DK;
+                const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
+                if (kidx < t_cap) {
 #pragma unroll
-                for (int m = 0; m < NF4; m++) {     // L1 bypassed: rows appended by earlier tokens of this launch came through the L2
-                    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(kbase + LPK * m));
-                    kr[m] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                    for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4(krs, kb, (kidx * (DK / 4) + ksub + LPK * m) * 4);
                 }
-            }
-            {
-                const float *vbase = Y.vcache + (size_t)head * p.P * DK + dd;
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     const int j = sl + NW * k;
-                    if (j < t_cap) vr[k] = __builtin_nontemporal_load(vbase + (size_t)j * DK);
+                    if (j < t_cap) vr[k] = xp_kv_load1(vrs, vb, j * DK + dd);
                 }
             }
             if constexpr (MERGE) {

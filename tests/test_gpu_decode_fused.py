@@ -147,13 +147,67 @@ def test_biogpt_base_24_layers(pkg, oracle, base24_f32, tmp_path, name):
     os.remove(path)
 
 
+def test_biogpt_base_24_layers_beyond_256_keys(pkg, oracle, base24_f32, tmp_path):
+    """configs[1] at full depth AND long context (n_ctx = 1024 is in the metric's name): a 300-token prompt in reference chunks (biogpt_hip_eval_prompt),
+    40 single-token biogpt_eval calls of a greedy caller -- served by the long-context launch in its resident form (kernels_xlong.hip.h: every XCD takes six
+    units and the helper duty of all 24 layers) -- every row against the oracle; then the rest of the context as one chunk and the last 8 positions
+    (n_past 1016 .. 1023: the 1024-key launch with its last helper range in use) one by one.  biogpt.cpp:729-764 at 24 layers."""
+    path = str(tmp_path / "q4_0.bin")
+    pkg.quantize_file(base24_f32, path, "q4_0")
+    g = pkg.BiogptModel.load(path)
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    o = oracle.OracleModel(path, n_threads=16)
+    rng = np.random.default_rng(31)
+    ctx = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 1023)]
+    lg = g.eval_prompt(ctx[:300], 0, 8)
+    for at in range(0, 300, 8):
+        lo = o.eval(ctx[at:min(300, at + 8)], at)
+    assert float(np.abs(lg - lo).max()) <= ATOL and int(lg.argmax()) == int(lo.argmax())
+    # the caller's loop, back to back (the resident launch leaves after 1 ms without a call: the oracle's rows come afterwards)
+    rows, toks, n_past = [], [], 300
+    for k in range(40):
+        toks.append(int(lg.argmax()))
+        lg = g.eval([toks[-1]], n_past + k)
+        rows.append(lg)
+    st = g.resident_stats()
+    worst, exact = 0.0, 0
+    for k in range(40):
+        assert toks[k] == int(lo.argmax()), "step %d: the caller's arg-max is not the oracle's" % k
+        lo = o.eval([toks[k]], n_past + k)
+        worst = max(worst, float(np.abs(rows[k] - lo).max()))
+        exact += int((rows[k] == lo).all())
+    print("24 layers q4_0, 301 .. 340 keys through the resident long-context launch: worst |diff| %.2e, %d/40 rows bit-identical, speculation %s" % (worst, exact, st))
+    assert worst <= ATOL and st["hits"] >= 20, st
+    # K / V rows appended by the resident launch (layer 0 and the last layer) are the oracle's
+    K = o.kv(0)
+    for l in (0, 23):
+        for pos in (299, 300, 339):
+            got = g.read_kv(0, (l * KW["n_positions"] + pos) * KW["d_model"], KW["d_model"])
+            assert np.abs(got - K[l, pos]).max() <= ATOL
+    # fill the context up to 1016 keys (one chunk: no mask inside an eval, F1 -- the same on both sides), then the last 8 positions one token at a time
+    n_past = 340
+    g.eval_device(ctx[n_past:1016], n_past); o.eval(ctx[n_past:1016], n_past)
+    worst2, exact2 = 0.0, 0
+    for n_past in range(1016, 1024):
+        lg, lo = g.eval([ctx[n_past]], n_past), o.eval([ctx[n_past]], n_past)
+        worst2 = max(worst2, float(np.abs(lg - lo).max()))
+        exact2 += int((lg == lo).all())
+        assert int(lg.argmax()) == int(lo.argmax())
+    print("24 layers q4_0, 1017 .. 1024 keys: worst |diff| %.2e, %d/8 rows bit-identical" % (worst2, exact2))
+    assert worst2 <= ATOL
+    assert g.xpipe_state() == 1, "the pipeline was abandoned during the run"
+    g.close()
+    os.remove(path)
+
+
 def _last_json_line(text):
     lines = [ln for ln in text.strip().splitlines() if ln.strip()]
     assert lines and lines[-1].lstrip().startswith("{"), "the JSON line must be the last line on stdout:\n" + text[-600:]
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("launcher", ["env", "torchrun"])
+@pytest.mark.parametrize("launcher", ["env", "torchrun", "self"])
 def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     """configs[4] plumbing on the GPU that is here: bench.py with the real `nccl` (= RCCL) backend -- broadcast_hparams ->
     biogpt_hip_load_into a torch-owned arena -> broadcast_arena -> timed region -> max_over_ranks -- replaces the single
@@ -165,6 +219,12 @@ def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     if launcher == "env":
         env.update(BIOGPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         cmd = [sys.executable] + args
+    elif launcher == "self":
+        # `python bench.py --gpus N` with no launcher in the environment re-executes itself under torch.distributed.run (N > 1 always; N = 1 with the switch)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        env.update(BIOGPT_BENCH_SELF_LAUNCH="1")
+        cmd = [sys.executable] + args
     else:
         env.update(BIOGPT_BENCH_FORCE_DIST="1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -175,6 +235,9 @@ def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert "replicas x1" in out["config"]["parallelism"]
     assert "broadcast" in r.stderr                      # the arena went through the collective
+    if launcher == "self":
+        assert "starting 1 rank(s)" in r.stderr and "torch.distributed.run" in r.stderr
+        assert "rank 0 / 1 bound cuda:0" in r.stderr and "communicator size 1" in r.stderr and "backend nccl" in r.stderr
     rec = json.load(open(dump + ".rank0"))
     ref, _ = oracle.OracleModel(rec["model"], n_threads=16).generate_greedy(rec["prompt"], 40, n_batch=8)
     assert rec["ids"] == [int(v) for v in ref]

@@ -50,3 +50,25 @@ def test_two_rank_replica_plumbing():
     assert u0 == [0, 2, 4, 6] and u1 == [1, 3, 5, 7]   # disjoint, complete cover of the 8 prompts
     assert ids0 == ids1 and ids0[0][:4] == [0, 2, 4, 6] and ids0[1][:4] == [101, 103, 105, 107]
     assert t0 == t1 == 2.0 and tot0 == tot1 == 1600.0
+
+
+def test_bench_self_launch_command_line(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start its own N ranks (the driver's command is exactly that): the command it turns
+    itself into, without executing it (no GPU here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BIOGPT_BENCH_SELF_LAUNCH"] = "print"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["self_launch"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    # under a launcher (WORLD_SIZE set) nothing is re-executed; a mismatch between --gpus and the launcher's world size is an error, not a silent 1-GPU run
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    env2.pop("BIOGPT_BENCH_SELF_LAUNCH")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "nproc-per-node must equal --gpus" in (r2.stderr + r2.stdout)
