@@ -170,7 +170,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -203,6 +203,8 @@ struct EngineOptions {
         lm_stream = get("BIOGPT_HIP_LM_STREAM", 1);          // the stand-alone lm_head as lm_stream_kernel (0: matvec_fast_kernel<PRO_LN, EPI_LOGITS>)
         res_spec = get("BIOGPT_HIP_SPEC", 1);                // a resident launch may start the next token from its own arg-max (greedy callers; resident_eval)
         resident_us = get("BIOGPT_HIP_RESIDENT_US", 1000);   // ... for at most this long without a new token (the device is not shared meanwhile)
+        hop_place = get("BIOGPT_HIP_HOP_PLACE", 1);        // the cross-XCD hand-off regions: 1 placed by a calibration launch (xpipe_place_hops), 0 first candidate, 2 the slower one (A/B)
+        verbose = get("BIOGPT_HIP_VERBOSE", 0);
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
@@ -277,6 +279,7 @@ struct biogpt_hip_ctx {
     // XCD-pipelined decode step (kernels_xpipe.hip.h): layer table, hand-off granules, {launch counter, error word}, pinned error mirror
     bgk::XpLayer *xp_layers = nullptr;
     bgk::xp_u64 *xp_gran = nullptr;
+    bgk::xp_u64 *xp_hop = nullptr;         // the hand-off regions that cross XCDs (x1 and x of every layer): two 8 KB candidates each, xpipe_place_hops picks
     bgk::xp_u64 *xp_gran_l = nullptr;      // long-context variant (kernels_xlong.hip.h): scores and partial outputs of the key-range helpers
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
@@ -648,13 +651,14 @@ void xpipe_release(biogpt_hip_ctx *c) {
     if (c->xp_layers) (void)hipFree(c->xp_layers);
     if (c->xp_gran) (void)hipFree(c->xp_gran);
     if (c->xp_gran_l) (void)hipFree(c->xp_gran_l);
+    if (c->xp_hop) (void)hipFree(c->xp_hop);
     if (c->xp_ctl) (void)hipFree(c->xp_ctl);
     if (c->xp_samp) (void)hipFree(c->xp_samp);
     if (c->xp_err_host) (void)hipHostFree(c->xp_err_host);
     if (c->res_mbox) (void)hipHostFree(c->res_mbox);
     if (c->res_done) (void)hipHostFree(c->res_done);
     c->res_mbox = nullptr; c->res_done = nullptr;
-    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_gran_l = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
+    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_gran_l = nullptr; c->xp_hop = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
 }
 
 bool xpipe_model_ok(const biogpt_hip_ctx *c) {
@@ -679,6 +683,60 @@ bool xpipe_set_lds(biogpt_hip_ctx *c) {
     const size_t sm = bgk::xpipe_smem_bytes(c->xp_gelu_p + c->xp_gelu_n);
     if (sm <= 64 * 1024) return true;
     return bg_xpipe_set_lds(ftype_to_type(c->hp.ftype), sm) == (int)hipSuccess;     // T_* values are the kernels' WType values
+}
+
+// Where the two cross-XCD hand-offs of every layer live (XpLayer::gx1, gx).  Device memory is interleaved over the two halves of the chip in 8 KB units
+// (tools/microbench18.hip, profiles/microbench18_hop_by_address_r4.txt): a granule written on XCD a and polled on XCD b takes 0.40 us when its line is near both,
+// 0.60 us when it is far from both, 0.50 us across the halves whatever the line.  Every region therefore has TWO 8 KB-aligned candidates (neighbours: one of each
+// kind) and a calibration launch plays ping-pong over both between the XCDs of ITS hop (bgk::xp_hop_probe_kernel: the stores and polls of the real hand-off);
+// the faster one is used.  mode (BIOGPT_HIP_HOP_PLACE): 1 calibrated (default), 0 always the first candidate, 2 the slower one (A/B).
+bool xpipe_place_hops(biogpt_hip_ctx *c, std::vector<bgk::XpLayer> &tab) {
+    const int nl = c->hp.n_layer, mode = c->opt.hop_place;
+    const size_t region = 1024, bytes = (size_t)nl * 4 * region * 8 + 16384;      // [layer][x1, x][candidate][1024 granules], 16 KB-aligned
+    if (hipMalloc(&c->xp_hop, bytes) != hipSuccess || hipMemset(c->xp_hop, 0, bytes) != hipSuccess) return false;
+    bgk::xp_u64 *base = reinterpret_cast<bgk::xp_u64 *>((reinterpret_cast<uintptr_t>(c->xp_hop) + 16383) & ~(uintptr_t)16383);
+    auto cand = [&](int l, int which, int k) { return base + ((size_t)(l * 2 + which) * 2 + k) * region; };
+    std::vector<int> pick((size_t)nl * 2, 0);
+    if (mode != 0) {
+        std::vector<bgk::XpProbe> pr;
+        for (int l = 0; l < nl; l++)
+            for (int which = 0; which < 2; which++) {
+                const int src = (2 * l + which) & 7, dst = (src + 1) & 7;      // x1: unit 2 l -> 2 l + 1; x: unit 2 l + 1 -> 2 l + 2 (the last layer's output goes to every lm_head XCD: judged by the same hop)
+                for (int k = 0; k < 2; k++)
+                    for (int line = 0; line < 2; line++) pr.push_back({cand(l, which, k) + (line ? 512 + 130 : 2), src, dst});
+            }
+        bgk::XpProbe *d_pr = nullptr;
+        uint32_t *d_ctl = nullptr;
+        unsigned long long *d_ticks = nullptr;
+        const int reps = 12;
+        std::vector<unsigned long long> ticks(pr.size(), 0ull);
+        uint32_t err = 1u;
+        if (hipMalloc(&d_pr, pr.size() * sizeof(bgk::XpProbe)) == hipSuccess && hipMalloc(&d_ctl, 128) == hipSuccess && hipMalloc(&d_ticks, pr.size() * 8) == hipSuccess &&
+            hipMemcpy(d_pr, pr.data(), pr.size() * sizeof(bgk::XpProbe), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_ctl, 0, 128) == hipSuccess &&
+            hipMemset(d_ticks, 0, pr.size() * 8) == hipSuccess) {
+            hipLaunchKernelGGL(bgk::xp_hop_probe_kernel, dim3(256), dim3(64), 0, c->stream, d_pr, (int)pr.size(), reps, d_ctl, d_ticks, d_ctl + 16);
+            if (hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(ticks.data(), d_ticks, pr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                (void)hipMemcpy(&err, d_ctl + 16, 4, hipMemcpyDeviceToHost);
+        }
+        (void)hipGetLastError();
+        if (d_pr) (void)hipFree(d_pr);
+        if (d_ctl) (void)hipFree(d_ctl);
+        if (d_ticks) (void)hipFree(d_ticks);
+        if (hipMemset(c->xp_hop, 0, bytes) != hipSuccess) return false;      // the probe values must not be mistaken for granules
+        if (err == 0u) {
+            double gain = 0.0;
+            for (int r = 0; r < nl * 2; r++) {
+                unsigned long long t[2];
+                for (int k = 0; k < 2; k++) t[k] = std::max(ticks[(size_t)(r * 2 + k) * 2], ticks[(size_t)(r * 2 + k) * 2 + 1]);      // a region is as slow as its slower line
+                const int fast = t[1] < t[0] ? 1 : 0;
+                pick[(size_t)r] = mode == 2 ? 1 - fast : fast;
+                gain += (double)(t[1 - fast] - t[fast]) * 10.0 / (2.0 * reps);
+            }
+            if (c->opt.verbose > 0) fprintf(stderr, "biogpt_hip: cross-XCD hand-off regions placed by measurement: the chosen 8 KB candidates are %.0f ns per hop faster than the others (mean over %d regions)\n", gain / (nl * 2), nl * 2);
+        }   // a failed calibration keeps the first candidates: slower hops, same results
+    }
+    for (int l = 0; l < nl; l++) { tab[(size_t)l].gx1 = cand(l, 0, pick[(size_t)l * 2]); tab[(size_t)l].gx = cand(l, 1, pick[(size_t)l * 2 + 1]); }
+    return true;
 }
 
 // once per context, outside any stream capture: is this an 8-XCD x 32-CU device that places workgroup b on XCD b % 8 ?
@@ -712,6 +770,7 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
     }
     const size_t gbytes = (size_t)hp.n_layer * bgk::XP_G_LAYER * 8;
     const uint32_t ctl0[3] = {1u, 0u, 1u};   // hand-off tag, error word, launch counter
+    if (!xpipe_place_hops(c, tab)) { (void)hipGetLastError(); xpipe_release(c); return; }
     if (hipMalloc(&c->xp_layers, tab.size() * sizeof(bgk::XpLayer)) != hipSuccess || hipMalloc(&c->xp_gran, gbytes) != hipSuccess ||
         hipMalloc(&c->xp_ctl, 64) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->xp_err_host), 64, hipHostMallocDefault) != hipSuccess ||
         hipMemcpy(c->xp_layers, tab.data(), tab.size() * sizeof(bgk::XpLayer), hipMemcpyHostToDevice) != hipSuccess ||

@@ -138,17 +138,17 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         if (hx_j0 <= n_past) {          // the range is, or becomes, active with this token
             const XpLayer &Y = p.layers[L];
             const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
-            // agent-scope loads (kernels_xpipe.hip.h, xp_kv_load*): the rows this workgroup appended itself come back from the XCD's L2
+            // streaming loads (kernels_xpipe.hip.h, xp_kv_load*<false>): the rows of this range that were appended during the launch were appended by THIS workgroup
             const float *kb = Y.kcache + (size_t)hx_head * P * DK, *vb = Y.vcache + (size_t)hx_head * P * DK;
             const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, P * DK * 4), vrs = xp_kv_rsrc(vb, P * DK * 4);
             if (hx_j0 + kidx < P) {
 #pragma unroll
-                for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4(krs, kb, ((hx_j0 + kidx) * (DK / 4) + ksub + LPK * m) * 4);
+                for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4<false>(krs, kb, ((hx_j0 + kidx) * (DK / 4) + ksub + LPK * m) * 4);
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int j = hx_j0 + sl + NW * k;
-                if (j < P) vr[k] = xp_kv_load1(vrs, vb, j * DK + dd);
+                if (j < P) vr[k] = xp_kv_load1<false>(vrs, vb, j * DK + dd);
             }
         }
     };
@@ -577,7 +577,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     } else if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256>(p.layers[L - 1].gx + tid, true, epoch, v, p, s_dead);
                         xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                     }
                     if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;      // residual of stage C
@@ -656,7 +656,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         if (lane < 2 * OS) {
                             const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
                             const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
-                            xp_put(G + XP_G_X1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
+                            xp_put(p.layers[L].gx1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
                         }
                     }
                     XL_WALL(3);
@@ -671,7 +671,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
                     if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256>(G + XP_G_X1 + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256>(p.layers[L].gx1 + tid, true, epoch, v, p, s_dead);
                         x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                         reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
                         XL_WALL2(9);
@@ -780,7 +780,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             }
                             const int lr = wave * F2R + lane, row = slot * 32 + lr;
                             const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
-                            xp_put(G + XP_G_X + xp_col_slot(row), epoch, __float_as_uint(v));
+                            xp_put(p.layers[L].gx + xp_col_slot(row), epoch, __float_as_uint(v));
                             if (L == n_layer - 1) p.x_final[row] = v;
                         }
                     }
@@ -866,7 +866,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             }
             if (wave < 4) {
                 uint32_t v[4];
-                xl_sweep<RES, 4, 256>(p.gran + (size_t)(n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, s_dead);
+                xl_sweep<RES, 4, 256>(p.layers[n_layer - 1].gx + tid, true, epoch, v, p, s_dead);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);

@@ -50,14 +50,19 @@ struct XpLayer {               // one layer's constants (device memory, read wit
     const float *bqkv, *bo, *b1, *b2;
     DevMatrix Wqkv, Wo, W1, W2;
     float *kcache, *vcache;    // layer slice, head-major [H][P][64]
+    // the two hand-offs of the layer that cross XCDs, 1024 granules (8 KB) each: x1 (attention half -> MLP half) and x (the layer's output -> the next layer's XCD).
+    // Device memory is interleaved over the two halves of the chip in 8 KB units and a granule costs 0.2 us more per far side (tools/microbench18.hip: XCD a -> b
+    // over a line near both 0.40 us, far from both 0.60 us); the host therefore owns two 8 KB-aligned candidates per region and points these at the one its
+    // calibration launch found faster for THIS hop (xpipe_place_hops).
+    unsigned long long *gx1, *gx;
 };
 
 // granules of one layer
 constexpr int XP_G_QKV = 0;                    // [3072] stacked q (scaled) / k / v rows; only the rows of workgroups 16-31 are published
 constexpr int XP_G_ATT = 3072;                 // [256] 4 x int8, [32] block scale, [32] block sum
-constexpr int XP_G_X1 = XP_G_ATT + 320;        // [1024]
+constexpr int XP_G_X1 = XP_G_ATT + 320;        // [1024] (unused since round 4: XpLayer::gx1)
 constexpr int XP_G_H = XP_G_X1 + 1024;         // [1024] 4 x int8, [128] scale, [128] sum
-constexpr int XP_G_X = XP_G_H + 1280;          // [1024] the layer's OUTPUT
+constexpr int XP_G_X = XP_G_H + 1280;          // [1024] the layer's OUTPUT (unused since round 4: XpLayer::gx)
 constexpr int XP_G_LAYER = XP_G_X + 1024;
 
 struct XpParams {
@@ -196,34 +201,34 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
     }
 }
 
-// K / V cache rows inside a persistent launch: rows appended by EARLIER tokens of the same launch were written by another compute unit of the XCD (the
-// 192- / 256-key variants: workgroup 16 + h appends what workgroup h reads) and rows >= T are requested every token before they exist, so a line of them
-// may sit, stale, in this compute unit's L1.  The loads therefore carry agent scope (sc1: L1 is not consulted, the XCD's L2 -- where every store of the
-// launch lands -- answers), which is what a relaxed agent-scope atomic load compiles to; as buffer loads so that 16 bytes stay one instruction and the
-// compiler still counts them (vmcnt).  `nt` (what __builtin_nontemporal_load gives) is only a replacement hint: an L1 hit on a stale line stays possible.
-#ifndef XP_KV_SC1
-#define XP_KV_SC1 1
-#endif
+// K / V cache rows inside a persistent launch.  In the 192- / 256-key variants workgroup 16 + h appends the rows that workgroup h -- another compute unit of the
+// XCD -- reads in later tokens of the same launch, and rows >= T are requested every token before they exist, so a stale line of them may sit in the reader's
+// L1.  There (SC1 = true) the loads carry agent scope (sc1: the L1 is not consulted, the XCD's L2 -- where every store of the launch lands -- answers), which is
+// what a relaxed agent-scope atomic load compiles to; as buffer loads, so that 16 bytes stay one instruction and the compiler still counts them (vmcnt).  `nt`
+// (__builtin_nontemporal_load) is only a replacement hint: an L1 hit on a stale line stays possible.  Where the SAME workgroup appends and re-reads its rows
+// (up to 128 keys: the head computes its own q / k / v rows; kernels_xlong.hip.h: the helper that owns the key range appends) the L1 is the writer's own and
+// follows its stores (workgroup-scope coherence needs no invalidate on this target outside threadgroup-split mode): streaming loads, SC1 = false.
+// Measured (profiles/ab_kv_sc1_r4.txt): sc1 everywhere costs the single-token launch 1 % at 104 keys (280.6 -> 283.3 us) and the long-context launch 6 %
+// (366 -> 389 us at 1024 keys: 8 MB of K / V per layer); in the 192- / 256-key variants 0.9 %.
 typedef uint32_t xp_v4u __attribute__((ext_vector_type(4)));
 constexpr int XP_CPOL_SC1 = 16;                   // gfx940+ cache-policy bits of the buffer intrinsics: 1 = sc0, 2 = nt, 16 = sc1
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xp_kv_rsrc(const float *base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00027000);      // raw buffer, 32-bit data format, offsets beyond `bytes` read 0
 }
+template <bool SC1>
 __device__ __forceinline__ float4 xp_kv_load4(__amdgpu_buffer_rsrc_t r, const float *base, int elem) {
-#if XP_KV_SC1
-    const xp_v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, XP_CPOL_SC1);
-    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-#else
-    const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(base + elem));
-    return make_float4(t4.x, t4.y, t4.z, t4.w);
-#endif
+    if constexpr (SC1) {
+        const xp_v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, XP_CPOL_SC1);
+        return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    } else {
+        const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(base + elem));
+        return make_float4(t4.x, t4.y, t4.z, t4.w);
+    }
 }
+template <bool SC1>
 __device__ __forceinline__ float xp_kv_load1(__amdgpu_buffer_rsrc_t r, const float *base, int elem) {
-#if XP_KV_SC1
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, XP_CPOL_SC1));
-#else
-    return __builtin_nontemporal_load(base + elem);
-#endif
+    if constexpr (SC1) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, XP_CPOL_SC1));
+    else return __builtin_nontemporal_load(base + elem);
 }
 
 // a lane's 4 x int8 and the three lanes above it packed into one word (valid in lanes with lane % 4 == 0)
@@ -343,7 +348,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         if (tk == 0 && U == xcd && U >= 2) {      // start this XCD's first weight load when unit U - 1 starts, not all eight at once
             if (tid == 0) {
                 // the output of unit U - 2: a layer's x, or (split layers, U - 2 has U's parity) the first half's x1 / the second half's x
-                const xp_u64 *g = SPLIT ? p.gran + (size_t)(L - 1) * XP_G_LAYER + (ROLE != 2 ? XP_G_X1 : XP_G_X) : p.gran + (size_t)(L - 2) * XP_G_LAYER + XP_G_X;
+                const xp_u64 *g = SPLIT ? (ROLE != 2 ? p.layers[L - 1].gx1 : p.layers[L - 1].gx) : p.layers[L - 2].gx;
                 for (uint32_t spins = 0;; spins++) {
                     if ((uint32_t)(__hip_atomic_load(g, XP_RLX) >> 32) == epoch) break;
                     if (spins >= XP_SPIN_MAX) { xp_fail(p, 3u); break; }
@@ -567,7 +572,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             } else if (wave < 4) {
                 uint32_t v[4];
-                xp_sweep_q<RES, 4, 256>(p.gran + (size_t)(L - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, etag);
+                xp_sweep_q<RES, 4, 256>(p.layers[L - 1].gx + tid, true, epoch, v, p, etag);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
@@ -636,17 +641,18 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             float vr[NV];
             const int ksub = tid & (LPK - 1), kidx = tid / LPK;
             const int dd = tid & (DK - 1), sl = tid >> 6;
-            {       // agent-scope loads (xp_kv_load*): rows appended by earlier tokens of this launch are taken from the XCD's L2, never from a stale L1 line
+            {       // rows appended by earlier tokens of this launch: by this workgroup itself (MERGE), else by workgroup 16 + head -> agent-scope loads (xp_kv_load*)
+                constexpr bool KV_SC1 = !MERGE;
                 const float *kb = Y.kcache + (size_t)head * p.P * DK, *vb = Y.vcache + (size_t)head * p.P * DK;
                 const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
                 if (kidx < t_cap) {
 #pragma unroll
-                    for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4(krs, kb, (kidx * (DK / 4) + ksub + LPK * m) * 4);
+                    for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4<KV_SC1>(krs, kb, (kidx * (DK / 4) + ksub + LPK * m) * 4);
                 }
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     const int j = sl + NW * k;
-                    if (j < t_cap) vr[k] = xp_kv_load1(vrs, vb, j * DK + dd);
+                    if (j < t_cap) vr[k] = xp_kv_load1<KV_SC1>(vrs, vb, j * DK + dd);
                 }
             }
             if constexpr (MERGE) {
@@ -808,8 +814,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (lane < 2 * OS) {
                 const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
-                if (SPLIT) xp_put(G + XP_G_X1 + xp_col_slot(row), etag, __float_as_uint(v));       // the MLP half runs on the next XCD
-                else xp_put_local(G + XP_G_X1 + xp_col_slot(row), etag, __float_as_uint(v));
+                if (SPLIT) xp_put(Y.gx1 + xp_col_slot(row), etag, __float_as_uint(v));       // the MLP half runs on the next XCD
+                else xp_put_local(Y.gx1 + xp_col_slot(row), etag, __float_as_uint(v));
             }
         }
         XP_WALL(3);
@@ -819,7 +825,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep_q<RES, 4, 256>(G + XP_G_X1 + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 4, 256>(Y.gx1 + tid, true, epoch, v, p, etag);
             x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
             XP_WALL(9);
@@ -928,7 +934,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
                 const int lr = wave * F2R + lane, row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
-                xp_put(G + XP_G_X + xp_col_slot(row), etag, __float_as_uint(v));
+                xp_put(Y.gx + xp_col_slot(row), etag, __float_as_uint(v));
                 if (L == p.n_layer - 1) p.x_final[row] = v;
             }
         }
@@ -971,7 +977,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep_q<RES, 4, 256>(p.gran + (size_t)(p.n_layer - 1) * XP_G_LAYER + XP_G_X + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 4, 256>(p.layers[p.n_layer - 1].gx + tid, true, epoch, v, p, etag);
             xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
         ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
@@ -1132,6 +1138,34 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     }
     if (slot < 16) xp_run<WT, LPK, NW, KCAP, 0, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
     else xp_run<WT, LPK, NW, KCAP, 1, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+}
+
+// Calibration of the cross-XCD hand-off regions (xpipe_place_hops, once per context): ONE lane on XCD src and ONE on XCD dst play ping-pong over the granule at
+// `addr` (ping) and addr + 1 (pong) with the stores and polls of the real hand-offs (write-through stores, agent-scope loads); ticks[i] = 100 MHz ticks of `reps`
+// round trips.  256 workgroups: on every XCD the first arrival is the pinger of the probes that start there, the second the ponger of those that end there, all
+// others leave.  Probe values carry 0xFFFF in their upper half: no hand-off tag ever gets there (xp_run gives up at 0xF0000000); the host zeroes the regions afterwards.
+struct XpProbe { unsigned long long *addr; int32_t src, dst; };
+__global__ void xp_hop_probe_kernel(const XpProbe *pr, int n, int reps, uint32_t *tickets, unsigned long long *ticks, uint32_t *err) {
+    if (threadIdx.x != 0) return;
+    const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
+    const uint32_t role = __hip_atomic_fetch_add(tickets + xcc, 1u, XP_RLX);
+    if (role > 1u) return;
+    for (int i = 0; i < n; i++) {
+        const XpProbe q = pr[i];
+        if ((role == 0u ? q.src : q.dst) != xcc) continue;
+        xp_u64 *X = q.addr, *Y = q.addr + 1;
+        const xp_u64 base = 0xFFFF000000000000ull | ((xp_u64)i << 16);
+        const unsigned long long t0 = wall_clock64();
+        for (int r = 1; r <= reps; r++) {
+            const xp_u64 want = base + (xp_u64)r;
+            if (role == 0u) __hip_atomic_store(X, want, XP_RLX);
+            const xp_u64 *w = role == 0u ? Y : X;
+            for (uint32_t spins = 0; __hip_atomic_load(w, XP_RLX) != want; spins++)
+                if (spins > XP_SPIN_MAX || ((spins & 1023u) == 1023u && __hip_atomic_load(err, XP_RLX) != 0u)) { __hip_atomic_store(err, 1u, XP_RLX); return; }
+            if (role == 1u) __hip_atomic_store(Y, want, XP_RLX);
+        }
+        if (role == 0u) ticks[i] = wall_clock64() - t0;
+    }
 }
 
 // where workgroup b of a 256-workgroup launch runs: the host checks b % 8 once per device before it trusts the pipeline

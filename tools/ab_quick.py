@@ -1,5 +1,5 @@
 """Quick A/B of several builds of the library (interleaved processes, same box), round 4:
-    python tools/ab_quick.py [--reps R] [--points 103,300,1023] LIB [LIB ...]
+    python tools/ab_quick.py [--reps R] [--points 103,300,1023] LIB[:ENV=VALUE,...] [LIB ...]
 Each arm (own process, BIOGPT_HIP_LIB): the headline workload (200-token greedy continuation of a 4-token prompt, 10 continuations after a warm-up) and the
 graph-replayed single-token step at the given n_past points.  Prints one line per arm and run; the ids of the continuation are compared between the arms."""
 import json
@@ -52,7 +52,11 @@ ids0 = None
 res = {l: [] for l in libs}
 for r in range(reps):
     for l in libs:
-        env = dict(os.environ, BIOGPT_HIP_LIB=os.path.join(root, l))
+        lib, _, extra = l.partition(":")      # an arm is LIB or LIB:NAME=VALUE,NAME=VALUE (environment of that arm)
+        env = dict(os.environ, BIOGPT_HIP_LIB=os.path.join(root, lib))
+        for kv in extra.split(","):
+            if "=" in kv:
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
         o = subprocess.run([sys.executable, os.path.abspath(__file__), "--arm", points], env=env, capture_output=True, text=True)
         try:
             dct = json.loads(o.stdout.strip().splitlines()[-1])
