@@ -197,7 +197,7 @@ struct EngineOptions {
         qkv_waves = get("BIOGPT_HIP_QKV_WAVES", 8);
         fc1_waves = get("BIOGPT_HIP_FC1_WAVES", 8);
         attn_waves = get("BIOGPT_HIP_ATTN_WAVES", 8);
-        xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 1);   // 1: the pipeline keeps the GELU table's non-trivial slices in LDS (70 KB); the exp table's slice was measured too: no gain
+        xpipe_tables = get("BIOGPT_HIP_XPIPE_TABLES", 3);   // bit 0: the MLP halves keep the GELU table's non-trivial slices in LDS (70 KB); bit 1: the attention workgroups the exp table's (39 KB)
         resident = get("BIOGPT_HIP_RESIDENT", 1);           // biogpt_hip_eval with one token: the pipelined launch stays on the device and takes the next call's token from a pinned mailbox
         res_dbg = get("BIOGPT_HIP_RES_DBG", 0);              // measurement only (kernels_xpipe.hip.h XpParams::res_dbg)
         lm_stream = get("BIOGPT_HIP_LM_STREAM", 1);          // the stand-alone lm_head as lm_stream_kernel (0: matvec_fast_kernel<PRO_LN, EPI_LOGITS>)
@@ -286,6 +286,7 @@ struct biogpt_hip_ctx {
     uint32_t *xp_err_host = nullptr;
     bool xp_in_call = false;               // guarded by g_xp_mu: an API call of this context has taken the device's pipeline slot and has not returned yet
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
+    int xp_exp_n = 0;      // the exp table's non-zero negative slice the attention workgroups keep in LDS
     int xp_gelu_p = 0, xp_gelu_n = 0, xp_gelu_z = 0;   // the GELU table's slices every workgroup keeps in LDS (kernels_xpipe.hip.h)
     int xp_state = 0;                      // 0 not probed, 1 usable, -1 unusable on this device / model / after a failure
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
@@ -809,6 +810,16 @@ void xpipe_prepare(biogpt_hip_ctx *c) {
             if (P <= 0x7C00 && N <= 0x7C00 && bgk::xpipe_smem_bytes(P + N) <= lds_max) { c->xp_gelu_p = P; c->xp_gelu_n = N; c->xp_gelu_z = Z; }
         }
     }
+    if ((c->opt.xpipe_tables & 2) && c->xp_gelu_p + c->xp_gelu_n > 0) {
+        // ggml_soft_max's table, rebuilt exactly as upload_weights builds it: arguments are <= 0; entry [0] must be 1.0 and the entries 0 from some negative argument
+        // down to the most negative finite value; the slice in between shares the LDS region of the GELU slices (which only the MLP halves use)
+        std::vector<uint16_t> te(0x7C00);
+        for (uint32_t i = 0; i < 0x7C00; i++) te[i] = f32_to_f16(expf(f16_to_f32((uint16_t)(0x8000u + i))));
+        int N = 0x7C00;
+        while (N > 0 && te[(size_t)N - 1] == 0) N--;
+        N = (N + 7) & ~7;
+        if (f32_to_f16(expf(0.0f)) == 0x3C00 && N > 0 && N <= c->xp_gelu_p + c->xp_gelu_n) c->xp_exp_n = N;
+    }
     if (!xpipe_set_lds(c)) { (void)hipGetLastError(); xpipe_release(c); return; }
     *c->xp_err_host = 0u;
     c->xp_state = 1;
@@ -988,7 +999,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.P = P; xp.t_cap = std::min(P, (t_max + 63) & ~63);
         xp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
         xp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
-        xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z;
+        xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z; xp.exp_n = c->xp_exp_n;
         xp.x_final = c->x;
         {   // lm_head inside the launch: its 64-row blocks (= the stand-alone launch's workgroups) three per workgroup of 7 XCDs
             const MatSlot &m = c->plan.lm_head;
@@ -1667,7 +1678,7 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     (void)xpipe_check(ctx);
     ctx->xp_tripped = false;
     xpipe_release(ctx);
-    ctx->xp_state = 0; ctx->xp_gelu_p = 0; ctx->xp_gelu_n = 0; ctx->xp_gelu_z = 0;
+    ctx->xp_state = 0; ctx->xp_gelu_p = 0; ctx->xp_gelu_n = 0; ctx->xp_gelu_z = 0; ctx->xp_exp_n = 0;
     xpipe_prepare(ctx);
     return 0;
 }

@@ -340,9 +340,17 @@ __device__ __forceinline__ void expand_unit(Unit<WT> &u) {
 }
 // ... and the fp16 scale converted to f32 once (u.sc = bits of d; not for Q4_1 / Q5_1).  Q8_0 units take part too (settle_unit only
 // converts their scale).
+// Round 4: the symmetric nibble formats are settled SIGNED -- q - 8 (Q4_0) / q - 16 (Q5_0) as int8, so that the block dot is sum_j (q_j - 8) x_j itself, the same
+// integer as sum_j q_j x_j - 8 sum_j x_j: the dot then needs no block sum of the activations (one instruction per unit, and the producers of Q8_0 activations no
+// longer compute, publish and poll the sums).  Bytes 0 .. 15 (0 .. 31): (b + 0x78) ^ 0x80 = b - 8 ((b + 0x70) ^ 0x80 = b - 16) in every byte, no carry between bytes.
 template <int WT>
 __device__ __forceinline__ void settle_unit(Unit<WT> &u) {
     if constexpr (WT != W_Q8_0) expand_unit<WT>(u);
+    if constexpr (WT == W_Q4_0 || WT == W_Q5_0) {
+        constexpr uint32_t B = WT == W_Q4_0 ? 0x78787878u : 0x70707070u;
+        u.q0.x = (u.q0.x + B) ^ 0x80808080u; u.q0.y = (u.q0.y + B) ^ 0x80808080u; u.q0.z = (u.q0.z + B) ^ 0x80808080u; u.q0.w = (u.q0.w + B) ^ 0x80808080u;
+        u.q1.x = (u.q1.x + B) ^ 0x80808080u; u.q1.y = (u.q1.y + B) ^ 0x80808080u; u.q1.z = (u.q1.z + B) ^ 0x80808080u; u.q1.w = (u.q1.w + B) ^ 0x80808080u;
+    }
     // Q4_1 / Q5_1 keep {d, m} packed: two f32 would be a tenth register per unit (8-9 spilled VGPRs measured in the 256-key variant)
     if constexpr (WT != W_Q4_1 && WT != W_Q5_1) u.sc = __float_as_uint(h2f((uint16_t)u.sc));
 }
@@ -360,13 +368,7 @@ __device__ __forceinline__ float unit_dot_settled(const Unit<WT> &u, const uint3
     }
     const float dw = __uint_as_float(u.sc);
     if (WT == W_Q8_0) return __fmul_rn((float)s, __fmul_rn(dw, xd));
-    if (WT == W_Q4_0) {
-        s -= 8 * xs_i;
-        return __fmul_rn(__fmul_rn((float)s, dw), xd);
-    }
-    if (WT == W_Q5_0) {
-        s -= 16 * xs_i;
-    }
+    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn((float)s, dw), xd);      // (signed units: s is already sum_j (q_j - 8) x_j; xs_i is not used)
     return __fmul_rn(__fmul_rn(dw, xd), (float)s);      // Q5_0
 }
 

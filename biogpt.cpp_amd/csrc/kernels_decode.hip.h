@@ -104,7 +104,8 @@ __device__ __forceinline__ void q8_scales(float amax, float &d, float &id) {
 #else
 #define LN_STAMP(k) do {} while (0)
 #endif
-template <bool Q81>
+// SUM = false: the consumer's units are settled signed (kernels.hip.h, settle_unit) and need no block sums of Q8_0 activations (s_xs is then not written)
+template <bool Q81, bool SUM = true>
 __device__ __forceinline__ void ln4_q8_1024(float4 v, float4 lw, float4 lb, float eps, double *s_red, uint32_t *s_xq, float *s_xd,
                                             uint32_t *s_xs, unsigned long long *ts = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,12 +147,16 @@ __device__ __forceinline__ void ln4_q8_1024(float4 v, float4 lw, float4 lb, floa
         q8_scales(amax, d, id);
         const int q0 = (int)roundf(__fmul_rn(a, id)), q1 = (int)roundf(__fmul_rn(b, id));
         const int q2 = (int)roundf(__fmul_rn(c, id)), q3 = (int)roundf(__fmul_rn(d4, id));
-        const int isum = group8_sum(q0 + q1 + q2 + q3);
         s_xq[tid] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-        if ((lane & 7) == 0) {
-            const int blk = tid >> 3;
-            if (Q81) { s_xd[blk] = d; s_xs[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
-            else { s_xd[blk] = h2f(f2h(d)); s_xs[blk] = (uint32_t)isum; }
+        if constexpr (Q81 || SUM) {
+            const int isum = group8_sum(q0 + q1 + q2 + q3);
+            if ((lane & 7) == 0) {
+                const int blk = tid >> 3;
+                if (Q81) { s_xd[blk] = d; s_xs[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
+                else { s_xd[blk] = h2f(f2h(d)); s_xs[blk] = (uint32_t)isum; }
+            }
+        } else {
+            if ((lane & 7) == 0) s_xd[tid >> 3] = h2f(f2h(d));
         }
     }
     LN_STAMP(14);
@@ -173,13 +178,14 @@ __device__ __forceinline__ float sum32_in_order(const float *part) {
 }
 
 // quantize_row_q8_0 / q8_1 of 32 values held one per lane by an aligned group of 32 lanes
-__device__ __forceinline__ void q8_block32(float v, bool q81, int8_t &q_out, float &d_out, uint32_t &s_out) {
+__device__ __forceinline__ void q8_block32(float v, bool q81, int8_t &q_out, float &d_out, uint32_t &s_out, bool want_sum = true) {
     const float amax = group32_max(fabsf(v));
     float d, id;
     q8_scales(amax, d, id);
     const int q = (int)roundf(__fmul_rn(v, id));
-    const int isum = group32_sum(q);
     q_out = (int8_t)q;
+    if (!q81 && !want_sum) { d_out = h2f(f2h(d)); s_out = 0u; return; }      // the consumer's units are settled signed (kernels.hip.h): no block sum
+    const int isum = group32_sum(q);
     if (q81) { d_out = d; s_out = __float_as_uint(__fmul_rn((float)isum, d)); }
     else { d_out = h2f(f2h(d)); s_out = (uint32_t)isum; }
 }

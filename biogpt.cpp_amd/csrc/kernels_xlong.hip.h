@@ -63,9 +63,32 @@ __device__ __forceinline__ void xl_live(uint32_t *s_dead) {
         if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(s_dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0) __builtin_amdgcn_endpgm();
     }
 }
-template <bool RES, int N, int S = 1>
+// CROSS: a hand-off that crosses XCDs -- two passes in flight (kernels_xpipe.hip.h, xp_sweep_pipelined)
+template <bool RES, int N, int S = 1, bool CROSS = false>
 __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t *s_dead) {
-    if constexpr (!RES) { xp_sweep<N, S>(g, active, epoch, v, p); return; }
+    if constexpr (!RES) {
+        if constexpr (CROSS && XP_CROSS_PIPE != 0) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
+        else xp_sweep<N, S>(g, active, epoch, v, p);
+        return;
+    }
+    if constexpr (CROSS && XP_CROSS_PIPE != 0) {
+        xp_u64 cur[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        for (uint32_t spins = 0;; spins++) {
+            xp_u64 nxt[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < N; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
+            if (__all(ok)) return;
+            if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); xl_die(s_dead); }
+            if ((spins & 255u) == 255u && xl_err(p)) xl_die(s_dead);
+#pragma unroll
+            for (int k = 0; k < N; k++) cur[k] = nxt[k];
+        }
+    }
     for (uint32_t spins = 0;; spins++) {
         bool ok = true;
         if (active) {
@@ -79,7 +102,7 @@ __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t 
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); xl_die(s_dead); }
         if ((spins & 255u) == 255u && xl_err(p)) xl_die(s_dead);
-        __builtin_amdgcn_s_sleep(1);
+        xp_poll_pause();
     }
 }
 
@@ -167,7 +190,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             // ---- the head's query row; the new key / value rows where they belong to this range (also appended to the cache: biogpt.cpp:721-727) ----
             if (wave == 0 || (has_new && wave < 3)) {
                 uint32_t v[1];
-                xl_sweep<RES, 1>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p, s_dead);
+                xl_sweep<RES, 1, 1, true>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p, s_dead);
                 s_cur[tid] = __uint_as_float(v[0]);
                 if (wave != 0) {
                     float *cache = (wave == 1) ? Y.kcache : Y.vcache;
@@ -217,7 +240,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (__all(ok)) break;
                     if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 6u); if (RES) xl_die(s_dead); break; }
                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    xp_poll_pause();
                 }
 #pragma unroll
                 for (int k = 0; k < NSC; k++) sc[k] = (tid + NT * k < T) ? __uint_as_float(v[k]) : -INFINITY;
@@ -306,7 +329,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (__all(ok)) break;
                     if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); if (RES) xl_die(s_dead); break; }
                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    xp_poll_pause();
                 }
                 s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
                 s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
@@ -323,12 +346,12 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 }
                 const float o = (float)(t0 + t1);
                 int8_t q8; float d8; uint32_t s8;
-                q8_block32(o, TI::q81, q8, d8, s8);
+                q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
                 const uint32_t packed = xp_pack4(q8);
                 xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
                 const int blk = hx_head * 2 + (tid >> 5);
                 if ((tid & 3) == 0) xp_put(G + XP_G_ATT + hx_head * 16 + (tid >> 2), epoch, packed);
-                if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
+                if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
             }
             XL_WALL(22);
             __syncthreads();                      // s_pv is rewritten by the next helper duty
@@ -471,7 +494,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                     if (__all(ok)) break;
                                     if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) xl_die(s_dead); break; }
                                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                                    __builtin_amdgcn_s_sleep(1);
+                                    xp_poll_pause();
                                 }
                                 if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
                                 if (a1) {
@@ -577,7 +600,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     } else if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256>(p.layers[L - 1].gx + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256, true>(p.layers[L - 1].gx + tid, true, epoch, v, p, s_dead);
                         xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                     }
                     if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;      // residual of stage C
@@ -586,7 +609,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         // ================= stage A: LayerNorm -> Q8 -> the 192 q / k / v rows of head `slot`, published for the head's helpers =================
                         float4 lnw = xv, lnb = xv;
                         if (worker) { lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid]; }
-                        ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                        ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
                         xl_live<RES>(s_dead);
                         XL_WALL(6);
                         uint32_t ax[8];
@@ -633,7 +656,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
                     if (wave < 5) {
                         uint32_t v[1];
-                        xl_sweep<RES, 1>(G + XP_G_ATT + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 1, 1, true>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, s_dead);      // (the block sums travel only with Q8_1 activations)
                         if (tid < 256) s_xq[tid] = v[0];
                         else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
                         else s_xs[tid - 288] = v[0];
@@ -671,13 +694,13 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
                     if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256>(p.layers[L].gx1 + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256, true>(p.layers[L].gx1 + tid, true, epoch, v, p, s_dead);
                         x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                         reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
                         XL_WALL2(9);
                         lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                     }
-                    ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                    ln4_q8_1024<TI::q81, TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
                     xl_live<RES>(s_dead);
                     XL_WALL2(10);
                     {
@@ -709,11 +732,11 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     XL_WALL2(11);
                     if (tid < 128) {
                         int8_t q8; float d8; uint32_t s8;
-                        q8_block32(s_g[tid], TI::q81, q8, d8, s8);
+                        q8_block32(s_g[tid], TI::q81, q8, d8, s8, TI::q81);
                         const uint32_t packed = xp_pack4(q8);
                         const int blk = slot * 4 + (tid >> 5);
                         if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), epoch, packed);
-                        if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
+                        if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_H + 1152 + blk, epoch, s8); }
                     }
                     XL_WALL2(4);
                     // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
@@ -721,7 +744,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         constexpr int NQ = 1024 / NT;
                         uint32_t v[NQ + 1];
                         const xp_u64 *g = G + XP_G_H + tid;
-                        const bool tail = tid < 256;
+                        const bool tail = tid < (TI::q81 ? 256 : 128);      // scales, and with Q8_1 activations the block sums
                         for (uint32_t spins = 0;; spins++) {
                             bool ok = true;
 #pragma unroll
@@ -738,7 +761,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             if (__all(ok)) break;
                             if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) xl_die(s_dead); break; }
                             if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                            __builtin_amdgcn_s_sleep(1);
+                            xp_poll_pause();
                         }
 #pragma unroll
                         for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];
@@ -866,10 +889,10 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             }
             if (wave < 4) {
                 uint32_t v[4];
-                xl_sweep<RES, 4, 256>(p.layers[n_layer - 1].gx + tid, true, epoch, v, p, s_dead);
+                xl_sweep<RES, 4, 256, true>(p.layers[n_layer - 1].gx + tid, true, epoch, v, p, s_dead);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
-            ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
             xl_live<RES>(s_dead);
             uint32_t ax[8];
             const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);

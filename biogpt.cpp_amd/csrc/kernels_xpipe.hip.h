@@ -83,6 +83,8 @@ struct XpParams {
     const uint16_t *exp_tab, *gelu_tab;
     int32_t gelu_p, gelu_n, gelu_z;   // every workgroup keeps gelu_tab[0 .. gelu_p) and [0x8000 .. 0x8000 + gelu_n) in LDS; above: identity up to
                                //   +inf, below: the constant gelu_z down to the most negative finite value (host-checked); 0 / 0: no slice
+    int32_t exp_n;             // the attention workgroups (even XCDs: no GELU slice there) keep exp_tab[0x8000 .. 0x8000 + exp_n) in LDS: every argument of ggml_soft_max's table for
+                               //   which the entry is not 0 (host-checked: [0] = 1.0, 0 from 0x8000 + exp_n down to the most negative finite value); 0: no slice
     float *x_final;            // [1024] input of the final LayerNorm + lm_head launch (written also when the lm_head runs in here)
     // final LayerNorm + lm_head inside this launch (lm != 0): the workgroups of the XCDs that do NOT compute the last layer take
     // three 64-row blocks of the output projection each -- the blocks, and the per-block arg-max partials, of the stand-alone
@@ -142,8 +144,29 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
     __hip_atomic_store(p.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// experiment switches of the poll loops (round 4 A/B runs, profiles/xpipe_ab_r4.txt): XP_CROSS_PIPE 1 = the sweeps of the two cross-XCD hand-offs keep TWO passes
+// in flight (the next pass is requested before the previous one is looked at); XP_POLL_SLEEP = s_sleep argument between passes (0: none); XP_EXP_LDS 0 = the softmax's exp table read from global memory
+#ifndef XP_CROSS_PIPE
+#define XP_CROSS_PIPE 1
+#endif
+#ifndef XP_LOCAL_PIPE
+#define XP_LOCAL_PIPE 0
+#endif
+#ifndef XP_EXP_LDS
+#define XP_EXP_LDS 1
+#endif
+#ifndef XP_POLL_SLEEP
+#define XP_POLL_SLEEP 0
+#endif
+__device__ __forceinline__ void xp_poll_pause() {
+#if XP_POLL_SLEEP > 0
+    __builtin_amdgcn_s_sleep(XP_POLL_SLEEP);
+#endif
+}
 template <int N, int S = 1>
 __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
+template <int N, int S>
+__device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
 
 // a post of the host in the resident launch's mailbox: one word, one PCIe read.  token 24 bits (0xffffff: leave), position 13 bits, speculate-next 1 bit, sequence number 24 bits
 __host__ __device__ inline xp_u64 xp_post(uint32_t seq, int n_past, int token, int spec) {
@@ -159,12 +182,38 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
 // Sweep with a publishing tag: etag is the tag this wave publishes with (the token's epoch), or 0 once the wave has seen the error / quit word -- from
 // then on it polls nothing and publishes only tag 0, which no poller accepts: a draining launch can never hand valid-looking garbage downstream (the
 // host may be waiting for exactly that token's completion words).
-template <bool RES, int N, int S = 1>
+template <bool RES, int N, int S = 1, bool CROSS = false>
 __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t &etag) {
-    if constexpr (!RES) { xp_sweep<N, S>(g, active, epoch, v, p); return; }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
+    if constexpr (!RES) {       // ordinary launches: the plain sweep (declared below), etag stays the epoch
+        if constexpr (CROSS && XP_CROSS_PIPE != 0) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
+        else xp_sweep<N, S>(g, active, epoch, v, p);
+        return;
+    }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
     if (etag == 0u) return;
+    if constexpr (CROSS && XP_CROSS_PIPE != 0) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
+        xp_u64 cur[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        for (uint32_t spins = 0;; spins++) {
+            xp_u64 nxt[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < N; k++) { ok &= (uint32_t)(cur[k] >> 32) == epoch; }
+            if (__all(ok)) {
+#pragma unroll
+                for (int k = 0; k < N; k++) v[k] = active ? (uint32_t)cur[k] : 0u;
+                return;
+            }
+            if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
+            if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+#pragma unroll
+            for (int k = 0; k < N; k++) cur[k] = nxt[k];
+        }
+    }
     for (uint32_t spins = 0;; spins++) {
         bool ok = true;
         if (active) {
@@ -178,7 +227,28 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
         if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
-        __builtin_amdgcn_s_sleep(1);
+        xp_poll_pause();
+    }
+}
+// two passes in flight: a pass is a round trip to the memory side (0.3 - 0.4 us across XCDs); looked at one after the other, a granule that lands just behind a
+// pass's request waits a whole round trip for the next one
+template <int N, int S>
+__device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p) {
+    xp_u64 cur[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+    for (uint32_t spins = 0;; spins++) {
+        xp_u64 nxt[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
+        if (__all(ok)) return;
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
+        if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
+#pragma unroll
+        for (int k = 0; k < N; k++) cur[k] = nxt[k];
     }
 }
 // every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
@@ -197,7 +267,7 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
-        __builtin_amdgcn_s_sleep(1);
+        xp_poll_pause();
     }
 }
 
@@ -436,7 +506,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                             if (__all(ok)) break;
                             if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) etag = 0u; break; }
                             if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
-                            __builtin_amdgcn_s_sleep(1);
+                            xp_poll_pause();
                         }
                         if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
                         if (a1) {
@@ -572,7 +642,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             } else if (wave < 4) {
                 uint32_t v[4];
-                xp_sweep_q<RES, 4, 256>(p.layers[L - 1].gx + tid, true, epoch, v, p, etag);
+                xp_sweep_q<RES, 4, 256, true>(p.layers[L - 1].gx + tid, true, epoch, v, p, etag);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
@@ -608,7 +678,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 reinterpret_cast<float4 *>(s_x)[tid] = xv;
                 lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
             }
-            ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
             XP_WALL(6);
             uint32_t ax[8];
             const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -672,7 +742,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     reinterpret_cast<float4 *>(s_x)[tid] = xv;
                     lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                 }
-                ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
                 XP_WALL(6);
                 uint32_t ax[8];
                 const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -740,7 +810,14 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             XP_WALL(13);
             double sum = 0.0;
             if (kidx < T && ksub == 0) {
-                const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);   // ggml_soft_max: fp16 exp table
+                // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
+                const uint32_t ix = f2h(__fsub_rn(sc, mx)), neg = ix - 0x8000u;
+                uint16_t e16;
+                if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
+                else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
+                else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
+                else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
+                const float val = h2f(e16);
                 s_S[kidx] = val;
                 sum = (double)val;
             }
@@ -781,18 +858,18 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
                 const float o = (float)(t0 + t1);
                 int8_t q8; float d8; uint32_t s8;
-                q8_block32(o, TI::q81, q8, d8, s8);
+                q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
                 const uint32_t packed = xp_pack4(q8);
                 const int blk = head * 2 + (tid >> 5);
                 if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), etag, packed);
-                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, etag, __float_as_uint(d8)); xp_put_local(G + XP_G_ATT + 288 + blk, etag, s8); }
+                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, etag, s8); }
             }
         }
         XP_WALL(2);
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if (wave < 5) {
             uint32_t v[1];
-            xp_sweep_q<RES, 1>(G + XP_G_ATT + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 1, 1, XP_LOCAL_PIPE != 0>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, etag);      // (the block sums travel only with Q8_1 activations)
             if (tid < 256) s_xq[tid] = v[0];
             else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
             else s_xs[tid - 288] = v[0];
@@ -825,13 +902,13 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep_q<RES, 4, 256>(Y.gx1 + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 4, 256, true>(Y.gx1 + tid, true, epoch, v, p, etag);
             x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
             XP_WALL(9);
             lnw = reinterpret_cast<const float4 *>(s_ln + 2048)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 3072)[tid];
         }
-        ln4_q8_1024<TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+        ln4_q8_1024<TI::q81, TI::q81>(x1v, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
         XP_WALL(10);
         {
             uint32_t ax[8];
@@ -862,11 +939,11 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         XP_WALL(11);
         if (tid < 128) {
             int8_t q8; float d8; uint32_t s8;
-            q8_block32(s_g[tid], TI::q81, q8, d8, s8);
+            q8_block32(s_g[tid], TI::q81, q8, d8, s8, TI::q81);
             const uint32_t packed = xp_pack4(q8);
             const int blk = slot * 4 + (tid >> 5);
             if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), etag, packed);
-            if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, etag, __float_as_uint(d8)); xp_put_local(G + XP_G_H + 1152 + blk, etag, s8); }
+            if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_H + 1152 + blk, etag, s8); }
         }
         XP_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
@@ -876,9 +953,26 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
             for (int k = 0; k <= NQ; k++) v[k] = 0u;
             const xp_u64 *g = G + XP_G_H + tid;
-            const bool tail = tid < 256;
+            const bool tail = tid < (TI::q81 ? 256 : 128);      // scales, and with Q8_1 activations the block sums
+#if XP_LOCAL_PIPE
+            xp_u64 cur[NQ + 1];
+#pragma unroll
+            for (int k = 0; k < NQ; k++) cur[k] = __hip_atomic_load(g + k * NT, XP_RLX);
+            cur[NQ] = tail ? __hip_atomic_load(g + 1024, XP_RLX) : ((xp_u64)epoch << 32);
+#endif
             for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
                 bool ok = true;
+#if XP_LOCAL_PIPE
+                xp_u64 nxt[NQ + 1];
+#pragma unroll
+                for (int k = 0; k < NQ; k++) nxt[k] = __hip_atomic_load(g + k * NT, XP_RLX);
+                nxt[NQ] = tail ? __hip_atomic_load(g + 1024, XP_RLX) : ((xp_u64)epoch << 32);
+#pragma unroll
+                for (int k = 0; k <= NQ; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
+                if (!tail) v[NQ] = 0u;
+#pragma unroll
+                for (int k = 0; k <= NQ; k++) cur[k] = nxt[k];
+#else
 #pragma unroll
                 for (int k = 0; k < NQ; k++) {
                     const xp_u64 a = __hip_atomic_load(g + k * NT, XP_RLX);
@@ -890,10 +984,11 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     v[NQ] = (uint32_t)a;
                     ok &= (uint32_t)(a >> 32) == epoch;
                 }
+#endif
                 if (__all(ok)) break;
                 if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) etag = 0u; break; }
                 if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
-                __builtin_amdgcn_s_sleep(1);
+                xp_poll_pause();
             }
 #pragma unroll
             for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];
@@ -977,10 +1072,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep_q<RES, 4, 256>(p.layers[p.n_layer - 1].gx + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 4, 256, true>(p.layers[p.n_layer - 1].gx + tid, true, epoch, v, p, etag);
             xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
-        ln4_q8_1024<TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+        ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
         uint32_t ax[8];
         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
         ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
@@ -1132,6 +1227,10 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         const int np8 = p.gelu_p / 8, nn8 = p.gelu_n / 8;
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
+    }
+    if (XP_EXP_LDS != 0 && SPLIT && !(xcd & 1) && slot < 16 && p.exp_n > 0) {      // the attention workgroups: the exp table's slice where the MLP halves keep GELU's
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
+        for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
     }
     if constexpr (SPLIT) {
         if (xcd & 1) { xp_run<WT, LPK, NW, KCAP, 2, true, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0); return; }

@@ -38,10 +38,12 @@ extern "C" int bg_xpipe_launch_resident(int wt, int t_cap, size_t smem_bytes, hi
     const bgk::XpParams &xp = *static_cast<const bgk::XpParams *>(params);
     switch (wt) {
         case bgk::W_Q4_0: return (int)launch_t<bgk::W_Q4_0>(t_cap, smem_bytes, st, xp);
+#ifndef BIOGPT_HIP_ONLY_Q4_0      // (experiment builds: only the Q4_0 kernels, a quarter of the compile time)
         case bgk::W_Q4_1: return (int)launch_t<bgk::W_Q4_1>(t_cap, smem_bytes, st, xp);
         case bgk::W_Q5_0: return (int)launch_t<bgk::W_Q5_0>(t_cap, smem_bytes, st, xp);
         case bgk::W_Q5_1: return (int)launch_t<bgk::W_Q5_1>(t_cap, smem_bytes, st, xp);
         case bgk::W_Q8_0: return (int)launch_t<bgk::W_Q8_0>(t_cap, smem_bytes, st, xp);
+#endif
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -49,10 +51,12 @@ extern "C" int bg_xpipe_launch_resident(int wt, int t_cap, size_t smem_bytes, hi
 extern "C" int bg_xpipe_set_lds_resident(int wt, size_t smem_bytes) {
     switch (wt) {
         case bgk::W_Q4_0: return (int)set_lds_t<bgk::W_Q4_0>(smem_bytes);
+#ifndef BIOGPT_HIP_ONLY_Q4_0      // (experiment builds: only the Q4_0 kernels, a quarter of the compile time)
         case bgk::W_Q4_1: return (int)set_lds_t<bgk::W_Q4_1>(smem_bytes);
         case bgk::W_Q5_0: return (int)set_lds_t<bgk::W_Q5_0>(smem_bytes);
         case bgk::W_Q5_1: return (int)set_lds_t<bgk::W_Q5_1>(smem_bytes);
         case bgk::W_Q8_0: return (int)set_lds_t<bgk::W_Q8_0>(smem_bytes);
+#endif
         default: return (int)hipErrorInvalidValue;
     }
 }
