@@ -134,6 +134,45 @@ def pmc_traffic(model_path):
     return round(fetch_b + write_b, 0), detail
 
 
+def pmc_mfma_busy(model_path, pass_seconds):
+    """SQ_VALU_MFMA_BUSY_CYCLES of one 512-column prompt pass (its own rocprofv3 --pmc pass over tools/pmc_target.py <model> prefill, --kernel-trace only beside it), as a
+    fraction of the SIMD cycles of the pass: busy / (pass time x 2.4 GHz x 1024 SIMDs).  The counter sums over the SIMDs; one v_mfma_i32_16x16x32_i8 is 16 busy cycles."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"):
+        raise RuntimeError("this run is itself under a profiler")
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = tempfile.mkdtemp(prefix="biogpt_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(here, "tools", "pmc_target.py"), model_path, "prefill"]
+        subprocess.run(cmd, timeout=200, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=False)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if not dbs:
+            raise RuntimeError("no rocprofv3 database")
+        con = sqlite3.connect(dbs[0])
+        rows = list(con.execute("select kernel_name, value from counters_collection where counter_name = 'SQ_VALU_MFMA_BUSY_CYCLES'"))
+        con.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    per = {}
+    for name, v in rows:
+        if v > 0:
+            k = name.split("(")[0][-60:]
+            per[k] = per.get(k, 0.0) + v
+    busy = sum(per.values()) / 2.0      # tools/pmc_target.py runs the pass twice
+    if busy <= 0:
+        raise RuntimeError("no MFMA dispatch in the pass")
+    return {"busy_cycles_per_pass": busy, "frac_of_simd_cycles": round(busy / (pass_seconds * 2.4e9 * 1024), 4),
+            "how": "one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass (kernel-trace only beside it) over tools/pmc_target.py <model> prefill; busy cycles of every MFMA kernel of one pass / "
+                   "(pass time x 2.4 GHz x 1024 SIMDs); attention runs on the VALU (exact double sums, DESIGN 4.5) and counts as zero"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -349,7 +388,16 @@ def main():
                 per = {"fc2": {"GBps": round(nbytes2 / secs2 / 1e9, 1), "us": round(secs2 * 1e6, 3), "bytes": nbytes2, "frac": round(nbytes2 / secs2 / 1e9 / HBM_PEAK_GBS, 4)}}
                 kname = "matvec_kernel<%s,LN,GELU> (fc1 %dx%d, 24 launches/token)" % (args.ftype.upper(), hp.d_ff, hp.d_model)
             secs_lm, nbytes_lm = model.bench_matvec(4, layer=0, reps=50)    # lm_head
-            per["lm_head"] = {"GBps": round(nbytes_lm / secs_lm / 1e9, 1), "us": round(secs_lm * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lm / 1e9 / HBM_PEAK_GBS, 4)}
+            per["lm_head"] = {"GBps": round(nbytes_lm / secs_lm / 1e9, 1), "us": round(secs_lm * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lm / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "HIP events around 50 back-to-back launches on the ONE copy of the matrix the model owns: between launches its 24.6 MB stay in the 256 MB Infinity Cache, so "
+                                      "this is a fabric-side rate, not an HBM rate (a pure read of the same bytes takes 2.4 us); rocprofv3's average over the calls of a whole bench run is higher "
+                                      "(profiles/rocprofv3_kernel_stats_r4.csv: the first calls after other work are cold)"}
+            try:        # the same kernel with the weights NOT cache-resident: a different one of 14 copies of the matrix per launch (344 MB) -- the figure an "HBM roofline" means
+                secs_lc, _ = model.bench_matvec(12, layer=0, reps=56)
+                per["lm_head_cold"] = {"GBps": round(nbytes_lm / secs_lc / 1e9, 1), "us": round(secs_lc * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lc / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "weights cycled through 14 device copies (344 MB > Infinity Cache + L2s): every launch streams its 24.6 MB from HBM"}
+            except Exception as e:
+                per["lm_head_cold"] = {"error": str(e)[:200]}
             ach = nbytes / secs / 1e9
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname,
@@ -407,7 +455,17 @@ def main():
             for _ in range(3):
                 model.eval_prompt(ptoks, 0, 8, want_logits=False)
             model.synchronize()
-            out["prompt_pass"] = {"tokens_per_s": round(3 * 512 / (time.perf_counter() - t1), 1),
+            t_pass = (time.perf_counter() - t1) / 3
+            # configs[2] in the driver's line: bytes (weights once + the K / V rows each column reads and writes + activations) and int8 operations of the pass against the two peaks
+            pb = pkg.decode_bytes_per_token(hp, 512)
+            mat = hp.n_layer * (3 * hp.d_model * hp.d_model + hp.d_model * hp.d_model + 2 * hp.d_ff * hp.d_model)
+            iops = 2.0 * 512 * mat + 2.0 * hp.n_vocab * hp.d_model
+            out["prompt_pass"] = {"tokens_per_s": round(512 / t_pass, 1), "ms_per_pass": round(t_pass * 1e3, 3),
+                                  "roofline": {"bytes_per_pass": int(pb), "GBps": round(pb / t_pass / 1e9, 1), "frac_of_hbm_peak": round(pb / t_pass / 1e9 / HBM_PEAK_GBS, 4),
+                                               "int8_ops_per_pass": iops, "TOPS": round(iops / t_pass / 1e12, 1), "int8_peak_TOPS": 3944.0, "frac_of_int8_peak": round(iops / t_pass / 1e12 / 3944.0, 4),
+                                               "mfma_busy": None,
+                                               "bound": "neither peak: the chain is VALU-bound -- every v_mfma_i32_16x16x32_i8 (16 cycles) is followed by the exact per-block f32 scaling of its 4 outputs per lane "
+                                                        "(the reference's arithmetic), and the attention (exact double sums) runs on the VALU"},
                                   "note": "512-token prompt, 64 reference evals of n_batch=8 in one pass (bench.py --workload prefill is the full bench line)"}
             # the drop-in API loop as a C++ caller runs it (main.cpp:91-151: one eval call per token, sampler on the host; never
             # `value`): the whole logits row over PCIe + host arg-max, and eval + device top-40 (512 bytes over PCIe)
@@ -519,6 +577,12 @@ def main():
             out["roofline"]["traffic_detail"] = detail
         except Exception as e:
             out["roofline"]["traffic_detail"] = {"error": str(e)[:300]}
+
+    if world == 1 and not prefill and not args.no_pmc and isinstance(out.get("prompt_pass"), dict) and "roofline" in out["prompt_pass"]:
+        try:
+            out["prompt_pass"]["roofline"]["mfma_busy"] = pmc_mfma_busy(path, out["prompt_pass"]["ms_per_pass"] * 1e-3)
+        except Exception as e:
+            out["prompt_pass"]["roofline"]["mfma_busy"] = {"error": str(e)[:300]}
 
     if dist is not None:
         dist.barrier()

@@ -56,6 +56,7 @@ struct MatSlot {  // offsets of one (possibly row-fused) matrix inside the arena
     int64_t M = 0, K = 0;
     size_t qs = 0, sc = 0, qh = 0;
     size_t qs_bytes = 0, sc_bytes = 0, qh_bytes = 0;
+    size_t xq = 0, xs = 0;      // offsets in the expanded row-tiled image of the MFMA kernels (ensure_tile_images; kernels_mfma.hip.h)
 };
 
 struct LayerSlots {
@@ -598,26 +599,35 @@ hipError_t launch_lnq(const biogpt_hip_ctx *c, const float *x, int N, size_t ln_
 
 // The fixed launch sequence for N tokens at the device-resident n_past (biogpt_graph's op order).
 // lm_rows: 0 = last row only into c->logits (+ arg-max partials), else all N rows into logits_all.
-// ---- row-tiled weight image for the MFMA kernels (kernels_mfma.hip.h) -------------------------------------
-// Same offsets as the arena (an image of matrix m lives at tile_img + m.qs / m.sc / m.qh), so addressing needs no
-// second plan; built by retile_kernel from the SoA arena the first time a pass has enough columns.
+// ---- row-tiled, expanded weight image for the MFMA kernels (kernels_mfma.hip.h) ---------------------------------
+// Per block 32 int8 weights + the scale as f32 ({d, m} for Q4_1 / Q5_1): laid out matrix by matrix the first time a pass has enough columns
+// (retile_kernel, from the SoA arena); 36 / 40 bytes per block -- 340 MB for BioGPT-base Q4_0, next to 288 GB of HBM.
 bgk::DevMatrix tile_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
     bgk::DevMatrix d;
-    d.qs = c->tile_img + m.qs;
-    d.sc = c->tile_img + m.sc;
-    d.qh = reinterpret_cast<const uint32_t *>(c->tile_img + m.qh);
+    d.qs = c->tile_img + m.xq;
+    d.sc = c->tile_img + m.xs;
+    d.qh = nullptr;
     d.type = m.type; d.M = (int32_t)m.M; d.K = (int32_t)m.K;
     return d;
 }
 template <int WT>
 void retile_one(biogpt_hip_ctx *c, const MatSlot &m) {
     const int64_t n = m.M * (m.K / QK);
-    hipLaunchKernelGGL((bgk::retile_kernel<WT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_matrix(c, m),
-                       c->tile_img + m.qs, c->tile_img + m.sc, reinterpret_cast<uint32_t *>(c->tile_img + m.qh));
+    hipLaunchKernelGGL((bgk::retile_kernel<WT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_matrix(c, m), c->tile_img + m.xq, c->tile_img + m.xs);
 }
 bool ensure_tile_images(biogpt_hip_ctx *c) {
     if (c->tile_img) return true;
-    HIP_TRY(false, hipMalloc(&c->tile_img, c->plan.total));
+    size_t off = 0;
+    auto place = [&](MatSlot &m) {
+        if (!is_quantized(m.type)) return;
+        const size_t nblk = (size_t)m.M * (size_t)(m.K / QK);
+        const bool q81 = m.type == T_Q4_1 || m.type == T_Q5_1;
+        m.xq = off; off = (off + nblk * 32 + 255) & ~(size_t)255;
+        m.xs = off; off = (off + nblk * (q81 ? 8 : 4) + 255) & ~(size_t)255;
+    };
+    for (auto &L : c->plan.layers) { place(L.qkv); place(L.o); place(L.fc1); place(L.fc2); }
+    place(c->plan.lm_head);
+    HIP_TRY(false, hipMalloc(&c->tile_img, std::max<size_t>(off, 256)));
     auto one = [&](const MatSlot &m) {
         switch (m.type) {
             case T_Q4_0: retile_one<bgk::W_Q4_0>(c, m); break;
@@ -2458,8 +2468,8 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     XpCallScope xp_scope(ctx);
     clear_error();
     if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 11) BG_FAIL(-1, "bad argument");
-    if (which >= 6 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
+    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 12) BG_FAIL(-1, "bad argument");
+    if (which >= 6 && which != 12 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
     t_ctx = ctx;
@@ -2471,6 +2481,29 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
     const int32_t wt0 = ftype_to_type(hp.ftype);
     const bool chain = is_quantized(wt0) && D == 1024 && F == 4096 && D / hp.n_head == 64 && P <= 1024 &&
                        !opt().no_fast && !opt().no_chain;
+    // which == 12: the stand-alone lm_head with its weights NOT resident in the Infinity Cache: 14 copies of the matrix (Q4_0: 14 x 24.6 MB = 344 MB > 256 MB + the L2s),
+    // a different one every launch -- the figure `north_star`'s "HBM roofline" means; which == 4 reads the one copy the model owns, which stays cache-resident between launches
+    struct ColdCopies {
+        std::vector<uint8_t *> v;
+        ~ColdCopies() { for (uint8_t *q : v) if (q) (void)hipFree(q); }
+    } cold;
+    size_t cold_sc_off = 0, cold_qh_off = 0;
+    if (which == 12) {
+        const MatSlot &m = ctx->plan.lm_head;
+        cold_sc_off = (m.qs_bytes + 255) & ~(size_t)255;
+        cold_qh_off = cold_sc_off + ((m.sc_bytes + 255) & ~(size_t)255);
+        const size_t total = cold_qh_off + m.qh_bytes + 256;
+        const int ncopy = (int)std::max<size_t>(3, ((size_t)344 << 20) / std::max<size_t>(1, total) + 1);
+        for (int i = 0; i < ncopy; i++) {
+            uint8_t *q = nullptr;
+            HIP_TRY(-2, hipMalloc(&q, total));
+            cold.v.push_back(q);
+            HIP_TRY(-2, hipMemcpyAsync(q, ctx->arena + m.qs, m.qs_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (m.sc_bytes) HIP_TRY(-2, hipMemcpyAsync(q + cold_sc_off, ctx->arena + m.sc, m.sc_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (m.qh_bytes) HIP_TRY(-2, hipMemcpyAsync(q + cold_qh_off, ctx->arena + m.qh, m.qh_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    }
     auto launch = [&](int l) -> bool {
         ctx->launch_parity ^= 1;
         if (which == 11) return enqueue_decode_fused(ctx, 104, 1, 0, 0, -1, -2);   // the XCD-pipelined launch alone: all layers of one token at 104 keys, no lm_head
@@ -2530,19 +2563,23 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             bgk::MatvecParams p = mv_base(ctx, m, s);
             p.x = ctx->x; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, ctx->plan.ln_w); p.ln_b = dev_vec(ctx, ctx->plan.ln_b);
             p.out = ctx->logits; p.ldo = V; p.pmax_val = ctx->pmax_val; p.pmax_idx = ctx->pmax_idx;
+            if (which == 12) {
+                const uint8_t *q = cold.v[(size_t)l % cold.v.size()];
+                p.W.qs = q; p.W.sc = q + cold_sc_off; p.W.qh = reinterpret_cast<const uint32_t *>(q + cold_qh_off);
+            }
             HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, ctx->stream)));
         }
         return true;
     };
     const int32_t tok0 = 0;
-    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : (which >= 6 ? 103 : 0))) return -2;
+    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : (which >= 6 && which != 12 ? 103 : 0))) return -2;
     const bool stamps = (ctx->opt.dbg & 32) != 0 && which < 5;
     if (stamps) {
         if (!ctx->tstamp) HIP_TRY(-2, hipMalloc(&ctx->tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
         HIP_TRY(-2, hipMemset(ctx->tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
     }
     float ms = 0.0f;
-    if (which >= 6) {
+    if (which >= 6 && which != 12) {
         // the decode-layer kernels finish faster than the host can launch them one by one (~3.3 us per eager launch):
         // capture one sweep over the layers and time graph replays, as the decode step itself is replayed
         const int per = which == 11 ? 4 : std::max(1, hp.n_layer);
@@ -2609,7 +2646,7 @@ int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
             return 0;
         }
         if (which == 7) { *bytes_out = 2.0 * 104 * D * 4 + 4.0 * D + 1.0 * D + 8.0 * (D / 32); return 0; }   // K, V rows at 104 keys + q + Q8 output
-        if (which >= 6) {   // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
+        if (which >= 6 && which != 12) {   // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
             const MatSlot *m6 = which == 6 ? &ctx->plan.layers[0].qkv : which == 8 ? &ctx->plan.layers[0].o : which == 9 ? &ctx->plan.layers[0].fc1 : &ctx->plan.layers[0].fc2;
             *bytes_out = (double)file_row_bytes(m6->type, m6->K) * (double)m6->M + 4.0 * (double)m6->K + 4.0 * (double)m6->M;
             return 0;

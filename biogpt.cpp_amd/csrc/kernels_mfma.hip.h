@@ -7,10 +7,10 @@
 // unchanged scalar arithmetic:
 //
 //   per wave = one 16 x 16 output tile, for block b = 0 .. K/32-1 IN ORDER:
-//     A = 16 rows x 32 weights of block b      (Q4: the nibbles as they are, Q5: + the fifth bit, Q8: the bytes)
+//     A = 16 rows x 32 weights of block b      (int8 from the expanded image: Q4_0 / Q5_0 signed, q - 8 / q - 16)
 //     B = 32 activations x 16 columns          (the producer's Q8_0 / Q8_1 blocks)
 //     C = A x B (int32, zero-initialised)      -> sumi[row][col] of THIS block, 4 per lane
-//     acc[row][col] += ggml's per-type term    (sumi - 8*sum(x)) * d_w * d_x  etc. (unit_dot_quant)
+//     acc[row][col] += ggml's per-type term    (sumi - 8*sum(x)) * d_w * d_x  etc. (unit_dot_quant; sumi - 8*sum(x) IS the signed dot)
 //
 // The accumulation runs over the blocks in block order inside one lane -- the association of the reference's
 // scalar vec_dot loop -- and the integer sums are exact: results are bit-identical to the VALU kernels and to
@@ -35,94 +35,103 @@ namespace bgk {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
-// ---- row-tiled weight image ---------------------------------------------------------------------------------
+// ---- row-tiled, EXPANDED weight image (round 4) ---------------------------------------------------------------
 // src (SoA arena): qs[(row*BPR + b) * QB], sc[(row*BPR + b)], qh[(row*BPR + b)]
-// dst (image)    : index (tile*BPR + b)*16 + r  with tile = row / 16, r = row % 16   (M is a multiple of 16)
+// dst (image)    : index i = (tile*BPR + b)*16 + r  with tile = row / 16, r = row % 16   (M is a multiple of 16):
+//                  q[i * 32 .. +31]  the block's 32 weights as int8 in element order -- Q4_0: q - 8, Q5_0: q - 16 (signed: the MFMA's integer dot is then
+//                                    sum_j (q_j - 8) x_j itself, no block sum of the activations is needed), Q4_1 / Q5_1: q (0 .. 15 / 0 .. 31), Q8_0: as stored;
+//                  s[i]              the block's scale as f32 (Q4_1 / Q5_1: {d, m} as two f32)
+// Round 2's image kept the file's nibbles and fp16 scales (16 + 2 bytes per block) and every MFMA was followed by ~35 VALU instructions per lane, of which the
+// operand unpack, the fp16 -> f32 conversions of four row scales and the "- 8 sum(x)" corrections were half; they are done once, here.  The image doubles (Q4: 36 bytes
+// per block instead of 18): 340 MB for BioGPT-base, read once per prompt pass.
 template <int WT>
-__global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq, uint8_t *ds, uint32_t *dh) {
+__global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq, uint8_t *ds) {
     using TI = TypeInfo<WT>;
-    constexpr int QB = TI::qbytes, SB = TI::q81 ? 4 : 2;
+    constexpr int QB = TI::qbytes;
     const int BPR = src.K / QK;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // source block index row*BPR + b
     if (idx >= (int64_t)src.M * BPR) return;
     const int row = (int)(idx / BPR), b = (int)(idx - (int64_t)row * BPR);
     const int64_t dst = ((int64_t)(row >> 4) * BPR + b) * 16 + (row & 15);
     const uint4 *q = reinterpret_cast<const uint4 *>(src.qs + idx * QB);
-    uint4 *o = reinterpret_cast<uint4 *>(dq + dst * QB);
-    o[0] = q[0];
-    if (QB == 32) o[1] = q[1];
-    if (SB == 4) reinterpret_cast<uint32_t *>(ds)[dst] = reinterpret_cast<const uint32_t *>(src.sc)[idx];
-    else reinterpret_cast<uint16_t *>(ds)[dst] = reinterpret_cast<const uint16_t *>(src.sc)[idx];
-    if (WT == W_Q5_0 || WT == W_Q5_1) dh[dst] = src.qh[idx];
+    uint4 *o = reinterpret_cast<uint4 *>(dq + dst * 32);
+    if (WT == W_Q8_0) { o[0] = q[0]; o[1] = q[1]; }
+    else {
+        const uint4 v = q[0];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t lo[4], hi[4];
+        uint32_t qh = 0u;
+        if (WT == W_Q5_0 || WT == W_Q5_1) qh = src.qh[idx];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {      // byte j of word i: low nibble = element 4 i + j, high nibble = element 16 + 4 i + j (expand_unit's unpacking)
+            lo[i] = w[i] & 0x0F0F0F0Fu;
+            hi[i] = (w[i] >> 4) & 0x0F0F0F0Fu;
+            if (WT == W_Q5_0 || WT == W_Q5_1) { lo[i] |= spread4(qh >> (4 * i)); hi[i] |= spread4(qh >> (16 + 4 * i)); }
+            if (WT == W_Q4_0) { lo[i] = (lo[i] + 0x78787878u) ^ 0x80808080u; hi[i] = (hi[i] + 0x78787878u) ^ 0x80808080u; }
+            if (WT == W_Q5_0) { lo[i] = (lo[i] + 0x70707070u) ^ 0x80808080u; hi[i] = (hi[i] + 0x70707070u) ^ 0x80808080u; }
+        }
+        o[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        o[1] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    }
+    if (TI::q81) {
+        const uint32_t dm = reinterpret_cast<const uint32_t *>(src.sc)[idx];
+        reinterpret_cast<float2 *>(ds)[dst] = make_float2(h2f((uint16_t)(dm & 0xFFFFu)), h2f((uint16_t)(dm >> 16)));
+    } else {
+        reinterpret_cast<float *>(ds)[dst] = h2f(reinterpret_cast<const uint16_t *>(src.sc)[idx]);
+    }
 }
 
-// ggml's block term from the integer dot (same expressions as unit_dot_quant)
+// ggml's block term from the integer dot (the expressions of unit_dot_quant; the symmetric formats' dots come out of the signed image already corrected)
 template <int WT>
-__device__ __forceinline__ float mfma_block_term(int dot, uint32_t sc, float xd, uint32_t xs) {
-    if (WT == W_Q8_0) return __fmul_rn((float)dot, __fmul_rn(h2f((uint16_t)sc), xd));
-    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn((float)(dot - 8 * (int)xs), h2f((uint16_t)sc)), xd);
-    if (WT == W_Q5_0) return __fmul_rn(__fmul_rn(h2f((uint16_t)sc), xd), (float)(dot - 16 * (int)xs));
-    const float dw = h2f((uint16_t)(sc & 0xFFFFu)), mw = h2f((uint16_t)(sc >> 16));
+__device__ __forceinline__ float mfma_block_term(int dot, float dw, float mw, float xd, uint32_t xs) {
+    if (WT == W_Q8_0) return __fmul_rn((float)dot, __fmul_rn(dw, xd));
+    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn((float)dot, dw), xd);
+    if (WT == W_Q5_0) return __fmul_rn(__fmul_rn(dw, xd), (float)dot);
     return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), (float)dot), __fmul_rn(mw, __uint_as_float(xs)));
 }
 
 template <int WT>
 struct MfmaBatch {                       // one lane's weight-side operands for CH consecutive blocks
     static constexpr int CH = 4;         // blocks per load batch (8 costs ~60 more VGPRs and an occupancy step)
-    static constexpr int SW = TypeInfo<WT>::q81 ? 4 : 2;   // dwords of the lane's 4 row scales per block
-    uint2 q[CH];                         // raw operand bytes (nibbles / int8)
-    uint32_t sc[CH][SW];                 // scales of rows 4g .. 4g+3 (fp16 d, or half2 {d, m})
-    uint32_t qh[CH];                     // Q5: fifth bits of the lane's A row
+    static constexpr int SW = TypeInfo<WT>::q81 ? 8 : 4;   // dwords of the lane's 4 row scales per block (f32 d, or {d, m})
+    uint2 q[CH];                         // the A operand itself: 8 int8 of row (lane & 15), elements 8 g .. 8 g + 7
+    uint32_t sc[CH][SW];                 // scales of rows 4g .. 4g+3
 };
 
-// this lane's three image pointers at block 0 of its tile; block b is a CONSTANT stride further (256 / 512 bytes of
-// quants, 32 / 64 bytes of scales, 64 bytes of fifth bits), so a batch is one base address plus immediate offsets
+// this lane's two image pointers at block 0 of its tile; block b is a CONSTANT stride further (512 bytes of weights, 64 / 128 bytes of scales),
+// so a batch is one base address plus immediate offsets
 template <int WT>
 struct MfmaLanePtrs {
     const uint8_t *q, *sc;
-    const uint32_t *qh;
 };
 template <int WT>
 __device__ __forceinline__ MfmaLanePtrs<WT> mfma_lane_ptrs(const DevMatrix &img, int64_t base, int li, int g) {
     using TI = TypeInfo<WT>;
     MfmaLanePtrs<WT> p;
-    p.q = (WT == W_Q8_0) ? img.qs + (base + li) * 32 + 8 * g : img.qs + (base + li) * 16 + 8 * (g & 1);
-    p.sc = img.sc + (base + 4 * g) * (TI::q81 ? 4 : 2);
-    p.qh = img.qh + base + li;
+    p.q = img.qs + (base + li) * 32 + 8 * g;
+    p.sc = img.sc + (base + 4 * g) * (TI::q81 ? 8 : 4);
     return p;
 }
 template <int WT>
 __device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const MfmaLanePtrs<WT> &lp, int b0) {
     using TI = TypeInfo<WT>;
-    constexpr int QS = (WT == W_Q8_0) ? 512 : 256, SS = TI::q81 ? 64 : 32;   // bytes per block of one tile
+    constexpr int QS = 512, SS = TI::q81 ? 128 : 64;   // bytes per block of one tile
     const uint8_t *q = lp.q + (size_t)b0 * QS, *sc = lp.sc + (size_t)b0 * SS;
-    const uint32_t *qh = lp.qh + (size_t)b0 * 16;
 #pragma unroll
     for (int j = 0; j < MfmaBatch<WT>::CH; j++) {
         t.q[j] = *reinterpret_cast<const uint2 *>(q + j * QS);
+        const uint4 v = *reinterpret_cast<const uint4 *>(sc + j * SS);
+        t.sc[j][0] = v.x; t.sc[j][1] = v.y; t.sc[j][2] = v.z; t.sc[j][3] = v.w;
         if (TI::q81) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sc + j * SS);
-            t.sc[j][0] = v.x; t.sc[j][1] = v.y; t.sc[j][2] = v.z; t.sc[j][3] = v.w;
-        } else {
-            const uint2 v = *reinterpret_cast<const uint2 *>(sc + j * SS);
-            t.sc[j][0] = v.x; t.sc[j][1] = v.y;
+            const uint4 w = *reinterpret_cast<const uint4 *>(sc + j * SS + 16);
+            t.sc[j][4] = w.x; t.sc[j][5] = w.y; t.sc[j][6] = w.z; t.sc[j][7] = w.w;
         }
-        if (WT == W_Q5_0 || WT == W_Q5_1) t.qh[j] = qh[j * 16];
     }
 }
 
 template <int WT>
 __device__ __forceinline__ long mfma_a_operand(const MfmaBatch<WT> &t, int j, int g) {
-    if (WT == W_Q8_0) return (long)(((unsigned long)t.q[j].y << 32) | t.q[j].x);
-    // 8 bytes of nibbles: low nibble of byte i = element i of the half, high nibble = element i + 16
-    const int sh = 4 * (g >> 1);
-    uint32_t lo = (t.q[j].x >> sh) & 0x0F0F0F0Fu, hi = (t.q[j].y >> sh) & 0x0F0F0F0Fu;
-    if (WT == W_Q5_0 || WT == W_Q5_1) {
-        const uint32_t bits = t.qh[j] >> (8 * g);   // fifth bits of elements 8g .. 8g+7
-        lo |= spread4(bits);
-        hi |= spread4(bits >> 4);
-    }
-    return (long)(((unsigned long)hi << 32) | lo);
+    return (long)(((unsigned long)t.q[j].y << 32) | t.q[j].x);
 }
 
 // NT = 16-column tiles per wave.  NT = 2: the weight-side work of a block (operand unpack, the four fp16 row scales) feeds
@@ -197,9 +206,12 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
         for (int j = 0; j < CH; j++) {
             const int b = b0 + j;
             const long aop = mfma_a_operand<WT>(tb, j, g);
-            uint32_t scr[4];
+            float dwr[4], mwr[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) scr[r] = TI::q81 ? tb.sc[j][r] : ((tb.sc[j][r >> 1] >> (16 * (r & 1))) & 0xFFFFu);
+            for (int r = 0; r < 4; r++) {
+                dwr[r] = __uint_as_float(TI::q81 ? tb.sc[j][2 * r] : tb.sc[j][r]);
+                mwr[r] = TI::q81 ? __uint_as_float(tb.sc[j][2 * r + 1]) : 0.0f;
+            }
             i32x4 c[NT];
             float xd[NT];
             uint32_t xs[NT];
@@ -207,14 +219,14 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
             for (int t = 0; t < NT; t++) {
                 const long bop = *reinterpret_cast<const long *>(bq + t * 16 * PITCH + b * QK);
                 xd[t] = bd[t * 16 * SP + b];
-                xs[t] = bs[t * 16 * SP + b];
+                xs[t] = TI::q81 ? bs[t * 16 * SP + b] : 0u;      // the block sums only serve the min term of Q4_1 / Q5_1
                 const i32x4 zero = {0, 0, 0, 0};
                 c[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop, zero, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[t][r] = __fadd_rn(acc[t][r], mfma_block_term<WT>(c[t][r], scr[r], xd[t], xs[t]));
+                for (int r = 0; r < 4; r++) acc[t][r] = __fadd_rn(acc[t][r], mfma_block_term<WT>(c[t][r], dwr[r], mwr[r], xd[t], xs[t]));
         }
     };
 #pragma unroll 1
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
                     const int c = e / BPP, b = e - c * BPP;
                     const int cc = min(col0 + c, p.N - 1);
                     s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
-                    s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + ph * BPP + b];
+                    if (TI::q81) s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + ph * BPP + b];
                 }
             }
         }
