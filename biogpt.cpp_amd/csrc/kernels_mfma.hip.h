@@ -234,25 +234,44 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
         // ---- stage this phase of the NC activation columns in LDS (coalesced 16-byte pieces) ----
         if (ph > 0) __syncthreads();                                            // the previous phase has been consumed
         {
+            // The activation bytes go from global memory STRAIGHT into LDS (global_load_lds_dwordx4, gfx950: 16 bytes per lane, a wave-instruction moves 1 KB of ONE
+            // column to 1 KB of that column's LDS row): no registers, every piece of the phase in flight at once.  Round 4: written as "load 16 bytes, store them to
+            // LDS" the compiler waited for each piece before it asked for the next (s_waitcnt vmcnt(0) between them, whatever the source order: it sinks every
+            // load to its LDS write) -- nine dependent L2 round trips per phase, a third of fc2's 26 us (profiles/prefill_mfma_staging_r4.txt).
             constexpr int PPC = KP / 16;                                        // 16-byte pieces per column
+            constexpr int NPIECE = NC * PPC / 256, NSC = (NC * BPP + 255) / 256;
+            static_assert(PPC % 64 == 0, "a wave's 64 pieces lie in one column");
+            typedef __attribute__((address_space(1))) const void gl_ptr;
+            typedef __attribute__((address_space(3))) void lds_ptr;
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-            for (int i = 0; i < NC * PPC / 256; i++) {
-                const int pc = tid + 256 * i, c = pc / PPC, o = (pc - c * PPC) * 16;
+            for (int i = 0; i < NPIECE; i++) {
+                const int pc0 = 64 * wv + 256 * i, c = pc0 / PPC, o0 = (pc0 - c * PPC) * 16;      // wave-uniform: the lane's piece is pc0 + lane
                 const int cc = min(col0 + c, p.N - 1);                          // idle columns re-read the last one
-                *reinterpret_cast<uint4 *>(s_q + c * PITCH + o) = *reinterpret_cast<const uint4 *>(p.aq_q + (size_t)cc * K + ph * KP + o);
+                __builtin_amdgcn_global_load_lds((gl_ptr *)(p.aq_q + (size_t)cc * K + ph * KP + o0 + lane * 16), (lds_ptr *)(s_q + c * PITCH + o0), 16, 0, 0);
+            }
+            float sd[NSC];
+            uint32_t ss[NSC];
+#pragma unroll
+            for (int i = 0; i < NSC; i++) {
+                const int e = min(tid + 256 * i, NC * BPP - 1);
+                const int c = e / BPP, b = e - c * BPP;
+                const int cc = min(col0 + c, p.N - 1);
+                sd[i] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
+                ss[i] = TI::q81 ? p.aq_s[(size_t)cc * BPR + ph * BPP + b] : 0u;
             }
 #pragma unroll
-            for (int i = 0; i < (NC * BPP + 255) / 256; i++) {
+            for (int i = 0; i < NSC; i++) {
                 const int e = tid + 256 * i;
                 if (e < NC * BPP) {
                     const int c = e / BPP, b = e - c * BPP;
-                    const int cc = min(col0 + c, p.N - 1);
-                    s_d[c * SP + b] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
-                    if (TI::q81) s_s[c * SP + b] = p.aq_s[(size_t)cc * BPR + ph * BPP + b];
+                    s_d[c * SP + b] = sd[i];
+                    if (TI::q81) s_s[c * SP + b] = ss[i];
                 }
             }
         }
         if (ph > 0) mfma_load_batch<WT>(t0, lp, ph * BPP);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                     // vmcnt(0): the direct-to-LDS loads of this wave have landed (the barrier publishes them)
         __syncthreads();
 #pragma unroll 1
         for (int nb = 0; nb < NB; nb += 2) {
