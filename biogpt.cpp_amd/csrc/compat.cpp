@@ -237,7 +237,8 @@ biogpt_vocab::id sample_from_top(std::vector<scored> &cand, double top_p, std::m
 
 // biogpt.cpp:908-980.  The reference copies all n logits into (score, id) pairs and std::partial_sort's them (~0.3 ms for 42 k entries: more than a decode
 // step takes on the MI355X).  Same selection in ONE pass over the floats: the k best so far are kept in descending order (equal values: lower id first, the
-// rule of oracle/sampler.py and of the device-side top-k; the reference's partial_sort leaves ties unspecified), a block of 16 logits is only looked at when
+// rule of oracle/sampler.py and of the device-side top-k; the reference's partial_sort leaves ties unspecified: with EQUAL logits at the k-th place the
+// sampled id can differ from what a particular build of the reference draws -- a deviation inside what the reference itself leaves open), a block of 16 logits is only looked at when
 // its maximum beats the current k-th value.  Scaling by 1 / temp is monotone, so it is applied to the k survivors only.
 biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const float *logits, int top_k, double top_p,
                                            double temp, std::mt19937 &rng) {
@@ -267,8 +268,8 @@ biogpt_vocab::id biogpt_sample_top_k_top_p(const biogpt_vocab &vocab, const floa
     int i = 0;
     for (; i < n && have < top_k; i++) offer(logits[i], i);
     for (; i + 16 <= n; i += 16) {
-        float m = logits[i];
-        for (int j = 1; j < 16; j++) m = logits[i + j] > m ? logits[i + j] : m;
+        float m = -INFINITY;      // (not logits[i]: a NaN there would hide the whole block -- every comparison with it is false)
+        for (int j = 0; j < 16; j++) m = logits[i + j] > m ? logits[i + j] : m;
         if (m > thr)
             for (int j = 0; j < 16; j++) offer(logits[i + j], i + j);
     }

@@ -171,7 +171,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -206,6 +206,8 @@ struct EngineOptions {
         resident_us = get("BIOGPT_HIP_RESIDENT_US", 1000);   // ... for at most this long without a new token (the device is not shared meanwhile)
         hop_place = get("BIOGPT_HIP_HOP_PLACE", 1);        // the cross-XCD hand-off regions: 1 placed by a calibration launch (xpipe_place_hops), 0 first candidate, 2 the slower one (A/B)
         verbose = get("BIOGPT_HIP_VERBOSE", 0);
+        eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
+        topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
@@ -852,6 +854,12 @@ bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
     if (owner == c) c->xp_in_call = true;      // until the API call that asked returns (XpCallScope)
     return owner == c;
 }
+// does another context of this process hold the device's pipeline slot (a persistent launch of its own may be on the device) ?
+bool xpipe_slot_held_by_other(const biogpt_hip_ctx *c) {
+    if (c->device < 0 || c->device >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_xp_mu);
+    return g_xp_owner[c->device] != nullptr && g_xp_owner[c->device] != c;
+}
 // an API entry that may take the pipeline slot: while it runs, no other context may relieve this one of the slot (its launches are not enqueued yet)
 struct XpCallScope {
     biogpt_hip_ctx *c;
@@ -1024,7 +1032,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
             if (ra) {     // resident launch (biogpt_hip_eval): token 0 and its position travel in the parameter block, the following ones through the mailbox
                 if (!(fold && host_row && advance == 0 && tok_src == 1 && xp.t_cap <= 1024 && (xp.t_cap <= 256 || xp.gran_l != nullptr))) BG_FAIL(false, "internal: a resident launch needs the lm_head inside the pipelined launch");
                 xp.resident = 1; xp.mbox = c->res_mbox; xp.mbox_seq0 = ra->seq0; xp.done_host = c->res_done;
-                xp.idle_ticks = (uint32_t)std::max(1, c->opt.resident_us) * 100u;
+                xp.idle_ticks = (uint32_t)std::min(10000000, std::max(1, c->opt.resident_us)) * 100u;      // 100 MHz ticks; clamped to 10 s (the product must fit 32 bits)
                 xp.res_tok0 = ra->tok0; xp.res_n_past0 = ra->n_past0; xp.res_dbg = c->opt.res_dbg;
                 xp.res_spec0 = ra->spec0; xp.spec_rec = c->res_spec;
                 xp.logits_alt = c->logits_alt; xp.logits_host_alt = c->logits_host_alt; xp.pmax_alt_val = c->pmax_val_alt; xp.pmax_alt_idx = c->pmax_idx_alt;
@@ -1755,6 +1763,8 @@ static bool resident_stop(biogpt_hip_ctx *c) {
 // that was started in vain plus a fresh launch.
 static bool spec_wanted(const biogpt_hip_ctx *c) { return c->opt.res_spec != 0 && c->spec_streak >= c->spec_need; }
 
+// the pinned row buffers: the logits row + (resident launches) the maxima of its 64-row blocks behind it (kernels_xpipe.hip.h, xp_blockmax_offset)
+static size_t host_row_bytes(const biogpt_hip_ctx *ctx) { return ((size_t)bgk::xp_blockmax_offset(ctx->hp.n_vocab) + 1024) * 4; }
 // one token through a resident launch; 1 = done (row in ctx->row_cur), 0 = not applicable here (caller takes the ordinary path), -2 = failure
 static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
     if (!ctx->opt.resident || ctx->opt.no_graph || !xpipe_lm_folds(ctx)) return 0;
@@ -1809,16 +1819,17 @@ static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
                 HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_done), 256 * 4, hipHostMallocDefault));
                 std::memset(ctx->res_mbox, 0xff, 64 * 8 * 4);
                 std::memset(ctx->res_done, 0, 256 * 4);
+                ctx->res_seq = 0; ctx->res_acc = 0;      // fresh completion words: the sequence numbers start over with them (a zeroed word must never look "ahead" of a late number)
             }
             if (!ctx->res_spec) {
                 HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_spec), 64, hipHostMallocDefault));
                 std::memset(ctx->res_spec, 0, 64);
-                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host_alt), V * 4, hipHostMallocDefault));
+                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host_alt), host_row_bytes(ctx), hipHostMallocDefault));
                 HIP_TRY(-2, hipMalloc(&ctx->logits_alt, V * 4));
                 HIP_TRY(-2, hipMalloc(&ctx->pmax_val_alt, (size_t)ctx->pmax_cap * 4));
                 HIP_TRY(-2, hipMalloc(&ctx->pmax_idx_alt, (size_t)ctx->pmax_cap * 4));
             }
-            if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), V * 4, hipHostMallocDefault));
+            if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), host_row_bytes(ctx), hipHostMallocDefault));
             if ((ctx->opt.res_dbg & 32) && !ctx->tstamp) {
                 HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
                 HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
@@ -1874,9 +1885,10 @@ static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
 }
 
 // form 0: the step; form 1: the step + a last node that writes the logits row into pinned host memory (biogpt_hip_eval)
-static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int form) {
+static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int form, bool *row_in_host = nullptr) {
     XpCallScope xp_scope(ctx);
     clear_error();
+    if (row_in_host) *row_in_host = false;
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
@@ -1890,6 +1902,12 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
         }
         const int b = graph_bucket(n_past + 1);
         const int pl = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;   // holds the slot until the stream is next synchronised (xpipe_check)
+        // ANOTHER context of this process holds the device's pipeline slot right now -- typically with a resident launch that waits for its caller's next token:
+        // this context's replayed five-launch graph then runs in the shadow of a persistent kernel that drains while the graph starts, and on this runtime the
+        // graph's last nodes were observed to see the PREVIOUS replay's activations (tools/dbg_two_contexts.py, profiles/two_contexts_r4.txt: the returned row was
+        // exactly the row of the call before, K / V rows correct; eager launches of the same kernels are not affected).  Such a call takes the eager launches.
+        const bool contended = pl == 0 && xpipe_slot_held_by_other(ctx);
+        if (contended) goto eager;
         if (!ctx->mbox_host) {
             HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->mbox_host), 64 * 8 * 4, hipHostMallocDefault));
             HIP_TRY(-2, hipMalloc(&ctx->mbox_ctr, 16));
@@ -1900,7 +1918,7 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
             const int nseg = 1;
             const int bounds[3] = {0, L, L};
             const size_t V = (size_t)ctx->hp.n_vocab;
-            if (form == 1 && !ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), V * 4, hipHostMallocDefault));
+            if (form == 1 && !ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), host_row_bytes(ctx), hipHostMallocDefault));
             HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
             for (int sgi = 0; sgi < nseg; sgi++) {
                 hipGraph_t g = nullptr;
@@ -1919,18 +1937,34 @@ static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
             ctx->graph_eval_segs[form] = nseg;
         }
         int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
+        if (ctx->opt.verbose > 1) fprintf(stderr, "biogpt_hip[%p]: single-token eval as a graph replay: pl %d form %d bucket %d n_past %d token %d mailbox slot %u\n", (void *)ctx, pl, form, b, n_past, tokens[0], ctx->mbox_sent & 63u);
         slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
         if (ctx->mbox_sent == ctx->mbox_synced) ctx->unsynced_from = n_past;
         ctx->mbox_sent++;
         for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[pl][form][b][sgi], ctx->stream));
+        if (row_in_host) *row_in_host = form == 1;
         return 0;
     }
+eager:
     if (!upload_state(ctx, tokens, n, n_past)) return -2;
     if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
     return 0;
 }
 
 int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) { return eval_device_impl(ctx, tokens, n, n_past, 0); }
+
+// low-latency wait for everything enqueued on the context's stream (the caller is blocked on this token anyway).  BIOGPT_HIP_EVAL_SYNC=1: hipStreamSynchronize instead
+// (diagnostic)
+static bool poll_stream(biogpt_hip_ctx *ctx) {
+    if (ctx->opt.eval_sync == 1) { HIP_TRY(false, hipStreamSynchronize(ctx->stream)); return true; }
+    if (ctx->opt.eval_sync == 2) { HIP_TRY(false, hipDeviceSynchronize()); return true; }
+    if (ctx->opt.eval_sync == 3) { HIP_TRY(false, hipEventRecord(ctx->ev1, ctx->stream)); HIP_TRY(false, hipEventSynchronize(ctx->ev1)); return true; }
+    for (;;) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) HIP_TRY(false, q);
+    }
+}
 
 // the k largest values of a row, descending, equal values: lower index first (topk_kernel's order) -- ONE pass: a block of 16 values is only looked at when its
 // maximum beats the current k-th value.  Returns how many were found (< k only when the row holds NaNs)
@@ -1948,12 +1982,47 @@ static int host_topk(const float *row, int n, int k, float *vals, int32_t *ids) 
     int i = 0;
     for (; i < n && have < k; i++) offer(row[i], i);
     for (; i + 16 <= n; i += 16) {
-        float m = row[i];
-        for (int j = 1; j < 16; j++) m = row[i + j] > m ? row[i + j] : m;
+        float m = -INFINITY;      // (not row[i]: a NaN there would hide the block -- every comparison with it is false)
+        for (int j = 0; j < 16; j++) m = row[i + j] > m ? row[i + j] : m;
         if (m > thr)
             for (int j = 0; j < 16; j++) offer(row[i + j], i + j);
     }
     for (; i < n; i++) offer(row[i], i);
+    return have;
+}
+
+// The same selection when the launch has left the maxima of the row's 64-row blocks behind it (a resident launch): the k-th largest block maximum t0 is a lower
+// bound of the k-th largest logit (k blocks hold a value >= t0), so every candidate lies in a block whose maximum is >= t0 -- k blocks, give or take ties, instead of
+// n / 64.  They are walked in index order with the same insertion rule, so values, ids and their order are those of host_topk (and of topk_kernel).
+static int host_topk_blocks(const float *row, int n, int k, const float *bmax, int nblocks, float *vals, int32_t *ids) {
+    if (nblocks < k || nblocks > 1024) return host_topk(row, n, k, vals, ids);
+    float top[64];
+    int have_b = 0;
+    for (int b = 0; b < nblocks; b++) {      // the k largest block maxima, descending (insertion into <= 64 slots: ~700 compares for BioGPT's 663 blocks)
+        const float v = bmax[b];
+        if (v != v) return host_topk(row, n, k, vals, ids);
+        if (have_b == k && !(v > top[k - 1])) continue;
+        int pos = have_b < k ? have_b : k - 1;
+        while (pos > 0 && top[pos - 1] < v) { top[pos] = top[pos - 1]; pos--; }
+        top[pos] = v;
+        if (have_b < k) have_b++;
+    }
+    const float t0 = top[k - 1];
+    int have = 0;
+    float thr = -INFINITY;
+    for (int b = 0; b < nblocks; b++) {
+        if (!(bmax[b] >= t0)) continue;
+        const int i0 = b * 64, i1 = std::min(n, i0 + 64);
+        for (int i = i0; i < i1; i++) {
+            const float v = row[i];
+            if ((have == k && !(v > thr)) || v != v) continue;
+            int pos = have < k ? have : k - 1;
+            while (pos > 0 && vals[pos - 1] < v) { vals[pos] = vals[pos - 1]; ids[pos] = ids[pos - 1]; pos--; }
+            vals[pos] = v; ids[pos] = i;
+            if (have < k) have++;
+            if (have == k) thr = vals[k - 1];
+        }
+    }
     return have;
 }
 
@@ -1972,7 +2041,10 @@ static int eval_topk_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n,
         const int r = resident_eval(ctx, tokens[0], n_past);
         if (r < 0) return r;
         if (r == 1) {
-            if (host_topk(ctx->row_cur, ctx->hp.n_vocab, k, vals_out, ids_out) == k) return k;
+            const float *bmax = ctx->row_cur + bgk::xp_blockmax_offset(ctx->hp.n_vocab);
+            const int got = ctx->opt.topk_blocks ? host_topk_blocks(ctx->row_cur, ctx->hp.n_vocab, k, bmax, ctx->lm_blocks, vals_out, ids_out)
+                                                 : host_topk(ctx->row_cur, ctx->hp.n_vocab, k, vals_out, ids_out);
+            if (got == k) return k;
             // NaNs in the row: the device path below has a defined answer for it (the position is evaluated again: same inputs, same K / V row)
         }
     }
@@ -1986,11 +2058,7 @@ static int eval_topk_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n,
                        out_val, out_idx, out_idx + 64);
     HIP_TRY(-2, hipGetLastError());
     // low-latency wait: poll the stream instead of sleeping on it (the caller is blocked on this token anyway)
-    for (;;) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) HIP_TRY(-2, q);
-    }
+    if (!poll_stream(ctx)) return -2;
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
     const float *hv = reinterpret_cast<const float *>(ctx->topk_host);
@@ -2070,7 +2138,13 @@ int biogpt_hip_bench_api_loop(biogpt_hip_ctx *ctx, const int32_t *prompt, int32_
     return n_predict;
 }
 
-const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) { return ctx ? ctx->logits : nullptr; }
+const float *biogpt_hip_logits_device(const biogpt_hip_ctx *ctx) {
+    if (!ctx) return nullptr;
+    // a resident launch may hold the last accepted row in its alternate buffer (odd sequence numbers) and may be running one position ahead: it is stopped here -- its
+    // results are folded into the ordinary buffers -- so that the pointer names the row of the last evaluated token, as the header says
+    if (ctx->res_live || (ctx->res_acc & 1u)) (void)resident_stop(const_cast<biogpt_hip_ctx *>(ctx));
+    return ctx->logits;
+}
 
 int biogpt_hip_read_logits(biogpt_hip_ctx *ctx, float *out) {
     if (!ctx || !out) BG_FAIL(-1, "null argument");
@@ -2107,19 +2181,15 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
         if (r < 0) return r;
         if (r == 1) { if (logits_out) std::memcpy(logits_out, ctx->row_cur, (size_t)ctx->hp.n_vocab * 4); return 0; }
     }
-    const int rc = eval_device_impl(ctx, tokens, n, n_past, 1);
+    bool in_graph = false;      // the replayed graph already wrote the pinned row
+    const int rc = eval_device_impl(ctx, tokens, n, n_past, 1, &in_graph);
     if (rc) return rc;
     const size_t bytes = (size_t)ctx->hp.n_vocab * 4;
-    const bool in_graph = n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(n_past + 1)));   // the replayed graph already wrote the pinned row
     if (!in_graph) {   // device -> pinned staging -> caller's (pageable) buffer: one DMA instead of the runtime's chunked staging
-        if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), bytes, hipHostMallocDefault));
+        if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), host_row_bytes(ctx), hipHostMallocDefault));
         HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    for (;;) {   // poll: the caller is blocked on this token anyway
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) HIP_TRY(-2, q);
-    }
+    if (!poll_stream(ctx)) return -2;   // poll: the caller is blocked on this token anyway
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
     ctx->row_cur = ctx->logits_host;

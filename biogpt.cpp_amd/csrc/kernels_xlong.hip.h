@@ -938,6 +938,12 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     for (int j = r; j < p.n_vocab; j++) { if (lg_host) __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
                 }
                 if (p.resident != 0) {
+                    if (lg_host && lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (kernels_xpipe.hip.h, XpParams::logits_host)
+                        float bm = s_redf[lane * NW];
+#pragma unroll
+                        for (int w = 1; w < NW; w++) bm = fmaxf(bm, s_redf[lane * NW + w]);
+                        __hip_atomic_store(lg_host + xp_blockmax_offset(p.n_vocab) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }

@@ -95,7 +95,9 @@ struct XpParams {
     DevMatrix Wlm;
     const float *lm_ln_w, *lm_ln_b;
     float *logits;
-    float *logits_host;        // optional pinned host copy of the row (biogpt_eval's output): written by the same lanes, no copy node behind the launch
+    float *logits_host;        // optional pinned host copy of the row (biogpt_eval's output): written by the same lanes, no copy node behind the launch.  A resident
+                               //   launch also leaves the maxima of its 64-row blocks behind the row, at [xp_blockmax_offset(n_vocab) + block]: the host's top-k selection
+                               //   (biogpt_hip_eval_topk, a caller that samples) then looks at the k blocks that can hold a candidate instead of at 42 k logits
     float *pmax_out_val; int32_t *pmax_out_idx;
     // resident mode (biogpt_hip_eval, one token per API call): the launch stays on the device after its first token; token tk >= 1 is taken from the
     // pinned mailbox slot (mbox_seq0 + tk) % 64 = {n_past, causal, token, seq} that the NEXT biogpt_eval() call fills -- workgroup 0 of XCD 0 waits for it,
@@ -168,6 +170,8 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
 template <int N, int S>
 __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
 
+// where the block maxima of a resident launch's row start in the pinned row buffers (floats; the buffers hold xp_blockmax_offset + 1024 floats)
+__host__ __device__ inline int xp_blockmax_offset(int n_vocab) { return (n_vocab + 1023) & ~1023; }
 // a post of the host in the resident launch's mailbox: one word, one PCIe read.  token 24 bits (0xffffff: leave), position 13 bits, speculate-next 1 bit, sequence number 24 bits
 __host__ __device__ inline xp_u64 xp_post(uint32_t seq, int n_past, int token, int spec) {
     return ((xp_u64)(seq & 0xffffffu) << 40) | ((xp_u64)(spec & 1) << 37) | ((xp_u64)((uint32_t)n_past & 0x1fffu) << 24) | (xp_u64)((uint32_t)token & 0xffffffu);
@@ -1125,6 +1129,12 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 for (int j = r; j < p.n_vocab; j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
             }
             if (p.resident != 0) {
+                if (lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (the same maxima tid < 4 records below)
+                    float bm = s_redf[lane * NW];
+#pragma unroll
+                    for (int w = 1; w < NW; w++) bm = fmaxf(bm, s_redf[lane * NW + w]);
+                    __hip_atomic_store(lg_host + xp_blockmax_offset(p.n_vocab) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 if (!(p.res_dbg & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((p.res_dbg & 32) && p.wall && lane == 0 && lm_rank == 0) p.wall[(size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 2 + 1] = wall_clock64();

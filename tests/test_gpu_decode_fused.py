@@ -575,6 +575,62 @@ def test_pipeline_slot_is_handed_back_and_replicas_reload(pkg, oracle, files):
         r.close()
 
 
+def test_generation_replays_the_graph_it_captured_when_the_slot_frees_up_mid_call(pkg, oracle, files, monkeypatch):
+    """generate_greedy with one token per launch (BIOGPT_HIP_XPIPE_MULTI=0) while ANOTHER context's asynchronous pipelined work is still in flight at the start:
+    the call finds the slot taken, captures the five-launch graphs -- and must replay exactly those even when the other context goes idle mid-call and the slot
+    could be taken over (round 3 asked again at every step and could name a graph that was never captured: rc -2).  ids == oracle, several times over."""
+    a = pkg.BiogptModel.load(files["q4_0"])
+    if a.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_MULTI", "0")
+    b = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_MULTI")
+    pb = [2, 7, 8, 9, 10]
+    ref, _ = oracle.OracleModel(files["q4_0"], n_threads=16).generate_greedy(pb, 30, n_batch=8)
+    rng = np.random.default_rng(5)
+    for rep in range(4):
+        for n_past in range(0, 12 + 4 * rep):          # a burst of asynchronous single-token evals: `a` holds the slot with work in flight ...
+            a.eval_device([int(rng.integers(4, KW["n_vocab"]))], n_past)
+        ids, _ = b.generate_greedy(pb, 30, n_batch=8)      # ... which ends somewhere inside this call
+        assert list(ids) == list(ref), rep
+        a.synchronize()
+    assert b.xpipe_state() in (0, 1)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_hand_off_region_placement_does_not_change_results(pkg, files, monkeypatch, mode):
+    """BIOGPT_HIP_HOP_PLACE: where the cross-XCD hand-off regions live (calibrated / first candidate / the slower candidate) is a matter of speed only: logits
+    of a prompt + steps through the 256 / 257-key border and a generation are identical to the calibrated placement."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    monkeypatch.setenv("BIOGPT_HIP_HOP_PLACE", mode)
+    u = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_HOP_PLACE")
+    rng = np.random.default_rng(9)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 259)]
+    for m in (g, u):
+        m.eval_device(toks[:250], 0)
+    for n_past in range(250, 260):
+        assert (g.eval([toks[n_past]], n_past) == u.eval([toks[n_past]], n_past)).all(), n_past
+    ig, _ = g.generate_greedy(toks[:5], 40, n_batch=8)
+    iu, _ = u.generate_greedy(toks[:5], 40, n_batch=8)
+    assert list(ig) == list(iu) and u.xpipe_state() == 1
+    g.close(); u.close()
+
+
+def test_lm_head_bench_with_cold_weights(pkg, files):
+    """biogpt_hip_bench_matvec(12): the stand-alone lm_head with its weights taken from a different device copy every launch (not cache-resident) -- the same bytes,
+    a sane time, and not faster than the cache-resident form by more than noise."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    s_warm, b_warm = g.bench_matvec(4, layer=0, reps=30)
+    s_cold, b_cold = g.bench_matvec(12, layer=0, reps=28)
+    assert b_warm == b_cold and 1e-6 < s_cold < 1e-3 and s_cold > 0.8 * s_warm
+    print("lm_head: cache-resident %.2f us, cold %.2f us per launch" % (s_warm * 1e6, s_cold * 1e6))
+    g.close()
+
+
 # ---- the pipeline beyond 256 keys (csrc/kernels_xlong.hip.h): attention spread over the chip, 32 / 64 keys per helper workgroup ----------
 
 @pytest.mark.parametrize("name", XPIPE_TYPES)

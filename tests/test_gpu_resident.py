@@ -285,3 +285,76 @@ def test_resident_launch_beyond_256_keys(pkg, files, monkeypatch, name):
         assert (kv[which] == u.read_kv(which, 0, n_past * D)).all()
     u.close()
     assert st["hits"] >= 150 and st["misses"] >= 1, st
+
+
+@pytest.mark.parametrize("k", [1, 5, 40, 64])
+def test_topk_behind_the_resident_launch_uses_the_block_maxima(pkg, files, monkeypatch, k):
+    """biogpt_hip_eval_topk in a loop of single-token calls (a caller that samples, biogpt.cpp:908-980 with top_k = 40): the resident launch leaves the maxima of the row's
+    64-row blocks behind the pinned row and the host selects from the k blocks that can hold a candidate -- the same values, ids and order as the full scan of the row
+    (BIOGPT_HIP_TOPK_BLOCKS=0) and as numpy on the row itself (value descending, equal values: lower id first); through the 256 -> 257-key border (the long-context launch)."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    monkeypatch.setenv("BIOGPT_HIP_TOPK_BLOCKS", "0")
+    u = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_TOPK_BLOCKS")
+    rng = np.random.default_rng(100 + k)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 245)]
+    for m in (g, u):
+        m.eval_device(prompt, 0)
+    tok = 77
+    for n_past in range(246, 266):
+        vg, ig = g.eval_topk([tok], n_past, k)
+        vu, iu = u.eval_topk([tok], n_past, k)
+        assert list(ig) == list(iu) and (vg == vu).all(), n_past
+        if n_past % 5 == 0:      # the row itself (the call re-evaluates the same position: same K / V row, same logits)
+            full = g.eval([tok], n_past)
+            order = np.lexsort((np.arange(full.size), -full))[:k]
+            assert list(ig) == [int(i) for i in order] and (vg == full[order]).all()
+        tok = int(ig[min(1, k - 1)])      # not the arg-max: the launch must wait for the caller's token, as it does for a sampling caller
+    assert g.xpipe_state() == 1
+    g.close(); u.close()
+
+
+@pytest.mark.parametrize("u_env", [None, "BIOGPT_HIP_XPIPE"])
+def test_two_contexts_interleave_single_token_evals_on_one_device(pkg, files, monkeypatch, u_env):
+    """Two contexts of one process take turns with single-token biogpt_hip_eval calls on ONE device: the first holds the pipeline slot with its resident launch
+    (which waits up to 1 ms for its caller's next token), the second runs every call on the five-launch layer behind it.  Round 3 replayed the second context's
+    captured graph there and got the row of ITS PREVIOUS CALL back (tools/dbg_two_contexts.py: K / V rows right, logits one call stale); such calls now take eager
+    launches.  Both contexts against a third one that evaluates the same tokens alone, without the pipeline."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    if u_env:
+        monkeypatch.setenv(u_env, "0")
+    u = pkg.BiogptModel.load(files["q4_0"])
+    if u_env:
+        monkeypatch.delenv(u_env)
+    rng = np.random.default_rng(3)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 245)]
+    g.eval_device(prompt, 0); u.eval_device(prompt, 0)
+    toks, rows_g, rows_u, top_u = [77], [], [], []
+    for n_past in range(246, 262):
+        a = g.eval([toks[-1]], n_past)
+        b = u.eval([toks[-1]], n_past) if n_past % 2 == 0 else None
+        if b is None:
+            vals, ids = u.eval_topk([toks[-1]], n_past, 5)
+            top_u.append((vals, ids))
+        rows_g.append(a); rows_u.append(b)
+        toks.append(int(a.argmax()))
+    g.close(); u.close()
+    monkeypatch.setenv("BIOGPT_HIP_RESIDENT", "0"); monkeypatch.setenv("BIOGPT_HIP_XPIPE", "0")
+    r = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_RESIDENT"); monkeypatch.delenv("BIOGPT_HIP_XPIPE")
+    r.eval_device(prompt, 0)
+    k = 0
+    for i, n_past in enumerate(range(246, 262)):
+        t = r.eval([toks[i]], n_past)
+        assert (rows_g[i] == t).all(), ("first context", n_past)
+        if rows_u[i] is not None:
+            assert (rows_u[i] == t).all(), ("second context", n_past)
+        else:
+            vals, ids = top_u[k]; k += 1
+            order = np.lexsort((np.arange(t.size), -t))[:5]
+            assert list(ids) == [int(v) for v in order] and (vals == t[order]).all(), ("second context, top-k", n_past)
+    r.close()
