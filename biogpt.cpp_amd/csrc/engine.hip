@@ -906,7 +906,8 @@ bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max);
 bool xpipe_lm_folds(const biogpt_hip_ctx *c) {
     const auto &hp = c->hp;
     const MatSlot &m = c->plan.lm_head;
-    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0));   // XCD 0 and the last unit's XCD take no part
+    // workgroups that take rows: the pipelined launch up to 256 keys (kernels_xpipe.hip.h, xp_lm_rank) and the long-context one (kernels_xlong.hip.h: every XCD but XCD 0 and the last unit's)
+    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = std::min(bgk::xp_lm_capacity(2 * hp.n_layer), 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0)));
     return c->opt.xpipe_lm && m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
 }
 int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {

@@ -170,6 +170,30 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
 template <int N, int S>
 __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
 
+// Which 256 rows (four 64-row blocks) of the output projection does workgroup (xcd, slot) take inside the pipelined launch ?  -1: none.  Not XCD 0's attention
+// workgroups (the next token's layer 0), not the last unit's XCD, and (XP_LM_LATE_XCD) not the XCD of the unit before it; the other XCDs in order, then
+// workgroups 16 .. 31 of XCD 0.  The host checks that the ranks cover the blocks (xpipe_lm_capacity).
+#ifndef XP_LM_LATE_XCD
+#define XP_LM_LATE_XCD 1
+#endif
+__host__ __device__ inline int xp_lm_rank(int xcd, int slot, int n_units) {
+    const int last_xcd = (n_units - 1) & 7, late_xcd = XP_LM_LATE_XCD ? ((n_units - 2) & 7) : last_xcd;
+    int n_full = 0, before = 0;
+    for (int x = 1; x < 8; x++) {
+        if (x == last_xcd || x == late_xcd) continue;
+        if (x < xcd) before++;
+        n_full++;
+    }
+    if (xcd == 0) return (XP_LM_LATE_XCD && slot >= 16) ? 32 * n_full + (slot - 16) : -1;
+    if (xcd == last_xcd || xcd == late_xcd) return -1;
+    return 32 * before + slot;
+}
+__host__ __device__ inline int xp_lm_capacity(int n_units) {      // workgroups that can take rows
+    int n = 0;
+    for (int x = 0; x < 8; x++)
+        for (int sl = 0; sl < 32; sl++) n += xp_lm_rank(x, sl, n_units) >= 0 ? 1 : 0;
+    return n;
+}
 // where the block maxima of a resident launch's row start in the pinned row buffers (floats; the buffers hold xp_blockmax_offset + 1024 floats)
 __host__ __device__ inline int xp_blockmax_offset(int n_vocab) { return (n_vocab + 1023) & ~1023; }
 // a post of the host in the resident launch's mailbox: one word, one PCIe read.  token 24 bits (0xffffff: leave), position 13 bits, speculate-next 1 bit, sequence number 24 bits
@@ -1045,9 +1069,12 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     // Their weights (four 64-row blocks = 16 units per lane) are loaded as soon as the workgroup's last layer of this token is
     // finished -- 1 .. 6 layers before the last layer's output exists -- so the logits cost one hop + LayerNorm + 16 block dots
     // instead of a launch boundary plus a 24.6 MB stream.  XCD 0 (next token's layer 0) and the last layer's XCD take no part.
-    const int lm_xr = xcd - (xcd > 0 ? 1 : 0) - ((last_xcd != 0 && xcd > last_xcd) ? 1 : 0);   // index among the XCDs that take part
-    const int lm_rank = slot + 32 * lm_xr;
-    if (p.lm != 0 && xcd != 0 && xcd != last_xcd && lm_rank * 4 < p.lm_blocks) {
+    // Round 4 (XP_LM_LATE_XCD): the XCD of the last-but-one unit takes no part either -- it is done with its unit only ~5 us before the last layer's output
+    // exists, its rows were still arriving then, and its workgroups delivered their logits (and the partials the next token's sampler waits for) 2.5 us
+    // behind everyone else (profiles/api_loop_device_clock_r4.txt: "XCD group of the last one: 0 0 0 0 0 64").  Their share goes to workgroups 16 .. 31 of
+    // XCD 0, which have been idle since that XCD's last unit (7 units ago) and are only needed again for the next token's out_proj.
+    const int lm_rank = xp_lm_rank(xcd, slot, n_units);
+    if (p.lm != 0 && lm_rank >= 0 && lm_rank * 4 < p.lm_blocks) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6;
