@@ -93,6 +93,7 @@ SYMBOLS = [
     ("biogpt_hip_generate_greedy", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_generate_greedy_batch", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     ("biogpt_hip_read_kv", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P]),
+    ("biogpt_hip_debug_stamps", C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(C.c_ulonglong)]),
     ("biogpt_hip_bench_matvec", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_decode", C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(C.c_double)]),
     ("biogpt_hip_bench_api_loop", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
@@ -389,6 +390,13 @@ class BiogptModel:
         if lib().biogpt_hip_read_kv(self._h, int(which), int(offset), int(count), out.ctypes.data) != 0:
             raise BiogptError(_err())
         return out
+
+    def debug_stamps(self, offset, count):
+        """Profiling builds: `count` raw stage stamps (100 MHz ticks) from word `offset` of the context's stamp buffer."""
+        out = (C.c_ulonglong * count)()
+        if lib().biogpt_hip_debug_stamps(self._h, offset, count, out) != 0:
+            raise BiogptError(_err())
+        return np.frombuffer(out, dtype=np.uint64).copy()
 
     def bench_matvec(self, which, layer=0, reps=200):
         secs, nbytes = C.c_double(0.0), C.c_double(0.0)

@@ -714,7 +714,10 @@ bool xpipe_place_hops(biogpt_hip_ctx *c, std::vector<bgk::XpLayer> &tab) {
         std::vector<bgk::XpProbe> pr;
         for (int l = 0; l < nl; l++)
             for (int which = 0; which < 2; which++) {
-                const int src = (2 * l + which) & 7, dst = (src + 1) & 7;      // x1: unit 2 l -> 2 l + 1; x: unit 2 l + 1 -> 2 l + 2 (the last layer's output goes to every lm_head XCD: judged by the same hop)
+                const int src = (2 * l + which) & 7;      // x1: unit 2 l -> 2 l + 1; x: unit 2 l + 1 -> 2 l + 2
+                // the last layer's output goes to every XCD that computes lm_head rows: readers in BOTH halves of the chip -- near the producer's half costs the far readers
+                // 0.5 us and the near ones 0.4, near the other half 0.5 and 0.6: judged by a hop that stays in the producer's half
+                const int dst = (l == nl - 1 && which == 1) ? (src ^ 1) : ((src + 1) & 7);
                 for (int k = 0; k < 2; k++)
                     for (int line = 0; line < 2; line++) pr.push_back({cand(l, which, k) + (line ? 512 + 130 : 2), src, dst});
             }
@@ -2268,6 +2271,10 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
     const bool use_graph = ctx->opt.no_graph == 0;
+    if ((ctx->opt.dbg & 128) && !ctx->tstamp) {      // profiling builds: stage stamps of the pipelined launches (tools/tail_timeline.py)
+        HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
+        HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
+    }
     // the device's pipeline slot, if it is free, is this call's until its final synchronisation
     // Decided ONCE per bucket, here: xpipe_usable() can take the slot over from a holder that has gone idle in the meantime, so asking again at replay
     // time could name a graph that was never captured.  The graph replayed for a bucket is the one instantiated for it.
@@ -2510,6 +2517,18 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     HIP_TRY(-2, hipMemcpy(gen.data(), ctx->seq_gen, gen.size() * 4, hipMemcpyDeviceToHost));
     for (int s = 0; s < n_seqs; s++) std::memcpy(out_ids + (size_t)s * n_predict, gen.data() + (size_t)s * P, (size_t)n_predict * 4);
     return n_predict;
+}
+
+// profiling builds (BIOGPT_HIP_PROFILE_HOOKS + BIOGPT_HIP_DBG=128): the raw 100 MHz stage stamps the pipelined launches left (kernels_xpipe.hip.h XP_WALL / XP_TAIL)
+int biogpt_hip_debug_stamps(biogpt_hip_ctx *ctx, size_t offset, size_t count, unsigned long long *out) {
+    clear_error();
+    if (!ctx || !out) BG_FAIL(-1, "null argument");
+    if (!ctx->tstamp || (offset + count) * 8 > ((size_t)4 << 20)) BG_FAIL(-1, "no stamps (profiling build with BIOGPT_HIP_DBG=128 only)");
+    HIP_TRY(-2, hipSetDevice(ctx->device));
+    if (!resident_stop(ctx)) return -2;
+    HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(-2, hipMemcpy(out, ctx->tstamp + offset, count * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t count, float *out) {

@@ -37,6 +37,9 @@ constexpr int XL_G_SC = 0;                     // [16 heads][1024 keys] scores
 constexpr int XL_G_PV = 16 * 1024;             // [16 heads][16 ranges][64 lo + 64 hi] partial sum_j V_jd p_j (double)
 constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
 
+#ifndef XL_COMBINE_HOME
+#define XL_COMBINE_HOME 1
+#endif
 #ifdef BIOGPT_HIP_PROFILE_HOOKS
 // wall clock of workgroups 0 and 16 of the layer's own XCD ([n_layer][32] slots; workgroup 0 is also the first helper of head 2 xcd)
 #define XL_WALL(k) do { if (p.wall && tid == 0 && (slot & 15) == 0 && own_first) p.wall[L * 32 + (k)] = wall_clock64(); } while (0)
@@ -176,6 +179,75 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         }
     };
 
+    // ---- the partial sums of one head added in range order (attn_split_combine_kernel's association), Q8, published for out_proj.  Round 3: by the head's first
+    //      helper on XCD head / 2 (partials in-XCD, the result across: two hops).  Round 4 (XL_COMBINE_HOME): by workgroup `head` of the layer's OWN XCD -- the one
+    //      that computed the head's q / k / v rows and waits for the attention output anyway: the partials cross XCDs (one hop, 2048 granules per head), the result
+    //      stays inside the XCD (plain stores): T = 1024 14.25 -> ~13.2 us per layer (profiles/xlong_timeline_r4.txt) ----
+    auto combine = [&](const int L, const uint32_t epoch, const int T, const int head, const bool home) __attribute__((always_inline)) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const bool own_first = home || (slot & 15) == 0;      // (profiling hooks: the workgroup whose stamps are kept)
+        {
+            __syncthreads();                      // s_pv: the slice sums of the helper duty have been read
+            const int nr = (T + KR - 1) / KR;     // active ranges
+            const xp_u64 *const G0 = p.gran_l + (size_t)L * XL_G_LAYER + XL_G_PV + head * 16 * 128;
+            {
+                const int d = tid & (DK - 1), part = tid >> 6;          // ranges part and part + 8
+                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                const bool a0 = part < nr, a1 = part + 8 < nr;
+                const xp_u64 *g0 = G0 + part * 128 + d, *g1 = G0 + (part + 8) * 128 + d;
+                // (one pass at a time: two in flight were measured here -- T = 1024 358 -> 365 us per token, profiles/xpipe_ab_r4.txt)
+                for (uint32_t spins = 0;; spins++) {
+                    bool ok = true;
+                    if (a0) {
+                        const xp_u64 x0 = __hip_atomic_load(g0, XP_RLX), x1 = __hip_atomic_load(g0 + 64, XP_RLX);
+                        v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
+                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
+                    }
+                    if (a1) {
+                        const xp_u64 x0 = __hip_atomic_load(g1, XP_RLX), x1 = __hip_atomic_load(g1 + 64, XP_RLX);
+                        v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
+                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
+                    }
+                    if (__all(ok)) break;
+                    if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); if (RES) xl_die(s_dead); break; }
+                    if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
+                    xp_poll_pause();
+                }
+                s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
+                s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
+            }
+            __syncthreads();
+            xl_live<RES>(s_dead);
+            XL_WALL(21);
+            if (tid < DK) {
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < 16; s += 2) {
+                    if (s < nr) t0 += s_pv[s * DK + tid];
+                    if (s + 1 < nr) t1 += s_pv[(s + 1) * DK + tid];
+                }
+                const float o = (float)(t0 + t1);
+                int8_t q8; float d8; uint32_t s8;
+                q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
+                const uint32_t packed = xp_pack4(q8);
+                xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
+                const int blk = head * 2 + (tid >> 5);
+                if (home) {
+                    if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
+                    if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, epoch, s8); }
+                } else {
+                    if ((tid & 3) == 0) xp_put(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
+                    if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
+                }
+            }
+            XL_WALL(22);
+            __syncthreads();                      // s_pv is rewritten by the next helper duty
+        }
+        (void)lane;
+    };
+
     // ================= helper duty for layer L (every workgroup, every layer): biogpt.cpp:729-764 for keys [hx_j0, hx_j0 + KR) of head hx_head =================
     auto helper = [&](const int L, const uint32_t epoch, const int n_past, const bool own_first, const bool more, const bool defer_fetch = false) __attribute__((always_inline)) {
         const int T = n_past + 1;
@@ -299,63 +371,13 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
                 const double part = t0 + t1;
                 xp_u64 *const gp = GL + XL_G_PV + (hx_head * 16 + hx_r) * 128 + tid;
-                xp_put_local(gp, epoch, (uint32_t)__double2loint(part));
-                xp_put_local(gp + 64, epoch, (uint32_t)__double2hiint(part));
+                // XL_COMBINE_HOME: the partials go straight to the layer's own XCD (write-through), where the head's workgroup adds them (stage C's prologue)
+                if (XL_COMBINE_HOME) { xp_put(gp, epoch, (uint32_t)__double2loint(part)); xp_put(gp + 64, epoch, (uint32_t)__double2hiint(part)); }
+                else { xp_put_local(gp, epoch, (uint32_t)__double2loint(part)); xp_put_local(gp + 64, epoch, (uint32_t)__double2hiint(part)); }
             }
             XL_WALL(20);
         }
-        if (hx_j0 < T && hx_r == 0) {
-            // ---- the head's first helper adds the partials in range order (attn_split_combine_kernel), Q8, publishes for the layer's own XCD ----
-            __syncthreads();                      // s_pv: the slice sums above have been read
-            const int nr = (T + KR - 1) / KR;     // active ranges
-            const xp_u64 *const G0 = p.gran_l + (size_t)L * XL_G_LAYER + XL_G_PV + hx_head * 16 * 128;
-            {
-                const int d = tid & (DK - 1), part = tid >> 6;          // ranges part and part + 8
-                uint32_t v[4] = {0u, 0u, 0u, 0u};
-                const bool a0 = part < nr, a1 = part + 8 < nr;
-                const xp_u64 *g0 = G0 + part * 128 + d, *g1 = G0 + (part + 8) * 128 + d;
-                for (uint32_t spins = 0;; spins++) {
-                    bool ok = true;
-                    if (a0) {
-                        const xp_u64 x0 = __hip_atomic_load(g0, XP_RLX), x1 = __hip_atomic_load(g0 + 64, XP_RLX);
-                        v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
-                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
-                    }
-                    if (a1) {
-                        const xp_u64 x0 = __hip_atomic_load(g1, XP_RLX), x1 = __hip_atomic_load(g1 + 64, XP_RLX);
-                        v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
-                        ok &= (uint32_t)(x0 >> 32) == epoch && (uint32_t)(x1 >> 32) == epoch;
-                    }
-                    if (__all(ok)) break;
-                    if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); if (RES) xl_die(s_dead); break; }
-                    if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                    xp_poll_pause();
-                }
-                s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
-                s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
-            }
-            __syncthreads();
-            xl_live<RES>(s_dead);
-            XL_WALL(21);
-            if (tid < DK) {
-                double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-                for (int s = 0; s < 16; s += 2) {
-                    if (s < nr) t0 += s_pv[s * DK + tid];
-                    if (s + 1 < nr) t1 += s_pv[(s + 1) * DK + tid];
-                }
-                const float o = (float)(t0 + t1);
-                int8_t q8; float d8; uint32_t s8;
-                q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
-                const uint32_t packed = xp_pack4(q8);
-                xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
-                const int blk = hx_head * 2 + (tid >> 5);
-                if ((tid & 3) == 0) xp_put(G + XP_G_ATT + hx_head * 16 + (tid >> 2), epoch, packed);
-                if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
-            }
-            XL_WALL(22);
-            __syncthreads();                      // s_pv is rewritten by the next helper duty
-        }
+        if (!XL_COMBINE_HOME && hx_j0 < T && hx_r == 0) combine(L, epoch, T, hx_head, false);      // (round 3: the head's first helper, then a cross-XCD hop)
         // this workgroup's K / V rows for its next helper duty (the next layer of this token, or layer 0 of the next token) -- issued AFTER the combiner's
         // polls, and on the layer's own XCD after stage C has published its rows: 32 KB of cache-missing loads occupy the compute unit's memory
         // pipeline for ~1.5 us, and whatever is issued behind them -- a poll (a wave's loads return in order), even a hand-off store -- waits
@@ -653,10 +675,11 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
             if constexpr (FIRST) {
                 {
+                    if constexpr (XL_COMBINE_HOME != 0 && ROLE == 0) combine(L, epoch, n_past + 1, slot, true);      // this workgroup's head: partials of its 16 key ranges -> attention output, in-XCD
                     // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
                     if (wave < 5) {
                         uint32_t v[1];
-                        xl_sweep<RES, 1, 1, true>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, s_dead);      // (the block sums travel only with Q8_1 activations)
+                        xl_sweep<RES, 1, 1, XL_COMBINE_HOME == 0>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, s_dead);      // (the block sums travel only with Q8_1 activations)
                         if (tid < 256) s_xq[tid] = v[0];
                         else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
                         else s_xs[tid - 288] = v[0];

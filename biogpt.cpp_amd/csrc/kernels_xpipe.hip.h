@@ -124,8 +124,12 @@ struct XpParams {
 #ifdef BIOGPT_HIP_PROFILE_HOOKS
 #define XP_WALL(k) do { if (p.wall && tid == 0) { const unsigned long long t_ = wall_clock64(); if ((slot & 15) == 0) p.wall[L * 16 + (k)] = t_; \
         if (L == p.n_layer - 1) p.wall[(p.n_layer + slot) * 16 + (k)] = t_; } } while (0)
+// the token's tail (round 4, tools/tail_timeline.py): bank tk % 8 of 16 stamps at wall[4096 ..]: 0 the last layer's output published (token tk), 1 .. 4 lm_head
+// workgroup 0: that output seen / LayerNorm done / rows done / partials published, 5 .. 6 XCD 0's workgroup 0: token tk sampled / its embedding done
+#define XP_TAIL(tok, k) do { if (p.wall && tid == 0) p.wall[4096 + ((tok) & 7) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define XP_WALL(k) do {} while (0)
+#define XP_TAIL(tok, k) do {} while (0)
 #endif
 
 // to ANOTHER XCD (the layer output): write-through (sc1) store, visible at the memory side
@@ -329,6 +333,55 @@ __device__ __forceinline__ float xp_kv_load1(__amdgpu_buffer_rsrc_t r, const flo
     else return __builtin_nontemporal_load(base + elem);
 }
 
+// arg-max steps without the LDS crossbar (round 4: __shfl_xor is a ds_bpermute, ~120 cycles per step; a DPP move is one VALU instruction): the larger value wins,
+// equal values: the lower index (std::max_element's rule)
+template <int CTRL>
+__device__ __forceinline__ void xp_argmax_dpp(float &bv, int &bi) {
+    const float ov = dpp_f<CTRL>(bv);
+    const int oi = dpp_i<CTRL>(bi);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+// ... over the whole wave: four DPP steps inside the 16-lane rows, then the four row results through readlane; the result is uniform
+__device__ __forceinline__ void xp_argmax_wave(float &bv, int &bi) {
+    xp_argmax_dpp<DPP_QUAD_XOR1>(bv, bi); xp_argmax_dpp<DPP_QUAD_XOR2>(bv, bi); xp_argmax_dpp<DPP_ROW_HALF_MIRROR>(bv, bi); xp_argmax_dpp<DPP_ROW_MIRROR>(bv, bi);
+    float rv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 0));
+    int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), r));
+        const int oi = __builtin_amdgcn_readlane(bi, r);
+        if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    bv = rv; bi = ri;
+}
+// Four consecutive elements (4 t .. 4 t + 3, inside one 32-element block) of row `row` of a block-quantized matrix of type WT, dequantized as dequant_elem does
+// (get_rows) -- with ONE 4-byte load of the quants (+ the scale, + Q5's fifth bits) instead of four byte loads and four scale loads: the embedding of
+// the sampled token is a dependent load on every token's chain (round 4, tools/tail_timeline.py: 3.1 us of a 251 us token with the generic form).
+template <int WT>
+__device__ __forceinline__ void xp_row4_request(const DevMatrix &m, int row, int t, uint32_t &q, uint32_t &sc, uint32_t &qh) {
+    using TI = TypeInfo<WT>;
+    const int64_t blk = (int64_t)row * (m.K / QK) + (t >> 3);
+    const int j = (4 * t) & 31;
+    if (WT == W_Q8_0) q = *reinterpret_cast<const uint32_t *>(m.qs + blk * 32 + j);
+    else q = *reinterpret_cast<const uint32_t *>(m.qs + blk * 16 + (j & 15));
+    sc = TI::q81 ? reinterpret_cast<const uint32_t *>(m.sc)[blk] : (uint32_t)reinterpret_cast<const uint16_t *>(m.sc)[blk];
+    qh = (WT == W_Q5_0 || WT == W_Q5_1) ? m.qh[blk] : 0u;
+}
+template <int WT>
+__device__ __forceinline__ void xp_row4_values(uint32_t q, uint32_t sc, uint32_t qh, int t, float (&e)[4]) {
+    const int j = (4 * t) & 31;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (WT == W_Q8_0) { e[i] = __fmul_rn((float)(int8_t)((q >> (8 * i)) & 0xFFu), h2f((uint16_t)sc)); continue; }
+        const uint32_t byte = (q >> (8 * i)) & 0xFFu;
+        int v = (j < 16) ? (int)(byte & 0x0Fu) : (int)(byte >> 4);
+        if (WT == W_Q5_0 || WT == W_Q5_1) v |= (int)((qh >> (j + i)) & 1u) << 4;
+        if (WT == W_Q4_0) e[i] = __fmul_rn((float)(v - 8), h2f((uint16_t)sc));
+        else if (WT == W_Q5_0) e[i] = __fmul_rn((float)(v - 16), h2f((uint16_t)sc));
+        else e[i] = __fadd_rn(__fmul_rn((float)v, h2f((uint16_t)(sc & 0xFFFFu))), h2f((uint16_t)(sc >> 16)));
+    }
+}
+
 // a lane's 4 x int8 and the three lanes above it packed into one word (valid in lanes with lane % 4 == 0)
 __device__ __forceinline__ uint32_t xp_pack4(int8_t q) {
     const int b = (int)(uint8_t)q;
@@ -510,6 +563,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (L == 0) {
                 int tok;
+                // the position's row of embed_positions does not depend on the token: requested before the sampler, in registers when the token is known
+                const bool emb_fast = p.tok_emb.type == WT && p.pos_emb.type == WT;
+                uint32_t pq = 0u, psc = 0u, pqh = 0u;
+                if (emb_fast && worker) xp_row4_request<WT>(p.pos_emb, n_past + 2, tid, pq, psc, pqh);
                 // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
                 // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024); every thread returns the arg-max
                 auto sample_prev = [&]() __attribute__((always_inline)) -> int {
@@ -543,12 +600,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                         }
                     }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const float ov = __shfl_xor(bv, off, 64);
-                        const int oi = __shfl_xor(bi, off, 64);
-                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                    }
+                    xp_argmax_wave(bv, bi);
                     if (lane == 0) { s_redf[wave] = bv; s_redi[wave] = bi; }
                     __syncthreads();
                     bv = s_redf[0]; bi = s_redi[0];
@@ -661,11 +713,22 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 } else {
                     tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
                 }
+                if (slot == 0) XP_TAIL(tk, 5);
                 if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
                     float e[4];
+                    if (emb_fast) {
+                        uint32_t tq, tsc, tqh;
+                        xp_row4_request<WT>(p.tok_emb, tok, tid, tq, tsc, tqh);
+                        float te[4], pe[4];
+                        xp_row4_values<WT>(pq, psc, pqh, tid, pe);
+                        xp_row4_values<WT>(tq, tsc, tqh, tid, te);
     #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                        for (int j = 0; j < 4; j++) e[j] = __fadd_rn(__fmul_rn(te[j], p.embed_scale), pe[j]);
+                    } else {
+    #pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                    }
                     xv = make_float4(e[0], e[1], e[2], e[3]);
                 }
             } else if (wave < 4) {
@@ -765,6 +828,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 for (int s = 0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
                 const float4 xv = layer_input();
                 XP_WALL(0);
+                if (L == 0 && slot == 0) { asm volatile("" :: "v"(xv.x)); XP_TAIL(tk, 6); }
                 float4 lnw = xv, lnb = xv;
                 if (worker) {
                     reinterpret_cast<float4 *>(s_x)[tid] = xv;
@@ -772,6 +836,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
                 ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
                 XP_WALL(6);
+                if (L == 0 && slot == 0) XP_TAIL(tk, 7);
                 uint32_t ax[8];
                 const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
                 ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
@@ -1062,6 +1127,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
         }
         XP_WALL(5);
+        if (L == p.n_layer - 1 && slot == 0) XP_TAIL(tk, 0);
         }   // SECOND
         __syncthreads();       // s_ln / s_bias / s_x1 are rewritten by the next unit of this XCD
     }
@@ -1105,8 +1171,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             uint32_t v[4];
             xp_sweep_q<RES, 4, 256, true>(p.layers[p.n_layer - 1].gx + tid, true, epoch, v, p, etag);
             xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            if (lm_rank == 0) XP_TAIL(tk, 1);
         }
         ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+        if (lm_rank == 0) XP_TAIL(tk, 2);
         uint32_t ax[8];
         const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
         ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
@@ -1130,13 +1198,11 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 best_val = v; best_idx = row;
             }
         }
+        if (lm_rank == 0) XP_TAIL(tk, 3);
         // per-block partial arg-max (lowest index wins ties): groups of 64 / NW lanes, then the NW waves through LDS
-#pragma unroll
-        for (int off = 1; off < 64 / NW; off <<= 1) {
-            const float ov = __shfl_xor(best_val, off, 64);
-            const int oi = __shfl_xor(best_idx, off, 64);
-            if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
-        }
+        static_assert(64 / NW == 8 || 64 / NW == 4, "finisher lanes per block");
+        xp_argmax_dpp<DPP_QUAD_XOR1>(best_val, best_idx); xp_argmax_dpp<DPP_QUAD_XOR2>(best_val, best_idx);
+        if (64 / NW == 8) xp_argmax_dpp<DPP_ROW_HALF_MIRROR>(best_val, best_idx);
         constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
         if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
         bool row_ok = true;
@@ -1191,6 +1257,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 if (RES && (p.res_dbg & 32) && p.wall && blk == 0) p.wall[32768 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 4 + 3] = wall_clock64();
             }
         }
+        if (lm_rank == 0) XP_TAIL(tk, 4);
         __syncthreads();       // s_redf / s_part / s_xq are rewritten by this workgroup's next layer
     }
     }   // tokens

@@ -212,6 +212,10 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
  * the flat [n_layer][n_positions][d_model] array (biogpt.cpp:331-335) to host memory. */
 int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t count, float *out);
 
+/* Profiling builds only (-DBIOGPT_HIP_PROFILE_HOOKS, BIOGPT_HIP_DBG=128; no reference counterpart): the raw wall-clock stamps (100 MHz ticks) the
+ * pipelined decode launches left in the context's stamp buffer, `count` words from word `offset` (tools/tail_timeline.py). */
+int biogpt_hip_debug_stamps(biogpt_hip_ctx *ctx, size_t offset, size_t count, unsigned long long *out);
+
 /* Stand-alone launch of the block-quantized mat-vec kernel on a weight matrix of the loaded
  * model, for kernel-level roofline timing: which = 0 fc1 of layer `layer`, 1 fc2,
  * 2 q/k/v fused, 3 out_proj, 4 lm_head (5-11: internal, see bench.py), 12 lm_head with the weights taken from a
