@@ -155,6 +155,14 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
 #ifndef XP_CROSS_PIPE
 #define XP_CROSS_PIPE 1
 #endif
+// XP_H16: the fc1 activations (the largest hand-off of a layer: 1152 granules polled by all 32 workgroups) travel as 16-byte granules {3 words, tag}: 512 per layer,
+// ONE aligned 16-byte plain store per producing lane, ONE 16-byte agent-scope load per polling lane and pass.  A 16-byte access of one lane to a naturally aligned
+// address is one request of one cache line at the XCD's L2 and was never observed torn on gfx950 (tools/microbench19.hip: 10^9 granule reads against a writer;
+// MI355X_MICROARCH.md says the same of 16-byte sc1 halves) -- an observation, not an architectural guarantee: measured at +0.4 % (4010 -> 4025 tok/s,
+// profiles/xpipe_ab_r4.txt), it stays OFF -- the 8-byte granules are single-copy atomic by the memory model, and 0.4 % does not buy a silent-corruption mode.
+#ifndef XP_H16
+#define XP_H16 0
+#endif
 #ifndef XP_LOCAL_PIPE
 #define XP_LOCAL_PIPE 0
 #endif
@@ -1035,11 +1043,48 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             q8_block32(s_g[tid], TI::q81, q8, d8, s8, TI::q81);
             const uint32_t packed = xp_pack4(q8);
             const int blk = slot * 4 + (tid >> 5);
+#if XP_H16
+            // the block's eight words sit in lanes 0, 4, .. 28 of its 32 lanes (two 16-lane rows); four granules per block, each assembled inside ONE row:
+            //   lane 0: {w0, w1, w2}   lane 12: {w3, d, s}   lane 16: {w4, w5, w6}   lane 28: {w7, 0, 0}      (granule 4 blk + 0 .. 3)
+            const uint32_t up4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)packed, 0x104, 0xf, 0xf, true);      // row_shl:4 -- the word of lane + 4
+            const uint32_t up8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)packed, 0x108, 0xf, 0xf, true);      // row_shl:8
+            const int l32 = tid & 31;
+            if (l32 == 0 || l32 == 12 || l32 == 16 || l32 == 28) {
+                const bool first = (l32 & 15) == 0;
+                xp_v4u gq;
+                gq.x = packed;
+                gq.y = first ? up4 : (l32 == 12 ? __float_as_uint(d8) : 0u);
+                gq.z = first ? up8 : (l32 == 12 ? s8 : 0u);
+                gq.w = etag;
+                const int gi = blk * 4 + (l32 == 0 ? 0 : l32 == 12 ? 1 : l32 == 16 ? 2 : 3);
+                *reinterpret_cast<xp_v4u *>(reinterpret_cast<unsigned char *>(G + XP_G_H) + (size_t)gi * 16) = gq;      // plain store: the line stays in the XCD's L2
+            }
+#else
             if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), etag, packed);
             if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_H + 1152 + blk, etag, s8); }
+#endif
         }
         XP_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
+#if XP_H16
+        {   // 512 granules of 16 bytes, one per thread: {3 words, tag}
+            static_assert(NT == 512, "one 16-byte granule per thread");
+            const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(G + XP_G_H), 0, 512 * 16, 0x00027000);
+            xp_v4u gq = {0u, 0u, 0u, 0u};
+            for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
+                gq = __builtin_amdgcn_raw_buffer_load_b128(hrs, tid * 16, 0, XP_CPOL_SC1);      // agent scope: the L1 is not consulted, the XCD's L2 answers
+                if (__all(gq.w == epoch)) break;
+                if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) etag = 0u; break; }
+                if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
+                xp_poll_pause();
+            }
+            const int blk = tid >> 2, part = tid & 3;
+            if (part == 0) { s_hq[blk * 8 + 0] = gq.x; s_hq[blk * 8 + 1] = gq.y; s_hq[blk * 8 + 2] = gq.z; }
+            else if (part == 1) { s_hq[blk * 8 + 3] = gq.x; s_hd[blk] = __uint_as_float(gq.y); s_hs[blk] = gq.z; }
+            else if (part == 2) { s_hq[blk * 8 + 4] = gq.x; s_hq[blk * 8 + 5] = gq.y; s_hq[blk * 8 + 6] = gq.z; }
+            else s_hq[blk * 8 + 7] = gq.x;
+        }
+#else
         {   // 1024 + 128 + 128 granules in ONE poll loop: every pass has all of a lane's loads in flight together
             constexpr int NQ = 1024 / NT;
             uint32_t v[NQ + 1];
@@ -1088,6 +1133,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (tid < 128) s_hd[tid] = __uint_as_float(v[NQ]);
             else if (tid < 256) s_hs[tid - 128] = v[NQ];
         }
+#endif
         __syncthreads();
         XP_WALL(12);
         {
