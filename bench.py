@@ -379,8 +379,8 @@ def main():
                              "60-72 tokens per launch)" % (args.ftype.upper(), hp.n_layer))
                     method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel as a single-token launch (hipGraph, as biogpt_eval's step is replayed), real arena weights; "
                               "algorithmic bytes = the four matrices of every layer and the output projection at file density + K / V rows of 104 keys + the new K / V rows + x in / out + the logits row; "
-                              "rocprofv3 agreement: profiles/rocprofv3_kernel_stats_r3.csv is taken with BIOGPT_HIP_XPIPE_MULTI=0 BIOGPT_HIP_RESIDENT=0 (every call one token); "
-                              "the launch is LATENCY-bound by design: a layer is %.1f us of dependent stages (profiles/xpipe_timeline_r3.txt) on 1/8 of the chip while the "
+                              "rocprofv3 agreement: profiles/rocprofv3_kernel_stats_r4.csv is taken with BIOGPT_HIP_XPIPE_MULTI=0 BIOGPT_HIP_RESIDENT=0 (every call one token); "
+                              "the launch is LATENCY-bound by design: a layer is %.1f us of dependent stages (profiles/xpipe_timeline_r4.txt) on 1/8 of the chip while the "
                               "other XCDs prefetch -- 8 TB/s would move a layer's 7.1 MB in 0.9 us" % (sx * 1e6 / hp.n_layer))
             else:
                 secs, nbytes = model.bench_matvec(0, layer=0, reps=reps)        # fc1: LN + mat-vec + GELU (generic kernels)
@@ -403,7 +403,7 @@ def main():
                 "bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 # HBM bytes from PMC counters need their own rocprofv3 --pmc passes: two child processes after the timed work (pmc_traffic below; null when
-                # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r3.txt)
+                # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r4.txt)
                 "traffic": None,
                 "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
                 "method": (method if quant and method else
