@@ -171,7 +171,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -215,6 +215,7 @@ struct EngineOptions {
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
         mfma_nt2_min = get("BIOGPT_HIP_MFMA_NT2_MIN", 64);
+        mfma_nt2_rows = get("BIOGPT_HIP_MFMA_NT2_ROWS", 2048);   // ... for matrices of at least this many rows (1024-row matrices: one wave per SIMD at 512 columns -- measured slower)
         eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
@@ -490,7 +491,7 @@ hipError_t launch_mfma_nt(const bgk::MatvecParams &p, const bgk::DevMatrix &img,
 // but fc2 25.3 -> 28.6 us and out_proj 8.6 -> 9.3 us -- 1024 rows x 512 columns are only 1024 such waves, one per SIMD
 template <int WT, int EPI, int K>
 hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    if (opt().mfma_nt2_min > 0 && p.N >= opt().mfma_nt2_min && p.W.M >= 2048) return launch_mfma_nt<WT, EPI, K, 2>(p, img, st);
+    if (opt().mfma_nt2_min > 0 && p.N >= opt().mfma_nt2_min && p.W.M >= opt().mfma_nt2_rows) return launch_mfma_nt<WT, EPI, K, 2>(p, img, st);
     return launch_mfma_nt<WT, EPI, K, 1>(p, img, st);
 }
 template <int WT>

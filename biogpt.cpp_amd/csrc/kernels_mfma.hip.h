@@ -35,6 +35,11 @@ namespace bgk {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
+// weight batches (4 blocks each) in flight per wave: 2 (round 2) or 3 (round 4 experiment, profiles/prefill_mfma_depth_r4.txt)
+#ifndef MFMA_DEPTH
+#define MFMA_DEPTH 2
+#endif
+
 // ---- row-tiled, EXPANDED weight image (round 4) ---------------------------------------------------------------
 // src (SoA arena): qs[(row*BPR + b) * QB], sc[(row*BPR + b)], qh[(row*BPR + b)]
 // dst (image)    : index i = (tile*BPR + b)*16 + r  with tile = row / 16, r = row % 16   (M is a multiple of 16):
@@ -172,6 +177,9 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
 
     const MfmaLanePtrs<WT> lp = mfma_lane_ptrs<WT>(img, base, li, g);
     MfmaBatch<WT> t0, t1;
+#if MFMA_DEPTH == 3
+    MfmaBatch<WT> t2;
+#endif
     mfma_load_batch<WT>(t0, lp, 0);
     // epilogue inputs (independent loads); M is a multiple of 4 everywhere
     const int orc = min(orow, M - 4);
@@ -273,6 +281,23 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
         if (ph > 0) mfma_load_batch<WT>(t0, lp, ph * BPP);
         __builtin_amdgcn_s_waitcnt(0x0f70);                                     // vmcnt(0): the direct-to-LDS loads of this wave have landed (the barrier publishes them)
         __syncthreads();
+#if MFMA_DEPTH == 3
+        // three weight batches in flight: a batch is requested two consume steps (8 blocks) before its MFMAs
+        mfma_load_batch<WT>(t1, lp, ph * BPP + CH);
+#pragma unroll 1
+        for (int nb = 0; nb < NB; nb += 3) {
+            if (nb + 2 < NB) mfma_load_batch<WT>(t2, lp, ph * BPP + (nb + 2) * CH);
+            consume(t0, nb * CH);
+            if (nb + 1 < NB) {
+                if (nb + 3 < NB) mfma_load_batch<WT>(t0, lp, ph * BPP + (nb + 3) * CH);
+                consume(t1, (nb + 1) * CH);
+            }
+            if (nb + 2 < NB) {
+                if (nb + 4 < NB) mfma_load_batch<WT>(t1, lp, ph * BPP + (nb + 4) * CH);
+                consume(t2, (nb + 2) * CH);
+            }
+        }
+#else
 #pragma unroll 1
         for (int nb = 0; nb < NB; nb += 2) {
             mfma_load_batch<WT>(t1, lp, ph * BPP + (nb + 1) * CH);
@@ -280,6 +305,7 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
             if (nb + 2 < NB) mfma_load_batch<WT>(t0, lp, ph * BPP + (nb + 2) * CH);
             consume(t1, (nb + 1) * CH);
         }
+#endif
     }
 
     if (EPI == EPI_GELU_Q8) {
