@@ -647,279 +647,7 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
     return true;
 }
 
-// ---- XCD-pipelined decode step (kernels_xpipe.hip.h): one persistent launch for all layers ------------------------
-// Two such launches of different contexts on one device could each hold part of the compute units and wait for the rest
-// (their workgroups only leave when their pipeline has run), so one context per device holds the path at a time: the slot is
-// taken when a pipelined launch (or a graph holding one) is about to be enqueued and handed back whenever the holder's stream
-// is known to be idle (every synchronising API call ends in xpipe_check).  A context that finds the slot taken runs that call on
-// the five-launch layer.  The slot table is the ONE piece of process-global state of this library; it serialises contexts of
-// this process only -- two PROCESSES driving pipelined contexts on one device are not coordinated.
-std::mutex g_xp_mu;
-biogpt_hip_ctx *g_xp_owner[64] = {};
-
-void xpipe_release(biogpt_hip_ctx *c) {
-    {
-        std::lock_guard<std::mutex> lk(g_xp_mu);
-        if (c->device >= 0 && c->device < 64 && g_xp_owner[c->device] == c) g_xp_owner[c->device] = nullptr;
-    }
-    if (c->xp_layers) (void)hipFree(c->xp_layers);
-    if (c->xp_gran) (void)hipFree(c->xp_gran);
-    if (c->xp_gran_l) (void)hipFree(c->xp_gran_l);
-    if (c->xp_hop) (void)hipFree(c->xp_hop);
-    if (c->xp_ctl) (void)hipFree(c->xp_ctl);
-    if (c->xp_samp) (void)hipFree(c->xp_samp);
-    if (c->xp_err_host) (void)hipHostFree(c->xp_err_host);
-    if (c->res_mbox) (void)hipHostFree(c->res_mbox);
-    if (c->res_done) (void)hipHostFree(c->res_done);
-    c->res_mbox = nullptr; c->res_done = nullptr;
-    c->xp_layers = nullptr; c->xp_gran = nullptr; c->xp_gran_l = nullptr; c->xp_hop = nullptr; c->xp_ctl = nullptr; c->xp_samp = nullptr; c->xp_err_host = nullptr;
-}
-
-bool xpipe_model_ok(const biogpt_hip_ctx *c) {
-    const auto &hp = c->hp;
-    const int32_t wt = ftype_to_type(hp.ftype);
-    return (wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1 || wt == T_Q8_0) && hp.d_model == 1024 && hp.d_ff == 4096 && hp.n_head == 16 &&
-           hp.n_positions >= 64 && hp.n_layer >= 1;
-}
-
-// the pipelined kernels live in their own translation unit (xpipe_tu.hip)
-extern "C" int bg_xpipe_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
-extern "C" int bg_xpipe_set_lds(int wt, size_t smem_bytes);
-
-// pipeline units of the model: half layers (attention half on an even XCD, MLP half on the next, odd one); the XCD of the last one (and XCD 0)
-// computes no lm_head rows
-int xpipe_last_xcd(const biogpt_hip_ctx *c) {
-    const int units = 2 * c->hp.n_layer;
-    return (units - 1) & 7;
-}
-// > 64 KB of dynamic LDS needs the opt-in attribute (per device); set outside any stream capture
-bool xpipe_set_lds(biogpt_hip_ctx *c) {
-    const size_t sm = bgk::xpipe_smem_bytes(c->xp_gelu_p + c->xp_gelu_n);
-    if (sm <= 64 * 1024) return true;
-    return bg_xpipe_set_lds(ftype_to_type(c->hp.ftype), sm) == (int)hipSuccess;     // T_* values are the kernels' WType values
-}
-
-// Where the two cross-XCD hand-offs of every layer live (XpLayer::gx1, gx).  Device memory is interleaved over the two halves of the chip in 8 KB units
-// (tools/microbench18.hip, profiles/microbench18_hop_by_address_r4.txt): a granule written on XCD a and polled on XCD b takes 0.40 us when its line is near both,
-// 0.60 us when it is far from both, 0.50 us across the halves whatever the line.  Every region therefore has TWO 8 KB-aligned candidates (neighbours: one of each
-// kind) and a calibration launch plays ping-pong over both between the XCDs of ITS hop (bgk::xp_hop_probe_kernel: the stores and polls of the real hand-off);
-// the faster one is used.  mode (BIOGPT_HIP_HOP_PLACE): 1 calibrated (default), 0 always the first candidate, 2 the slower one (A/B).
-bool xpipe_place_hops(biogpt_hip_ctx *c, std::vector<bgk::XpLayer> &tab) {
-    const int nl = c->hp.n_layer, mode = c->opt.hop_place;
-    const size_t region = 1024, bytes = (size_t)nl * 4 * region * 8 + 16384;      // [layer][x1, x][candidate][1024 granules], 16 KB-aligned
-    if (hipMalloc(&c->xp_hop, bytes) != hipSuccess || hipMemset(c->xp_hop, 0, bytes) != hipSuccess) return false;
-    bgk::xp_u64 *base = reinterpret_cast<bgk::xp_u64 *>((reinterpret_cast<uintptr_t>(c->xp_hop) + 16383) & ~(uintptr_t)16383);
-    auto cand = [&](int l, int which, int k) { return base + ((size_t)(l * 2 + which) * 2 + k) * region; };
-    std::vector<int> pick((size_t)nl * 2, 0);
-    if (mode != 0) {
-        std::vector<bgk::XpProbe> pr;
-        for (int l = 0; l < nl; l++)
-            for (int which = 0; which < 2; which++) {
-                const int src = (2 * l + which) & 7;      // x1: unit 2 l -> 2 l + 1; x: unit 2 l + 1 -> 2 l + 2
-                // the last layer's output goes to every XCD that computes lm_head rows: readers in BOTH halves of the chip -- near the producer's half costs the far readers
-                // 0.5 us and the near ones 0.4, near the other half 0.5 and 0.6: judged by a hop that stays in the producer's half
-                const int dst = (l == nl - 1 && which == 1) ? (src ^ 1) : ((src + 1) & 7);
-                for (int k = 0; k < 2; k++)
-                    for (int line = 0; line < 2; line++) pr.push_back({cand(l, which, k) + (line ? 512 + 130 : 2), src, dst});
-            }
-        bgk::XpProbe *d_pr = nullptr;
-        uint32_t *d_ctl = nullptr;
-        unsigned long long *d_ticks = nullptr;
-        const int reps = 12;
-        std::vector<unsigned long long> ticks(pr.size(), 0ull);
-        uint32_t err = 1u;
-        if (hipMalloc(&d_pr, pr.size() * sizeof(bgk::XpProbe)) == hipSuccess && hipMalloc(&d_ctl, 128) == hipSuccess && hipMalloc(&d_ticks, pr.size() * 8) == hipSuccess &&
-            hipMemcpy(d_pr, pr.data(), pr.size() * sizeof(bgk::XpProbe), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_ctl, 0, 128) == hipSuccess &&
-            hipMemset(d_ticks, 0, pr.size() * 8) == hipSuccess) {
-            hipLaunchKernelGGL(bgk::xp_hop_probe_kernel, dim3(256), dim3(64), 0, c->stream, d_pr, (int)pr.size(), reps, d_ctl, d_ticks, d_ctl + 16);
-            if (hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(ticks.data(), d_ticks, pr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-                (void)hipMemcpy(&err, d_ctl + 16, 4, hipMemcpyDeviceToHost);
-        }
-        (void)hipGetLastError();
-        if (d_pr) (void)hipFree(d_pr);
-        if (d_ctl) (void)hipFree(d_ctl);
-        if (d_ticks) (void)hipFree(d_ticks);
-        if (hipMemset(c->xp_hop, 0, bytes) != hipSuccess) return false;      // the probe values must not be mistaken for granules
-        if (err == 0u) {
-            double gain = 0.0;
-            for (int r = 0; r < nl * 2; r++) {
-                unsigned long long t[2];
-                for (int k = 0; k < 2; k++) t[k] = std::max(ticks[(size_t)(r * 2 + k) * 2], ticks[(size_t)(r * 2 + k) * 2 + 1]);      // a region is as slow as its slower line
-                const int fast = t[1] < t[0] ? 1 : 0;
-                pick[(size_t)r] = mode == 2 ? 1 - fast : fast;
-                gain += (double)(t[1 - fast] - t[fast]) * 10.0 / (2.0 * reps);
-            }
-            if (c->opt.verbose > 0) fprintf(stderr, "biogpt_hip: cross-XCD hand-off regions placed by measurement: the chosen 8 KB candidates are %.0f ns per hop faster than the others (mean over %d regions)\n", gain / (nl * 2), nl * 2);
-        }   // a failed calibration keeps the first candidates: slower hops, same results
-    }
-    for (int l = 0; l < nl; l++) { tab[(size_t)l].gx1 = cand(l, 0, pick[(size_t)l * 2]); tab[(size_t)l].gx = cand(l, 1, pick[(size_t)l * 2 + 1]); }
-    return true;
-}
-
-// once per context, outside any stream capture: is this an 8-XCD x 32-CU device that places workgroup b on XCD b % 8 ?
-// then the layer table, the granules and the control words.  Leaves xp_state = 1 or -1; never fails the caller.
-void xpipe_prepare(biogpt_hip_ctx *c) {
-    if (c->xp_state != 0) return;
-    c->xp_state = -1;
-    if (!xpipe_model_ok(c)) return;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || prop.multiProcessorCount != 256) { (void)hipGetLastError(); return; }
-    uint32_t *probe = nullptr;
-    if (hipMalloc(&probe, 256 * 4) != hipSuccess) { (void)hipGetLastError(); return; }
-    std::vector<uint32_t> where(256, 99u);
-    hipLaunchKernelGGL(bgk::xp_probe_kernel, dim3(256), dim3(64), 0, c->stream, probe);
-    bool ok = hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(where.data(), probe, 256 * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(probe);
-    int per_xcd[16] = {};
-    for (int b = 0; ok && b < 256; b++) per_xcd[where[(size_t)b] & 15u]++;
-    for (int x = 0; ok && x < 16; x++) ok = per_xcd[x] == (x < 8 ? 32 : 0);   // 8 XCDs, workgroups dealt evenly
-    if (!ok) { (void)hipGetLastError(); return; }
-    const auto &hp = c->hp;
-    const size_t P = (size_t)hp.n_positions, D = (size_t)hp.d_model;
-    std::vector<bgk::XpLayer> tab((size_t)hp.n_layer);
-    for (int l = 0; l < hp.n_layer; l++) {
-        const LayerSlots &L = c->plan.layers[(size_t)l];
-        bgk::XpLayer &y = tab[(size_t)l];
-        y.ln0_w = dev_vec(c, L.ln0_w); y.ln0_b = dev_vec(c, L.ln0_b); y.ln1_w = dev_vec(c, L.ln1_w); y.ln1_b = dev_vec(c, L.ln1_b);
-        y.bqkv = dev_vec(c, L.qkv_b); y.bo = dev_vec(c, L.o_b); y.b1 = dev_vec(c, L.fc1_b); y.b2 = dev_vec(c, L.fc2_b);
-        y.Wqkv = dev_matrix(c, L.qkv); y.Wo = dev_matrix(c, L.o); y.W1 = dev_matrix(c, L.fc1); y.W2 = dev_matrix(c, L.fc2);
-        y.kcache = c->memory_k + (size_t)l * P * D; y.vcache = c->memory_v + (size_t)l * P * D;
-    }
-    const size_t gbytes = (size_t)hp.n_layer * bgk::XP_G_LAYER * 8;
-    const uint32_t ctl0[3] = {1u, 0u, 1u};   // hand-off tag, error word, launch counter
-    if (!xpipe_place_hops(c, tab)) { (void)hipGetLastError(); xpipe_release(c); return; }
-    if (hipMalloc(&c->xp_layers, tab.size() * sizeof(bgk::XpLayer)) != hipSuccess || hipMalloc(&c->xp_gran, gbytes) != hipSuccess ||
-        hipMalloc(&c->xp_ctl, 64) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->xp_err_host), 64, hipHostMallocDefault) != hipSuccess ||
-        hipMemcpy(c->xp_layers, tab.data(), tab.size() * sizeof(bgk::XpLayer), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->xp_gran, 0, gbytes) != hipSuccess || hipMemset(c->xp_ctl, 0, 64) != hipSuccess ||
-        hipMemcpy(c->xp_ctl, ctl0, 12, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&c->xp_samp, 2056 * 8) != hipSuccess || hipMemset(c->xp_samp, 0, 2056 * 8) != hipSuccess) {
-        (void)hipGetLastError();
-        xpipe_release(c);
-        return;
-    }
-    if (hp.n_positions > 256 && c->opt.xpipe_long) {   // contexts beyond 256 keys: the key-range helpers' granules (393 KB per layer); without them those contexts keep the five-launch layer
-        const size_t lbytes = (size_t)hp.n_layer * bgk::XL_G_LAYER * 8;
-        if (hipMalloc(&c->xp_gran_l, lbytes) != hipSuccess || hipMemset(c->xp_gran_l, 0, lbytes) != hipSuccess) {
-            (void)hipGetLastError();
-            if (c->xp_gran_l) (void)hipFree(c->xp_gran_l);
-            c->xp_gran_l = nullptr;
-        }
-    }
-    if (c->opt.xpipe_fault) {
-        const uint32_t one = 1u;
-        (void)hipMemcpy(c->xp_ctl + 8, &one, 4, hipMemcpyHostToDevice);
-    }
-    {
-        // the GELU table, rebuilt exactly as upload_weights builds it: identity from some positive argument up to +inf, one constant from some negative
-        // argument down to the most negative finite value
-        std::vector<uint16_t> tg(65536);
-        for (uint32_t i = 0; i < 65536; i++) tg[i] = f32_to_f16(gelu_tanh_f32(f16_to_f32((uint16_t)i)));
-        int P = 0x7C01;
-        while (P > 0 && tg[(size_t)P - 1] == (uint16_t)(P - 1)) P--;
-        const uint16_t Z = tg[0xFBFF];
-        int N = 0x7C00;
-        while (N > 0 && tg[0x8000 + (size_t)N - 1] == Z) N--;
-        P = (P + 7) & ~7; N = (N + 7) & ~7;
-        const size_t lds_max = 160 * 1024;
-        if (c->opt.xpipe_tables & 1) {
-            if (P <= 0x7C00 && N <= 0x7C00 && bgk::xpipe_smem_bytes(P + N) <= lds_max) { c->xp_gelu_p = P; c->xp_gelu_n = N; c->xp_gelu_z = Z; }
-        }
-    }
-    if ((c->opt.xpipe_tables & 2) && c->xp_gelu_p + c->xp_gelu_n > 0) {
-        // ggml_soft_max's table, rebuilt exactly as upload_weights builds it: arguments are <= 0; entry [0] must be 1.0 and the entries 0 from some negative argument
-        // down to the most negative finite value; the slice in between shares the LDS region of the GELU slices (which only the MLP halves use)
-        std::vector<uint16_t> te(0x7C00);
-        for (uint32_t i = 0; i < 0x7C00; i++) te[i] = f32_to_f16(expf(f16_to_f32((uint16_t)(0x8000u + i))));
-        int N = 0x7C00;
-        while (N > 0 && te[(size_t)N - 1] == 0) N--;
-        N = (N + 7) & ~7;
-        if (f32_to_f16(expf(0.0f)) == 0x3C00 && N > 0 && N <= c->xp_gelu_p + c->xp_gelu_n) c->xp_exp_n = N;
-    }
-    if (!xpipe_set_lds(c)) { (void)hipGetLastError(); xpipe_release(c); return; }
-    *c->xp_err_host = 0u;
-    c->xp_state = 1;
-}
-
-// may a step of context bucket t_max go through the pipeline at all (model, device, options, bucket) ?
-bool xpipe_bucket_ok(const biogpt_hip_ctx *c, int t_max) {
-    return c->opt.xpipe && c->xp_state == 1 && (t_max <= 256 || (t_max <= 1024 && c->xp_gran_l != nullptr && c->opt.xpipe_long)) && c->device >= 0 && c->device < 64;
-}
-// ... and does this context hold the device's pipeline slot ?  Taken here if it is free -- or if its holder is outside every API call that took it and
-// has nothing in flight (a resident launch that left after its idle time keeps the slot until its context is called again: such a holder is relieved here;
-// it notices at its next call, like any context that finds the slot taken).
-bool xpipe_usable(biogpt_hip_ctx *c, int t_max) {
-    if (!xpipe_bucket_ok(c, t_max)) return false;
-    std::lock_guard<std::mutex> lk(g_xp_mu);
-    biogpt_hip_ctx *&owner = g_xp_owner[c->device];
-    if (owner != nullptr && owner != c && !owner->xp_in_call && hipStreamQuery(owner->stream) == hipSuccess) owner = nullptr;
-    (void)hipGetLastError();      // hipErrorNotReady of the query is not an error of this call
-    if (owner == nullptr) owner = c;
-    if (owner == c) c->xp_in_call = true;      // until the API call that asked returns (XpCallScope)
-    return owner == c;
-}
-// does another context of this process hold the device's pipeline slot (a persistent launch of its own may be on the device) ?
-bool xpipe_slot_held_by_other(const biogpt_hip_ctx *c) {
-    if (c->device < 0 || c->device >= 64) return false;
-    std::lock_guard<std::mutex> lk(g_xp_mu);
-    return g_xp_owner[c->device] != nullptr && g_xp_owner[c->device] != c;
-}
-// an API entry that may take the pipeline slot: while it runs, no other context may relieve this one of the slot (its launches are not enqueued yet)
-struct XpCallScope {
-    biogpt_hip_ctx *c;
-    explicit XpCallScope(biogpt_hip_ctx *ctx) : c(ctx) {}
-    ~XpCallScope() {
-        if (!c) return;
-        std::lock_guard<std::mutex> lk(g_xp_mu);
-        c->xp_in_call = false;
-    }
-};
-// the context's stream is idle (the caller just synchronised it): nothing pipelined is in flight, another context may have the slot
-void xpipe_handback(biogpt_hip_ctx *c) {
-    if (c->device < 0 || c->device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_xp_mu);
-    if (g_xp_owner[c->device] == c) g_xp_owner[c->device] = nullptr;
-}
-
-// after a synchronisation: did a hand-off of the pipeline time out (or a workgroup land on an unexpected XCD) ?  Then the
-// outputs of that call are garbage: report it, drop the captured graphs and never use the path again in this context.
-bool xpipe_check(biogpt_hip_ctx *c) {
-    xpipe_handback(c);
-    if (!c->xp_err_host || *c->xp_err_host == 0u) { c->unsynced_from = -1; return true; }
-    const uint32_t code = *c->xp_err_host;
-    if (code == bgk::XP_QUIT) {     // a resident launch left on its own (idle) or on request: not a failure; the device-side word is cleared in stream order
-        *c->xp_err_host = 0u;
-        HIP_TRY(false, hipMemsetAsync(c->xp_ctl + 1, 0, 4, c->stream));
-        return true;
-    }
-    *c->xp_err_host = 0u;
-    c->xp_state = -1;
-    c->xp_tripped = true;
-    for (auto &pl : c->graph_step) for (auto &row : pl) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    for (auto &pl : c->graph_eval) for (auto &f : pl) for (auto &row : f) for (auto &g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    BG_FAIL(false, "the XCD-pipelined decode step failed (code %u: %s); this context now uses the five-launch layer", code,
-            code == 2u ? "its workgroups were not dealt 32 per XCD -- another stream's kernels were dispatched in between" : code == 5u ? "hand-off tags used up" : "a hand-off timed out");
-}
-
-int graph_bucket(int T);
-int bucket_tmax(const biogpt_hip_ctx *c, int b);
-int fast_lm_grid(const biogpt_hip_ctx *c);
-bool fused_decode_ok(const biogpt_hip_ctx *c, int t_max);
-// tokens one pipelined launch may generate from context T = n_past + 1 on: up to the end of T's context bucket (0: not on the pipeline)
-// does the final LayerNorm + lm_head run inside the pipelined launch (its 64-row blocks four per workgroup of the XCDs that are done) ?
-bool xpipe_lm_folds(const biogpt_hip_ctx *c) {
-    const auto &hp = c->hp;
-    const MatSlot &m = c->plan.lm_head;
-    // workgroups that take rows: the pipelined launch up to 256 keys (kernels_xpipe.hip.h, xp_lm_rank) and the long-context one (kernels_xlong.hip.h: every XCD but XCD 0 and the last unit's)
-    const int lm_parts = fast_lm_grid(c), last_xcd = xpipe_last_xcd(c), lm_wgs = std::min(bgk::xp_lm_capacity(2 * hp.n_layer), 32 * (8 - 1 - (last_xcd != 0 ? 1 : 0)));
-    return c->opt.xpipe_lm && m.type == ftype_to_type(hp.ftype) && m.K == 1024 && m.M == hp.n_vocab && lm_parts == (hp.n_vocab + 63) / 64 && lm_parts <= 4 * lm_wgs && lm_parts <= 1024;
-}
-int xpipe_multi_tokens(biogpt_hip_ctx *c, int T) {
-    if (!c->opt.xpipe_multi || !xpipe_lm_folds(c)) return 0;
-    const int tmax = bucket_tmax(c, graph_bucket(T));
-    if (!fused_decode_ok(c, tmax) || !xpipe_usable(c, tmax)) return 0;
-    return tmax - T + 1;
-}
+#include "engine_xpipe.inc"
 
 // ---- fused single-token decode step (kernels_decode.hip.h): 3 launches per layer + lm_head ---------------------
 // tok_src 1: the token is in the device state (an eval call); 2: arg-max of the previous step's lm_head partials.
@@ -1735,228 +1463,7 @@ int biogpt_hip_merge(const biogpt_hip_ctx *ctx, int32_t rank, const char **bytes
     return 0;
 }
 
-// ---- resident single-token evals -------------------------------------------------------------------------------------------------------
-// biogpt_eval() is called once per token (main.cpp:91-151).  As separate launches every call pays the pipelined launch's start-up (arrival
-// tickets, first weight load exposed, GELU slice) + a graph launch + the completion poll: ~30 us of a ~300 us token.  With the device to itself
-// the launch can simply STAY: after token tk it waits -- bounded by BIOGPT_HIP_RESIDENT_US -- for the next call to drop {n_past, token, seq} into a
-// pinned mailbox, and every lm_head workgroup reports the rows it has written to the pinned logits row with a completion word.  A call then costs
-// two PCIe hops and no HIP API call.  Anything else the context is asked to do first ends the resident launch (resident_stop).
-static bool resident_stop(biogpt_hip_ctx *c) {
-    if (!c || !c->res_live) return true;
-    c->res_live = false;
-    if (c->res_left > 0 && c->res_mbox) {      // it still waits for tokens: ask it to leave (a slot whose position is not the expected one)
-        const uint32_t seq = ++c->res_seq;
-        __atomic_store_n(reinterpret_cast<unsigned long long *>(c->res_mbox + (size_t)(seq & 63u) * 8), bgk::xp_post(seq, 0x1fff, 0xffffff, 0), __ATOMIC_RELEASE);
-    }
-    c->res_left = 0;
-    c->spec_pending = false;
-    HIP_TRY(false, hipSetDevice(c->device));
-    HIP_TRY(false, hipStreamSynchronize(c->stream));      // a pass the launch started on its own account finishes first (at most one token's time)
-    const bool ok = xpipe_check(c);
-    if (c->res_acc & 1u) {      // the last pass the caller asked for wrote the alternate buffers: everything outside the resident launch reads the ordinary ones
-        const size_t V = (size_t)c->hp.n_vocab;
-        HIP_TRY(false, hipMemcpyAsync(c->logits, c->logits_alt, V * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(false, hipMemcpyAsync(c->pmax_val, c->pmax_val_alt, (size_t)c->pmax_cap * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(false, hipMemcpyAsync(c->pmax_idx, c->pmax_idx_alt, (size_t)c->pmax_cap * 4, hipMemcpyDeviceToDevice, c->stream));
-        c->res_acc = 0;
-    }
-    return ok;
-}
-
-// Speculation policy: a launch runs ahead of the caller only after spec_need consecutive calls whose token WAS the device's arg-max of the row before (a greedy
-// caller: always; a sampling caller: rarely for long), and every miss doubles spec_need (up to 64; 256 hits in a row halve it again) -- a miss costs the pass
-// that was started in vain plus a fresh launch.
-static bool spec_wanted(const biogpt_hip_ctx *c) { return c->opt.res_spec != 0 && c->spec_streak >= c->spec_need; }
-
-// the pinned row buffers: the logits row + (resident launches) the maxima of its 64-row blocks behind it (kernels_xpipe.hip.h, xp_blockmax_offset)
-static size_t host_row_bytes(const biogpt_hip_ctx *ctx) { return ((size_t)bgk::xp_blockmax_offset(ctx->hp.n_vocab) + 1024) * 4; }
-// one token through a resident launch; 1 = done (row in ctx->row_cur), 0 = not applicable here (caller takes the ordinary path), -2 = failure
-static int resident_eval(biogpt_hip_ctx *ctx, int32_t token, int32_t n_past) {
-    if (!ctx->opt.resident || ctx->opt.no_graph || !xpipe_lm_folds(ctx)) return 0;
-    const int tmax = bucket_tmax(ctx, graph_bucket(n_past + 1));
-    if (!fused_decode_ok(ctx, tmax) || !xpipe_bucket_ok(ctx, tmax)) return 0;      // up to 256 keys kernels_xpipe.hip.h, beyond (<= 1024) kernels_xlong.hip.h, each in its resident form
-    if (ctx->hp.n_vocab >= 0xffffff || ctx->hp.n_positions >= 0x1fff) return 0;      // the mailbox word's fields (xp_post)
-    const size_t V = (size_t)ctx->hp.n_vocab;
-    const volatile uint32_t *const err = reinterpret_cast<const volatile uint32_t *>(ctx->xp_err_host);
-    for (int attempt = 0; attempt < 4; attempt++) {
-        if (ctx->res_live && (*err != 0u || ctx->res_left <= 0 || n_past != ctx->res_next)) {
-            if (!resident_stop(ctx)) return -2;      // it has left (idle), is used up, or the caller moved elsewhere in the sequence
-        }
-        uint32_t seq;
-        if (ctx->res_live) {      // hand the token to the launch that is waiting for it -- or that has already started this position with its own arg-max
-            seq = ctx->res_seq + 1u;
-            // the device's arg-max of the previous row, written when that row was complete (a few microseconds before the caller could have read it)
-            bool have = false, gone = false;
-            int32_t guess = -1;
-            for (uint32_t spin = 0; spin < (ctx->spec_pending ? 0x40000000u : 1u); spin++) {
-                const unsigned long long rec = __atomic_load_n(ctx->res_spec, __ATOMIC_ACQUIRE);
-                if ((uint32_t)(rec >> 32) == seq) { have = true; guess = (int32_t)(uint32_t)rec; break; }
-                if (*err != 0u) { gone = true; break; }
-            }
-            if (ctx->spec_pending && !have) {      // the launch left before it got here (idle time-out, failure): a fresh launch takes the token
-                (void)gone;
-                if (!resident_stop(ctx)) return -2;
-                if (ctx->xp_state != 1) return 0;
-                continue;
-            }
-            if (have) ctx->spec_streak = (guess == token) ? ctx->spec_streak + 1 : 0;
-            if (ctx->spec_pending) {
-                if (guess != token) {      // the pass in flight is not the one the caller wants: it ends the launch (the post below would not match), a fresh one follows
-                    ctx->spec_misses++;
-                    ctx->spec_need = std::min(ctx->spec_need * 2, 64);      // (0.6 ^ 64 ~ 6e-15: a sampling caller does not get there; a greedy one is back after 64 tokens)
-                    ctx->spec_run = 0;
-                    if (!resident_stop(ctx)) return -2;
-                    if (ctx->xp_state != 1) return 0;
-                    continue;
-                }
-                ctx->spec_hits++;
-                if (++ctx->spec_run % 256 == 0) ctx->spec_need = std::max(4, ctx->spec_need / 2);      // a long run ahead of the caller earns the trust back
-            }
-            ctx->res_seq = seq;
-            ctx->res_next++; ctx->res_left--;
-            const bool spec_next = ctx->res_left > 0 && spec_wanted(ctx);
-            __atomic_store_n(reinterpret_cast<unsigned long long *>(ctx->res_mbox + (size_t)(seq & 63u) * 8), bgk::xp_post(seq, n_past, token, spec_next ? 1 : 0), __ATOMIC_RELEASE);
-            ctx->spec_pending = spec_next;
-        } else {
-            if (!xpipe_usable(ctx, tmax)) return 0;      // another context holds the device's pipeline slot
-            if (!ctx->res_mbox) {
-                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_mbox), 64 * 8 * 4, hipHostMallocDefault));
-                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_done), 256 * 4, hipHostMallocDefault));
-                std::memset(ctx->res_mbox, 0xff, 64 * 8 * 4);
-                std::memset(ctx->res_done, 0, 256 * 4);
-                ctx->res_seq = 0; ctx->res_acc = 0;      // fresh completion words: the sequence numbers start over with them (a zeroed word must never look "ahead" of a late number)
-            }
-            if (!ctx->res_spec) {
-                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->res_spec), 64, hipHostMallocDefault));
-                std::memset(ctx->res_spec, 0, 64);
-                HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host_alt), host_row_bytes(ctx), hipHostMallocDefault));
-                HIP_TRY(-2, hipMalloc(&ctx->logits_alt, V * 4));
-                HIP_TRY(-2, hipMalloc(&ctx->pmax_val_alt, (size_t)ctx->pmax_cap * 4));
-                HIP_TRY(-2, hipMalloc(&ctx->pmax_idx_alt, (size_t)ctx->pmax_cap * 4));
-            }
-            if (!ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), host_row_bytes(ctx), hipHostMallocDefault));
-            if ((ctx->opt.res_dbg & 32) && !ctx->tstamp) {
-                HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
-                HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
-            }
-            seq = ++ctx->res_seq;
-            const int n_tok = tmax - n_past;          // up to the end of the context bucket
-            const bool spec_next = n_tok > 1 && spec_wanted(ctx);
-            const ResidentArgs ra{token, n_past, seq, spec_next ? 1 : 0};
-            bool row_done = false;
-            if (!enqueue_decode_fused(ctx, tmax, 1, 0, 0, -1, -1, n_tok, ctx->logits_host, &row_done, 1, &ra)) return -2;
-            if (!row_done) BG_FAIL(-2, "internal: the resident launch does not write the host row");
-            ctx->res_live = true; ctx->res_next = n_past + 1; ctx->res_left = n_tok - 1;
-            ctx->res_nw = (ctx->lm_blocks + 3) / 4;
-            ctx->mbox_synced = ctx->mbox_sent;
-            ctx->spec_pending = spec_next;
-        }
-        // completion: one word per lm_head workgroup, written behind its rows (a launch that runs ahead may already have moved a word on to the next number)
-        const volatile uint32_t *done = ctx->res_done;
-        const int nw = ctx->res_nw;
-        // no clock on the fast path (a clock read is a system call on some virtualised hosts: microseconds): the 5 s guard starts counting after ~10^6 polls
-        std::chrono::steady_clock::time_point t0{};
-        if (ctx->opt.res_dbg & 8) {      // time between the previous call's return and this post = the caller's own time + this function's overhead
-            t0 = std::chrono::steady_clock::now();
-            if (ctx->res_calls > 0) ctx->res_t_call += std::chrono::duration<double>(t0 - ctx->res_t_last).count();
-            ctx->res_calls++;
-        }
-        bool ok = false, left = false, timing = false;
-        std::chrono::steady_clock::time_point tg{};
-        int k = 0;                       // completion words seen so far
-        for (uint32_t spin = 0;; spin++) {
-            while (k < nw && (int32_t)(done[k] - seq) >= 0) k++;
-            if (k == nw) { ok = true; break; }
-            if (*err != 0u) { left = true; break; }
-            if ((spin & 0xfffffu) == 0xfffffu) {
-                if (!timing) { tg = std::chrono::steady_clock::now(); timing = true; }
-                else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count() > 5.0) break;
-            }
-        }
-        if (ok) {
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            ctx->res_acc = seq;
-            ctx->row_cur = (seq & 1u) ? ctx->logits_host_alt : ctx->logits_host;
-            if (ctx->opt.res_dbg & 8) { ctx->res_t_last = std::chrono::steady_clock::now(); ctx->res_t_wait += std::chrono::duration<double>(ctx->res_t_last - t0).count(); }
-            return 1;
-        }
-        if (!left) { (void)resident_stop(ctx); BG_FAIL(-2, "a resident decode launch did not answer within 5 s"); }
-        // the launch left (idle time-out racing with this call) or failed: wait for it, then this token goes into a fresh launch -- or, after a
-        // failure, onto the five-launch layer through the ordinary path
-        if (!resident_stop(ctx)) return -2;
-        if (ctx->xp_state != 1) return 0;
-    }
-    return 0;
-}
-
-// form 0: the step; form 1: the step + a last node that writes the logits row into pinned host memory (biogpt_hip_eval)
-static int eval_device_impl(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, int form, bool *row_in_host = nullptr) {
-    XpCallScope xp_scope(ctx);
-    clear_error();
-    if (row_in_host) *row_in_host = false;
-    if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
-    HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
-    // one token at a position of the five-launch decode step: replay its captured graph -- its first node pulls the
-    // token and the position from a pinned mailbox slot -- instead of a copy command and 121 launches one by one
-    if (n == 1 && !ctx->opt.no_graph && fused_decode_ok(ctx, bucket_tmax(ctx, graph_bucket(n_past + 1)))) {   // the captured step runs at the BUCKET's context bound
-        if (ctx->mbox_host && ctx->mbox_sent - ctx->mbox_synced >= 64) {   // never overwrite a slot a queued replay has not read yet
-            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-            ctx->mbox_synced = ctx->mbox_sent;
-            if (!xpipe_check(ctx)) return -2;
-        }
-        const int b = graph_bucket(n_past + 1);
-        const int pl = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;   // holds the slot until the stream is next synchronised (xpipe_check)
-        // ANOTHER context of this process holds the device's pipeline slot right now -- typically with a resident launch that waits for its caller's next token:
-        // this context's replayed five-launch graph then runs in the shadow of a persistent kernel that drains while the graph starts, and on this runtime the
-        // graph's last nodes were observed to see the PREVIOUS replay's activations (tools/dbg_two_contexts.py, profiles/two_contexts_r4.txt: the returned row was
-        // exactly the row of the call before, K / V rows correct; eager launches of the same kernels are not affected).  Such a call takes the eager launches.
-        const bool contended = pl == 0 && xpipe_slot_held_by_other(ctx);
-        if (contended) goto eager;
-        if (!ctx->mbox_host) {
-            HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->mbox_host), 64 * 8 * 4, hipHostMallocDefault));
-            HIP_TRY(-2, hipMalloc(&ctx->mbox_ctr, 16));
-            HIP_TRY(-2, hipMemset(ctx->mbox_ctr, 0, 16));
-        }
-        if (!ctx->graph_eval[pl][form][b][0]) {
-            const int L = ctx->hp.n_layer;
-            const int nseg = 1;
-            const int bounds[3] = {0, L, L};
-            const size_t V = (size_t)ctx->hp.n_vocab;
-            if (form == 1 && !ctx->logits_host) HIP_TRY(-2, hipHostMalloc(reinterpret_cast<void **>(&ctx->logits_host), host_row_bytes(ctx), hipHostMallocDefault));
-            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-            for (int sgi = 0; sgi < nseg; sgi++) {
-                hipGraph_t g = nullptr;
-                HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                if (sgi == 0) hipLaunchKernelGGL(bgk::fetch_state_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->mbox_host, ctx->mbox_ctr, ctx->state);
-                bool row_done = false;
-                const bool ok = enqueue_decode_fused(ctx, bucket_tmax(ctx, b), 1, 0, bounds[sgi], bounds[sgi + 1], -1, 1, form == 1 ? ctx->logits_host : nullptr, &row_done, pl);
-                if (ok && form == 1 && sgi == nseg - 1 && !row_done)
-                    hipLaunchKernelGGL(bgk::logits_to_host_kernel, dim3((unsigned)((V + 1023) / 1024)), dim3(256), 0, ctx->stream, ctx->logits, ctx->logits_host, (int)V);
-                const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-                if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
-                HIP_TRY(-2, e);
-                HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_eval[pl][form][b][sgi], g, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(g);
-            }
-            ctx->graph_eval_segs[form] = nseg;
-        }
-        int32_t *slot = ctx->mbox_host + (size_t)(ctx->mbox_sent & 63u) * 8;
-        if (ctx->opt.verbose > 1) fprintf(stderr, "biogpt_hip[%p]: single-token eval as a graph replay: pl %d form %d bucket %d n_past %d token %d mailbox slot %u\n", (void *)ctx, pl, form, b, n_past, tokens[0], ctx->mbox_sent & 63u);
-        slot[0] = n_past; slot[1] = ctx->opt.causal; slot[2] = tokens[0];
-        if (ctx->mbox_sent == ctx->mbox_synced) ctx->unsynced_from = n_past;
-        ctx->mbox_sent++;
-        for (int sgi = 0; sgi < ctx->graph_eval_segs[form]; sgi++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_eval[pl][form][b][sgi], ctx->stream));
-        if (row_in_host) *row_in_host = form == 1;
-        return 0;
-    }
-eager:
-    if (!upload_state(ctx, tokens, n, n_past)) return -2;
-    if (!enqueue_forward(ctx, n, false, n_past + n)) return -2;
-    return 0;
-}
-
-int biogpt_hip_eval_device(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past) { return eval_device_impl(ctx, tokens, n, n_past, 0); }
+#include "engine_resident.inc"
 
 // low-latency wait for everything enqueued on the context's stream (the caller is blocked on this token anyway).  BIOGPT_HIP_EVAL_SYNC=1: hipStreamSynchronize instead
 // (diagnostic)
@@ -2555,400 +2062,7 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
     return 0;
 }
 
-int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps, double *seconds_out, double *bytes_out) {
-    XpCallScope xp_scope(ctx);
-    clear_error();
-    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || (which < 4 && (layer < 0 || layer >= ctx->hp.n_layer)) || which > 12) BG_FAIL(-1, "bad argument");
-    if (which >= 6 && which != 12 && !fused_decode_ok(ctx, 104)) BG_FAIL(-1, "the five-launch decode layer needs BioGPT-base shapes and block-quantized weights");
-    HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
-    t_ctx = ctx;
-    const auto &hp = ctx->hp;
-    const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, P = hp.n_positions;
-    const int tw = target_wgs();
-    // cycling through the layers defeats L2 residency of one matrix; the whole model still
-    // fits the 256 MiB Infinity Cache -- stated in DESIGN.md
-    const int32_t wt0 = ftype_to_type(hp.ftype);
-    const bool chain = is_quantized(wt0) && D == 1024 && F == 4096 && D / hp.n_head == 64 && P <= 1024 &&
-                       !opt().no_fast && !opt().no_chain;
-    // which == 12: the stand-alone lm_head with its weights NOT resident in the Infinity Cache: 14 copies of the matrix (Q4_0: 14 x 24.6 MB = 344 MB > 256 MB + the L2s),
-    // a different one every launch -- the figure `north_star`'s "HBM roofline" means; which == 4 reads the one copy the model owns, which stays cache-resident between launches
-    struct ColdCopies {
-        std::vector<uint8_t *> v;
-        ~ColdCopies() { for (uint8_t *q : v) if (q) (void)hipFree(q); }
-    } cold;
-    size_t cold_sc_off = 0, cold_qh_off = 0;
-    if (which == 12) {
-        const MatSlot &m = ctx->plan.lm_head;
-        cold_sc_off = (m.qs_bytes + 255) & ~(size_t)255;
-        cold_qh_off = cold_sc_off + ((m.sc_bytes + 255) & ~(size_t)255);
-        const size_t total = cold_qh_off + m.qh_bytes + 256;
-        const int ncopy = (int)std::max<size_t>(3, ((size_t)344 << 20) / std::max<size_t>(1, total) + 1);
-        for (int i = 0; i < ncopy; i++) {
-            uint8_t *q = nullptr;
-            HIP_TRY(-2, hipMalloc(&q, total));
-            cold.v.push_back(q);
-            HIP_TRY(-2, hipMemcpyAsync(q, ctx->arena + m.qs, m.qs_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-            if (m.sc_bytes) HIP_TRY(-2, hipMemcpyAsync(q + cold_sc_off, ctx->arena + m.sc, m.sc_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-            if (m.qh_bytes) HIP_TRY(-2, hipMemcpyAsync(q + cold_qh_off, ctx->arena + m.qh, m.qh_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-    }
-    auto launch = [&](int l) -> bool {
-        ctx->launch_parity ^= 1;
-        if (which == 11) return enqueue_decode_fused(ctx, 104, 1, 0, 0, -1, -2);   // the XCD-pipelined launch alone: all layers of one token at 104 keys, no lm_head
-        if (which >= 6 && which <= 10) {   // one kernel of the five-launch decode layer (kernels_decode.hip.h), layer l mod L, `layer` = n_past for attention
-            const int ll = l % hp.n_layer;
-            return enqueue_decode_fused(ctx, 104, 0, 0, ll, ll + 1, which - 6);
-        }
-        if (which == 5) {  // attention of layer (l mod L) with `layer` keys in the cache
-            bgk::AttnParams a{};
-            const int ll = l % hp.n_layer, dk = D / hp.n_head;
-            a.q = ctx->q; a.kcache = ctx->memory_k + (size_t)ll * P * D; a.vcache = ctx->memory_v + (size_t)ll * P * D;
-            a.out = ctx->att; a.st = ctx->state;
-            a.exp_tab = reinterpret_cast<const uint16_t *>(ctx->arena + ctx->plan.exp_tab);
-            a.N = 1; a.D = D; a.dk = dk; a.P = P;
-            a.dbg = ctx->opt.dbg; a.tstamp = ctx->tstamp;
-            a.oq_q = ctx->aq_q[0]; a.oq_d = ctx->aq_d[0]; a.oq_s = ctx->aq_s[0];
-            a.t_cap = std::min(P, (layer + 1 + 63) & ~63);
-            if (a.t_cap <= 256) hipLaunchKernelGGL((bgk::attn_fast_kernel<1, true>), dim3(hp.n_head, 1), dim3(4 * ((a.t_cap + 63) & ~63)), 0, ctx->stream, a);
-            else if (a.t_cap <= 512) hipLaunchKernelGGL((bgk::attn_fast_kernel<2, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((bgk::attn_fast_kernel<4, false>), dim3(hp.n_head, 1), dim3(1024), 0, ctx->stream, a);
-            HIP_TRY(false, hipGetLastError());
-            return true;
-        }
-        const LayerSlots &L = ctx->plan.layers[(size_t)(hp.n_layer ? l % hp.n_layer : 0)];
-        if (which == 0) {
-            const MvShape s = mv_shape(L.fc1.type, L.fc1.M, L.fc1.K, tw);
-            bgk::MatvecParams p = mv_base(ctx, L.fc1, s);
-            p.x = ctx->x1; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, L.ln1_w); p.ln_b = dev_vec(ctx, L.ln1_b);
-            p.bias = dev_vec(ctx, L.fc1_b); p.out = ctx->h; p.ldo = F;
-            if (chain) { p.oq_q = ctx->aq_q[1]; p.oq_d = ctx->aq_d[1]; p.oq_s = ctx->aq_s[1]; HIP_TRY(false, launch_chain(CHAIN_FC1, p, ctx->stream)); }
-            else HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_GELU>(p, s, ctx->stream)));
-        } else if (which == 1) {
-            const MvShape s = mv_shape(L.fc2.type, L.fc2.M, L.fc2.K, tw);
-            bgk::MatvecParams p = mv_base(ctx, L.fc2, s);
-            p.x = ctx->h; p.ldx = F; p.N = 1; p.bias = dev_vec(ctx, L.fc2_b);
-            p.resid = ctx->x1; p.ldr = D; p.out = ctx->x; p.ldo = D;
-            if (chain) { p.aq_q = ctx->aq_q[1]; p.aq_d = ctx->aq_d[1]; p.aq_s = ctx->aq_s[1]; HIP_TRY(false, launch_chain(CHAIN_FC2, p, ctx->stream)); }
-            else HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
-        } else if (which == 2) {
-            const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw);
-            bgk::MatvecParams p = mv_base(ctx, L.qkv, s);
-            p.x = ctx->x; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, L.ln0_w); p.ln_b = dev_vec(ctx, L.ln0_b);
-            p.bias = dev_vec(ctx, L.qkv_b); p.q_out = ctx->q;
-            p.kcache = ctx->memory_k + (size_t)(l % hp.n_layer) * P * D; p.vcache = ctx->memory_v + (size_t)(l % hp.n_layer) * P * D;
-            p.q_scale = 0.125f;
-            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_QKV>(p, s, ctx->stream)));
-        } else if (which == 3) {
-            const MvShape s = mv_shape(L.o.type, L.o.M, L.o.K, tw);
-            bgk::MatvecParams p = mv_base(ctx, L.o, s);
-            p.x = ctx->att; p.ldx = D; p.N = 1; p.bias = dev_vec(ctx, L.o_b);
-            p.resid = ctx->x; p.ldr = D; p.out = ctx->x1; p.ldo = D;
-            if (chain) { p.aq_q = ctx->aq_q[0]; p.aq_d = ctx->aq_d[0]; p.aq_s = ctx->aq_s[0]; HIP_TRY(false, launch_chain(CHAIN_OPROJ, p, ctx->stream)); }
-            else HIP_TRY(false, (launch_mv<bgk::PRO_PLAIN, bgk::EPI_RESID>(p, s, ctx->stream)));
-        } else {
-            const MatSlot &m = ctx->plan.lm_head;
-            const MvShape s = mv_shape(m.type, m.M, m.K, tw);
-            bgk::MatvecParams p = mv_base(ctx, m, s);
-            p.x = ctx->x; p.ldx = D; p.N = 1; p.ln_w = dev_vec(ctx, ctx->plan.ln_w); p.ln_b = dev_vec(ctx, ctx->plan.ln_b);
-            p.out = ctx->logits; p.ldo = V; p.pmax_val = ctx->pmax_val; p.pmax_idx = ctx->pmax_idx;
-            if (which == 12) {
-                const uint8_t *q = cold.v[(size_t)l % cold.v.size()];
-                p.W.qs = q; p.W.sc = q + cold_sc_off; p.W.qh = reinterpret_cast<const uint32_t *>(q + cold_qh_off);
-            }
-            HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, ctx->stream)));
-        }
-        return true;
-    };
-    const int32_t tok0 = 0;
-    if (!upload_state(ctx, &tok0, 1, which == 5 ? layer : (which >= 6 && which != 12 ? 103 : 0))) return -2;
-    const bool stamps = (ctx->opt.dbg & 32) != 0 && which < 5;
-    if (stamps) {
-        if (!ctx->tstamp) HIP_TRY(-2, hipMalloc(&ctx->tstamp, 2 * 8192 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(-2, hipMemset(ctx->tstamp, 0, 2 * 8192 * 8 * sizeof(unsigned long long)));
-    }
-    float ms = 0.0f;
-    if (which >= 6 && which != 12) {
-        // the decode-layer kernels finish faster than the host can launch them one by one (~3.3 us per eager launch):
-        // capture one sweep over the layers and time graph replays, as the decode step itself is replayed
-        const int per = which == 11 ? 4 : std::max(1, hp.n_layer);
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        bool ok = true;
-        for (int i = 0; i < per && ok; i++) ok = launch(layer + i);
-        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
-        if (!ok || ce != hipSuccess) { if (g) (void)hipGraphDestroy(g); BG_FAIL(-2, "graph capture of the decode kernel failed"); }
-        HIP_TRY(-2, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
-        const int sweeps = std::max(1, reps / per);
-        for (int i = 0; i < 2; i++) HIP_TRY(-2, hipGraphLaunch(ge, ctx->stream));
-        HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-        for (int i = 0; i < sweeps; i++) HIP_TRY(-2, hipGraphLaunch(ge, ctx->stream));
-        HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
-        HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
-        HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        (void)hipGraphExecDestroy(ge);
-        reps = sweeps * per;
-    } else {
-        for (int i = 0; i < 3; i++) if (!launch(layer + i)) return -2;
-        HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-        for (int i = 0; i < reps; i++) if (!launch(layer + i)) return -2;
-        HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
-        HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
-        HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    }
-    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
-    if (stamps) {  // timeline of the last two launches (A then B), shader-clock cycles
-        const MatSlot *mm = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
-                          : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
-        int grid = mv_shape(mm->type, mm->M, mm->K, tw).grid;
-        if (which == 4 && ctx->opt.lm_stream && ctx->opt.lm_steps == 8 && mm->K == 1024 && is_quantized(mm->type) && !ctx->opt.no_fast) grid = ((mm->M + 63) / 64 + 2) / 3;      // lm_stream_kernel's
-        std::vector<unsigned long long> h(2 * (size_t)grid * 8);
-        HIP_TRY(-2, hipMemcpy(h.data(), ctx->tstamp, h.size() * 8, hipMemcpyDeviceToHost));
-        const int pb = ctx->launch_parity, pa = pb ^ 1;  // B = last launch, A = the one before
-        auto at = [&](int par, int b, int k) { return h[((size_t)par * grid + b) * 8 + k]; };
-        unsigned long long a_min0 = ~0ull, a_max6 = 0, b_min0 = ~0ull, a_max0 = 0;
-        std::vector<double> seg[6];
-        for (int b = 0; b < grid; b++) {
-            a_min0 = std::min(a_min0, at(pa, b, 0)); a_max0 = std::max(a_max0, at(pa, b, 0));
-            a_max6 = std::max(a_max6, at(pa, b, 6)); b_min0 = std::min(b_min0, at(pb, b, 0));
-            for (int k = 0; k < 6; k++) seg[k].push_back((double)(at(pa, b, k + 1) - at(pa, b, k)));
-        }
-        fprintf(stderr, "timeline which=%d grid=%d: span(first entry -> last exit)=%llu cyc, entry spread=%llu, gap to next kernel's first entry=%lld\n",
-                which, grid, a_max6 - a_min0, a_max0 - a_min0, (long long)(b_min0 - a_max6));
-        const char *names[6] = {"entry->loads issued", "->x arrived", "->prologue done", "->barrier passed", "->main loop done", "->finish+epilogue"};
-        for (int k = 0; k < 6; k++) {
-            std::sort(seg[k].begin(), seg[k].end());
-            fprintf(stderr, "   %-22s med %7.0f  max %7.0f cyc\n", names[k], seg[k][seg[k].size() / 2], seg[k].back());
-        }
-    }
-    if (bytes_out) {
-        if (which == 5) { *bytes_out = 2.0 * (layer + 1) * D * 4; return 0; }  // K and V rows of one layer
-        if (which == 11) {   // every layer's four matrices + K / V rows at 104 keys + the new K / V rows + one x column in and out
-            double b = 0.0;
-            for (const auto &L : ctx->plan.layers)
-                for (const MatSlot *m : {&L.qkv, &L.o, &L.fc1, &L.fc2}) b += (double)file_row_bytes(m->type, m->K) * (double)m->M;
-            b += hp.n_layer * (2.0 * 104 * D * 4 + 2.0 * D * 4) + 8.0 * D;
-            if (ctx->opt.xpipe_lm) b += (double)file_row_bytes(ctx->plan.lm_head.type, ctx->plan.lm_head.K) * (double)ctx->plan.lm_head.M + 4.0 * V;   // + the output projection and the logits row
-            *bytes_out = b;
-            return 0;
-        }
-        if (which == 7) { *bytes_out = 2.0 * 104 * D * 4 + 4.0 * D + 1.0 * D + 8.0 * (D / 32); return 0; }   // K, V rows at 104 keys + q + Q8 output
-        if (which >= 6 && which != 12) {   // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
-            const MatSlot *m6 = which == 6 ? &ctx->plan.layers[0].qkv : which == 8 ? &ctx->plan.layers[0].o : which == 9 ? &ctx->plan.layers[0].fc1 : &ctx->plan.layers[0].fc2;
-            *bytes_out = (double)file_row_bytes(m6->type, m6->K) * (double)m6->M + 4.0 * (double)m6->K + 4.0 * (double)m6->M;
-            return 0;
-        }
-        const MatSlot *m = which == 0 ? &ctx->plan.layers[0].fc1 : which == 1 ? &ctx->plan.layers[0].fc2
-                         : which == 2 ? &ctx->plan.layers[0].qkv : which == 3 ? &ctx->plan.layers[0].o : &ctx->plan.lm_head;
-        // rows*cols*(block_bytes/32) + 4*cols (activation) + 4*rows (out)
-        *bytes_out = (double)file_row_bytes(m->type, m->K) * (double)m->M + 4.0 * (double)m->K + 4.0 * (double)m->M;
-    }
-    return 0;
-}
-
-int biogpt_hip_bench_stream(biogpt_hip_ctx *ctx, int32_t rows, int reps, int steps, double *seconds_out, double *bytes_out) {
-    // The decode mat-vec kernel body on a weight stream far larger than the caches: rows x 1024 synthetic
-    // Q4_0 blocks (random bytes), the model's final LayerNorm as prologue, logits epilogue without arg-max.
-    clear_error();
-    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (ctx->hp.d_model != 1024 || rows < 1024 || rows % 1024 || reps < 1 || steps < 2) BG_FAIL(-1, "bad argument");
-    HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
-    t_ctx = ctx;
-    const size_t nblk = (size_t)rows * 32;
-    uint8_t *qs = nullptr, *sc = nullptr;
-    float *out = nullptr;
-    HIP_TRY(-2, hipMalloc(&qs, nblk * 16));
-    HIP_TRY(-2, hipMalloc(&sc, nblk * 2));
-    HIP_TRY(-2, hipMalloc(&out, (size_t)rows * 4));
-    {
-        std::vector<uint32_t> h(nblk * 4);
-        uint64_t s = 0x9E3779B97F4A7C15ull;
-        for (auto &v : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (uint32_t)(s >> 32); }
-        HIP_TRY(-2, hipMemcpy(qs, h.data(), nblk * 16, hipMemcpyHostToDevice));
-        std::vector<uint16_t> d(nblk, 0x2000);  // fp16 2^-7: finite, no NaN/inf scales
-        HIP_TRY(-2, hipMemcpy(sc, d.data(), nblk * 2, hipMemcpyHostToDevice));
-    }
-    bgk::MatvecParams p{};
-    p.W.qs = qs; p.W.sc = sc; p.W.qh = nullptr; p.W.type = T_Q4_0; p.W.M = rows; p.W.K = 1024;
-    p.x = ctx->x; p.ldx = 1024; p.N = 1; p.eps = 1e-5f;
-    p.ln_w = dev_vec(ctx, ctx->plan.ln_w); p.ln_b = dev_vec(ctx, ctx->plan.ln_b);
-    p.out = out; p.ldo = rows; p.st = ctx->state; p.inv_k = 1.0 / 1024.0; p.k_pow2 = 1;
-    p.rpw = 2 * steps;
-    const int grid = (rows + 4 * p.rpw - 1) / (4 * p.rpw);
-    const size_t sm = bgk::matvec_fast_smem_bytes(1024, p.rpw);
-    auto launch = [&] { hipLaunchKernelGGL((bgk::matvec_fast_kernel<bgk::W_Q4_0, bgk::PRO_LN, bgk::EPI_LOGITS, 1024, 4, 1>), dim3(grid), dim3(256), sm, ctx->stream, p); };
-    for (int i = 0; i < 2; i++) launch();
-    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; i++) launch();
-    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
-    float ms = 0.0f;
-    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
-    if (bytes_out) *bytes_out = 18.0 * (double)nblk + 4.0 * 1024 + 4.0 * rows;   // file-density bytes (18 B / block) + x + out
-    (void)hipFree(qs); (void)hipFree(sc); (void)hipFree(out);
-    return 0;
-}
-
-int biogpt_hip_bench_decode(biogpt_hip_ctx *ctx, int32_t n_past, int reps, double *seconds_out) {
-    XpCallScope xp_scope(ctx);
-    clear_error();
-    if (!ctx || !ctx->ready) BG_FAIL(-1, "no model");
-    if (reps < 1 || n_past < 0 || n_past >= ctx->hp.n_positions) BG_FAIL(-1, "bad argument");
-    HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
-    const int b = graph_bucket(n_past + 1);
-    if ((ctx->opt.dbg & 224) && !ctx->tstamp) {
-        HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
-        HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
-    }
-    const int pl = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;
-    if (!ensure_graph(ctx, 0, b, pl)) return -2;
-    const int32_t tok0 = 2;
-    if (!upload_state(ctx, &tok0, 1, n_past)) return -2;
-    for (int i = 0; i < 3; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl][0][b], ctx->stream));
-    HIP_TRY(-2, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int i = 0; i < reps; i++) HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl][0][b], ctx->stream));
-    HIP_TRY(-2, hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(-2, hipEventSynchronize(ctx->ev1));
-    float ms = 0.0f;
-    HIP_TRY(-2, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    if (seconds_out) *seconds_out = (double)ms * 1e-3 / reps;
-    if (!xpipe_check(ctx)) return -2;
-    if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1 && bucket_tmax(ctx, b) > 256) {
-        // long-context variant (kernels_xlong.hip.h): [n_layer][32] stamps of workgroup 0 of the layer's own XCDs (it is also the first helper -- and the combiner -- of head 2 xcd)
-        const int nl = ctx->hp.n_layer;
-        std::vector<unsigned long long> w((size_t)nl * 32);
-        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp, w.size() * 8, hipMemcpyDeviceToHost));
-        const int order[18] = {0, 6, 1, 16, 17, 18, 19, 20, 21, 22, 8, 3, 9, 10, 11, 4, 12, 5};
-        const char *names[18] = {"x arrived", "LayerNorm + Q8 done", "q/k/v rows published", "helper: q row arrived", "helper: own scores published", "helper: head's scores arrived",
-                                 "helper: max / exp / sum done", "helper: partial PV published", "combiner: partials arrived", "combiner: attention output published",
-                                 "attention output arrived", "out_proj rows published", "x1 arrived", "LayerNorm + Q8 done", "fc1 rows + GELU done",
-                                 "fc1 activations published", "fc1 activations arrived", "layer output published"};
-        double seg[18] = {}, hop = 0.0;
-        for (int l = 1; l < nl; l++) {
-            for (int k = 1; k < 18; k++) seg[k] += (double)(long long)(w[(size_t)l * 32 + order[k]] - w[(size_t)l * 32 + order[k - 1]]) * 0.01;
-            hop += (double)(long long)(w[(size_t)l * 32] - w[(size_t)(l - 1) * 32 + 5]) * 0.01;
-        }
-        const double n = nl > 1 ? nl - 1 : 1;
-        fprintf(stderr, "XCD pipeline, long-context variant: wall clock of workgroup 0 of the layer's XCDs, mean over layers 1.. (us since the previous line)\n");
-        fprintf(stderr, "   %-40s %6.2f   (previous layer's output published -> seen on the next XCD)\n", names[0], hop / n);
-        for (int k = 1; k < 18; k++) fprintf(stderr, "   %-40s %6.2f\n", names[k], seg[k] / n);
-        fprintf(stderr, "   one layer = %.2f us\n", nl > 1 ? (double)(long long)(w[(size_t)(nl - 1) * 32 + 5] - w[5]) * 0.01 / n : 0.0);
-    } else if ((ctx->opt.dbg & 128) && ctx->tstamp && pl == 1) {
-        // XCD pipeline (build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS): wall clock (100 MHz) of workgroup 0 of each layer's XCD, last replay
-        const int nl = ctx->hp.n_layer;
-        std::vector<unsigned long long> w((size_t)nl * 16);
-        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp, w.size() * 8, hipMemcpyDeviceToHost));
-        // stamp order inside a layer
-        const int order[16] = {0, 6, 1, 7, 13, 14, 15, 2, 8, 3, 9, 10, 11, 4, 12, 5};
-        const char *names[16] = {"x arrived", "LayerNorm + Q8 done", "q/k/v rows stored / handed over", "q/k/v rows arrived", "scores + max", "exp + sum",
-                                 "PV + slice sums in LDS", "attention output published", "attention output arrived", "out_proj rows published", "x1 arrived",
-                                 "LayerNorm + Q8 done", "fc1 rows + GELU done", "fc1 activations published", "fc1 activations arrived", "layer output published"};
-        double seg[16] = {}, hop = 0.0;
-        for (int l = 1; l < nl; l++) {
-            for (int k = 1; k < 16; k++) seg[k] += (double)(long long)(w[(size_t)l * 16 + order[k]] - w[(size_t)l * 16 + order[k - 1]]) * 0.01;
-            hop += (double)(long long)(w[(size_t)l * 16] - w[(size_t)(l - 1) * 16 + 5]) * 0.01;
-        }
-        const double n = nl > 1 ? nl - 1 : 1;
-        fprintf(stderr, "XCD pipeline: wall clock of workgroup 0 of the layer's XCD, mean over layers 1.. (us since the previous line)\n");
-        fprintf(stderr, "   %-36s %6.2f   (previous layer's output published -> seen on the next XCD)\n", names[0], hop / n);
-        for (int k = 1; k < 16; k++) fprintf(stderr, "   %-36s %6.2f\n", names[k], seg[k] / n);
-        fprintf(stderr, "   one layer = %.2f us\n", nl > 1 ? (double)(long long)(w[(size_t)(nl - 1) * 16 + 5] - w[5]) * 0.01 / n : 0.0);
-        {   // the two cross-XCD hops by the XCD they arrive on: x (layer l-1's MLP half on XCD 2l-1 -> layer l's attention half on XCD 2l mod 8), x1 (XCD 2l -> 2l+1)
-            double hx[4] = {}, hx1[4] = {}; int cnt[4] = {};
-            for (int l = 1; l < nl; l++) {
-                hx[l & 3] += (double)(long long)(w[(size_t)l * 16] - w[(size_t)(l - 1) * 16 + 5]) * 0.01;
-                hx1[l & 3] += (double)(long long)(w[(size_t)l * 16 + 9] - w[(size_t)l * 16 + 3]) * 0.01;
-                cnt[l & 3]++;
-            }
-            for (int k = 0; k < 4; k++)
-                if (cnt[k]) fprintf(stderr, "   hops onto XCD %d / %d: x %.2f us (from XCD %d), x1 %.2f us\n", 2 * k, 2 * k + 1, hx[k] / cnt[k], (2 * k + 7) & 7, hx1[k] / cnt[k]);
-        }
-        // the last layer, every workgroup of its XCD: us since workgroup 0 saw the layer input
-        std::vector<unsigned long long> ws((size_t)32 * 16);
-        HIP_TRY(-2, hipMemcpy(ws.data(), ctx->tstamp + (size_t)nl * 16, ws.size() * 8, hipMemcpyDeviceToHost));
-        fprintf(stderr, "   last layer, per workgroup (columns: the 16 events above):\n");
-        for (int sl = 0; sl < 32; sl++) {
-            fprintf(stderr, "   wg %2d:", sl);
-            for (int k = 0; k < 16; k++) {
-                const unsigned long long t = ws[(size_t)sl * 16 + order[k]];
-                if (t == 0) fprintf(stderr, "      -"); else fprintf(stderr, " %6.2f", (double)(long long)(t - ws[0]) * 0.01);
-            }
-            fprintf(stderr, "\n");
-        }
-    }
-    if ((ctx->opt.dbg & 64) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
-        // wall-clock (100 MHz) entry / exit of every workgroup of the last replay: per kernel, relative to the previous kernel's last exit
-        const int nk = 5 * ctx->hp.n_layer;
-        std::vector<unsigned long long> w((size_t)nk * 2048);
-        HIP_TRY(-2, hipMemcpy(w.data(), ctx->tstamp + 128, w.size() * 8, hipMemcpyDeviceToHost));
-        const int grids[5] = {ctx->opt.qkv_waves == 8 ? 192 : ctx->opt.qkv_waves == 4 ? 384 : 96, 16, ctx->opt.oproj_waves == 4 ? 128 : ctx->opt.oproj_waves == 8 ? 64 : 32, ctx->opt.fc1_blocks == 2 ? 64 : 128,
-                              ctx->opt.fc2_waves == 4 ? 256 : ctx->opt.fc2_waves == 8 ? 128 : 64};
-        const char *kn[5] = {"dec_qkv  ", "dec_attn ", "dec_oproj", "dec_fc1  ", "dec_fc2  "};
-        double acc[5][5] = {};
-        unsigned long long prev_exit = 0;
-        for (int k = 0; k < nk; k++) {
-            unsigned long long e0 = ~0ull, e1 = 0, x0 = ~0ull, x1 = 0;
-            for (int g = 0; g < grids[k % 5]; g++) {
-                const unsigned long long en = w[((size_t)k * 1024 + g) * 2], ex = w[((size_t)k * 1024 + g) * 2 + 1];
-                e0 = std::min(e0, en); e1 = std::max(e1, en); x0 = std::min(x0, ex); x1 = std::max(x1, ex);
-            }
-            if (k >= 5) {   // skip layer 0 (no previous stamp; embedding variant)
-                acc[k % 5][0] += (double)(long long)(e0 - prev_exit); acc[k % 5][1] += (double)(e1 - e0);
-                acc[k % 5][2] += (double)(x0 - e0); acc[k % 5][3] += (double)(x1 - e0); acc[k % 5][4] += 1.0;
-            }
-            prev_exit = x1;
-        }
-        fprintf(stderr, "wall-clock timeline per kernel (us, mean over layers 1..): previous kernel's last exit -> first entry | entry spread | first exit | last exit (from first entry)\n");
-        double tot = 0.0;
-        for (int j = 0; j < 5; j++) {
-            fprintf(stderr, "   %s  gap %.2f | entries within %.2f | first exit %.2f | last exit %.2f\n", kn[j], acc[j][0] / acc[j][4] * 0.01,
-                    acc[j][1] / acc[j][4] * 0.01, acc[j][2] / acc[j][4] * 0.01, acc[j][3] / acc[j][4] * 0.01);
-            tot += (acc[j][0] + acc[j][3]) / acc[j][4] * 0.01;
-        }
-        fprintf(stderr, "   one layer = %.2f us\n", tot);
-    }
-    if ((ctx->opt.dbg & 32) && ctx->tstamp && fused_decode_ok(ctx, bucket_tmax(ctx, b))) {
-        // per-segment shader-clock stamps, last layer, workgroup 0 / thread 0 (build with EXTRA=-DBIOGPT_HIP_PROFILE_HOOKS)
-        unsigned long long h[80];
-        HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));
-        struct Seg { const char *kernel; int base, n; const char *names[5]; };
-        const Seg segs[5] = {
-            {"dec_qkv_kernel", 0, 3, {"entry -> loads issued / token embedded", "-> LayerNorm + Q8 in LDS", "-> rows finished, q / KV stored", "", ""}},
-            {"dec_attn_kernel", 16, 4, {"entry -> loads issued", "-> scores + max", "-> exp table, sum", "-> PV, Q8, stored", ""}},
-            {"dec_oproj_kernel", 32, 3, {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store", "", ""}},
-            {"dec_fc1_kernel", 48, 4, {"entry -> loads issued", "-> LayerNorm + Q8 in LDS", "-> rows finished, GELU", "-> Q8 block stored", ""}},
-            {"dec_fc2_kernel", 64, 3, {"entry -> loads issued", "-> block terms in LDS", "-> in-order sum + store", "", ""}},
-        };
-        for (const Seg &sg : segs) {
-            fprintf(stderr, "%s segments (shader cycles, workgroup 0 / wave 0):\n", sg.kernel);
-            for (int k = 0; k < sg.n; k++) fprintf(stderr, "   %-42s %7lld\n", sg.names[k], (long long)(h[sg.base + k + 1] - h[sg.base + k]));
-            if (sg.base == 0 || sg.base == 48) {   // inside the shared LayerNorm + Q8
-                const char *ln[7] = {"loads issued -> column arrived", "-> wave sum 1 stored", "-> barrier 1", "-> mean, wave sum 2 stored", "-> barrier 2", "-> normalised value", "-> Q8 written"};
-                const unsigned long long t0 = h[sg.base + 1];
-                unsigned long long prev = t0;
-                for (int k = 0; k < 7; k++) { fprintf(stderr, "      %-39s %7lld\n", ln[k], (long long)(h[sg.base + 8 + k] - prev)); prev = h[sg.base + 8 + k]; }
-            }
-        }
-    } else if ((ctx->opt.dbg & 32) && ctx->tstamp) {
-        unsigned long long h[16 * 8];
-        HIP_TRY(-2, hipMemcpy(h, ctx->tstamp, sizeof h, hipMemcpyDeviceToHost));
-        fprintf(stderr, "attention timeline (block 0, last layer; cycles since wave 0 entry):\n");
-        for (int w = 0; w < 16; w += 5) {
-            fprintf(stderr, "  wave %2d:", w);
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %7lld", (long long)(h[w * 8 + k] - h[0]));
-            fprintf(stderr, "\n");
-        }
-    }
-    return 0;
-}
-
+#include "engine_bench.inc"
 // SURVEY 8 f1 on the device: `nrows` rows of `k` f32 values (host memory) -> the file's block format of `type`, byte-identical to
 // the host quantizer (biogpt_hip_quantize_file uses the host one: it has to work without a GPU)
 int biogpt_hip_quantize_rows_device(int device, int32_t type, const float *src, int64_t nrows, int64_t k, uint8_t *dst) {
