@@ -163,6 +163,14 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
 #ifndef XP_H16
 #define XP_H16 0
 #endif
+// XP_SPLIT_Q (192- / 256-key variants, where the head's workgroup has no room for all 192 q / k / v rows beside its K / V registers): the head's workgroup computes its
+// own 64 q rows (4 units per lane) and starts on the scores of the old keys while workgroup 16 + head computes and hands over only the token's k / v rows -- the hand-over
+// (0.45 us in-XCD) overlaps with the scores instead of standing in front of them.  Round 3: workgroup 16 + head computed all 192 rows and the attention waited for them.
+// Measured per token inside multi-token launches (tools/bucket_ab.py): 133 .. 188 keys 262.1 -> 254.2 us; in the 256-key variant, whose two polling waves have keys of their
+// own beyond 192 keys, 265.8 -> 268.0: there it stays off.
+#ifndef XP_SPLIT_Q
+#define XP_SPLIT_Q 1
+#endif
 #ifndef XP_LOCAL_PIPE
 #define XP_LOCAL_PIPE 0
 #endif
@@ -483,6 +491,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     uint16_t *const s_gelu = reinterpret_cast<uint16_t *>(smem + XP_S_TOTAL);
     uint32_t *const s_dead = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 96);      // [4] behind the 8 doubles the attention stage uses
+    uint32_t *const s_kvdead = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 64);    // [2] resident launch, XP_SPLIT_Q: the waves that took the token's k / v rows in saw the launch drain
     uint32_t *const s_spec = reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 112);     // [3] resident launch, workgroup 0 of XCD 0: {speculate the next token, the token the current pass was started with unasked (-1: none)}
     const int t_cap = p.t_cap;
     const int n_units = SPLIT ? 2 * p.n_layer : p.n_layer;                     // pipeline units: layers, or half layers
@@ -762,14 +771,15 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         if (!attn_wg && !MERGE) {
             // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
+            constexpr int Q0 = (XP_SPLIT_Q != 0 && KCAP <= 192) ? QS / 3 : 0;      // XP_SPLIT_Q: the q rows (units 0 .. QS / 3 - 1) are the head's own workgroup's
             Unit<WT> wqkv[QS];
 #pragma unroll
-            for (int s = 0; s < QS; s++) {
+            for (int s = Q0; s < QS; s++) {
                 const int jj = s * 2 * NW + wave * 2 + rsub;
                 load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
             }
 #pragma unroll
-            for (int s = 0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
+            for (int s = Q0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
             const float4 xv = layer_input();
             XP_WALL(0);
             float4 lnw = xv, lnb = xv;
@@ -786,11 +796,11 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const uint32_t axs = s_xs[sub];
             float *const part = s_part + wave * 2 * QS * DEC_PS;
 #pragma unroll
-            for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
+            for (int s = Q0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 2 * QS) {
+            if (lane >= 2 * Q0 && lane < 2 * QS) {
                 const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
                 float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
                 const int which = jj >> 6, d = jj & 63;
@@ -868,6 +878,42 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     }
                 }
                 XP_WALL(1);
+            } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
+                // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
+                constexpr int Q0 = QS / 3;
+                Unit<WT> wq[Q0];
+#pragma unroll
+                for (int s = 0; s < Q0; s++) {
+                    const int jj = s * 2 * NW + wave * 2 + rsub;      // < 64: a q row
+                    load_unit<WT>(wq[s], Y.Wqkv, (int64_t)(head * 64 + jj) * 32 + sub);
+                }
+#pragma unroll
+                for (int s = 0; s < Q0; s++) xp_settle<WT, EXPAND>(wq[s]);
+                const float4 xv = layer_input();
+                XP_WALL(0);
+                float4 lnw = xv, lnb = xv;
+                if (worker) {
+                    reinterpret_cast<float4 *>(s_x)[tid] = xv;
+                    lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
+                }
+                ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                XP_WALL(6);
+                uint32_t ax[8];
+                const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                const float axd = s_xd[sub];
+                const uint32_t axs = s_xs[sub];
+                float *const part = s_part + wave * 2 * Q0 * DEC_PS;
+#pragma unroll
+                for (int s = 0; s < Q0; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wq[s], ax, axd, __uint_as_float(axs), (int)axs);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 2 * Q0) {
+                    const int jj = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
+                    s_cur[jj] = __fmul_rn(__fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS)), p.q_scale);      // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                }
+                XP_WALL(1);
             } else {
                 {   // the layer input is the residual of stage C; it arrives about 2 us before the q / k / v rows
                     const float4 xv = layer_input();
@@ -882,25 +928,47 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             __syncthreads();
             XP_WALL(7);
-            float sc = -INFINITY;
-            if ((tid & ~63) < LPK * T) {
-                if (kidx == n_past) {
-#pragma unroll
-                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
-                }
+            constexpr bool LATE_KV = !MERGE && XP_SPLIT_Q != 0 && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
+            auto key_score = [&](const float4 (&kk)[NF4]) __attribute__((always_inline)) -> float {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int m = 0; m < NF4; m++) {
                     const float4 qm = *reinterpret_cast<const float4 *>(s_cur + 4 * (LPK * m + ksub));
-                    a0 += (double)__fmul_rn(kr[m].x, qm.x); a1 += (double)__fmul_rn(kr[m].y, qm.y);
-                    a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
+                    a0 += (double)__fmul_rn(kk[m].x, qm.x); a1 += (double)__fmul_rn(kk[m].y, qm.y);
+                    a2 += (double)__fmul_rn(kk[m].z, qm.z); a3 += (double)__fmul_rn(kk[m].w, qm.w);
                 }
                 double acc = (a0 + a1) + (a2 + a3);
                 acc += dpp_d<DPP_QUAD_XOR1>(acc);
                 if (LPK >= 4) acc += dpp_d<DPP_QUAD_XOR2>(acc);
                 if (LPK >= 8) acc += dpp_d<DPP_ROW_HALF_MIRROR>(acc);
                 if (LPK >= 16) acc += dpp_d<DPP_ROW_MIRROR>(acc);
-                if (kidx < T) sc = (float)acc;
+                return (float)acc;
+            };
+            if constexpr (LATE_KV) {      // the two highest waves (no keys of their own up to 192 keys) take the k / v rows in: wave NW - 2 the key row, wave NW - 1 the value row
+                if (wave >= NW - 2) {
+                    uint32_t v[1];
+                    const int which = wave - (NW - 3);
+                    xp_sweep_q<RES, 1>(G + XP_G_QKV + which * 1024 + head * 64 + lane, true, epoch, v, p, etag);
+                    s_cur[which * 64 + lane] = __uint_as_float(v[0]);
+                    if (RES && lane == 0) s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                }
+            }
+            float sc = -INFINITY;
+            if ((tid & ~63) < LPK * T) {
+                if (!LATE_KV && kidx == n_past) {
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                }
+                if (kidx < T && !(LATE_KV && kidx == n_past)) sc = key_score(kr);
+            }
+            if constexpr (LATE_KV) {
+                __syncthreads();      // the token's k / v rows are in s_cur
+                if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                if (kidx == n_past) {      // the LPK lanes of the new key
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                    sc = key_score(kr);
+                }
             }
             float mx = wave_max_f32(sc);
             if (lane == 0) s_redf[wave] = mx;
