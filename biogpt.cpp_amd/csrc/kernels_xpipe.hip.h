@@ -171,6 +171,14 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
 #ifndef XP_SPLIT_Q
 #define XP_SPLIT_Q 1
 #endif
+// XP_SOFTMAX_WAVE: the softmax of the <= 256-key variants with ONE exchange through LDS (the scores) instead of two (the waves' maxima, then their sums): see the
+// attention stage.  Measured per token inside multi-token launches (tools/bucket_ab.py): profiles/xpipe_ab_r4.txt.
+#ifndef XP_SOFTMAX_WAVE
+#define XP_SOFTMAX_WAVE 1
+#endif
+#ifndef XP_SUM_INT      // (the two-exchange softmax with integer sums of the numerators: measured, no gain)
+#define XP_SUM_INT 0
+#endif
 #ifndef XP_LOCAL_PIPE
 #define XP_LOCAL_PIPE 0
 #endif
@@ -445,6 +453,13 @@ __device__ __forceinline__ void xp_settle(Unit<WT> &u) {
         settle_unit<WT>(u);
         asm volatile("" : "+v"(u.q0.x), "+v"(u.q0.y), "+v"(u.q0.z), "+v"(u.q0.w), "+v"(u.q1.x), "+v"(u.q1.y), "+v"(u.q1.z), "+v"(u.q1.w), "+v"(u.sc));
     }
+}
+
+// sum of one unsigned value per lane over the wave, uniform result (4 DPP adds, 4 v_readlane, scalar adds)
+__device__ __forceinline__ uint32_t xp_wave_sum_u32(uint32_t v) {
+    int s = (int)v;
+    s += dpp_i<DPP_QUAD_XOR1>(s); s += dpp_i<DPP_QUAD_XOR2>(s); s += dpp_i<DPP_ROW_HALF_MIRROR>(s); s += dpp_i<DPP_ROW_MIRROR>(s);
+    return (uint32_t)((__builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16)) + (__builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48)));
 }
 
 // The launch's work for one role: ATTN = this workgroup is one of the XCD's 16 attention heads (else it computes q/k/v rows).  The
@@ -824,14 +839,18 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 constexpr bool KV_SC1 = !MERGE;
                 const float *kb = Y.kcache + (size_t)head * p.P * DK, *vb = Y.vcache + (size_t)head * p.P * DK;
                 const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
-                if (kidx < t_cap) {
+                // (KV_SC1: unconditional -- a row beyond the cache slice reads as 0, buffer loads are range-checked -- so that no register is left undefined on any path)
+                if (KV_SC1 || kidx < t_cap) {
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4<KV_SC1>(krs, kb, (kidx * (DK / 4) + ksub + LPK * m) * 4);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     const int j = sl + NW * k;
-                    if (j < t_cap) vr[k] = xp_kv_load1<KV_SC1>(vrs, vb, j * DK + dd);
+                    vr[k] = (KV_SC1 || j < t_cap) ? xp_kv_load1<KV_SC1>(vrs, vb, j * DK + dd) : 0.0f;
                 }
             }
             if constexpr (MERGE) {
@@ -961,53 +980,121 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
                 if (kidx < T && !(LATE_KV && kidx == n_past)) sc = key_score(kr);
             }
-            if constexpr (LATE_KV) {
-                __syncthreads();      // the token's k / v rows are in s_cur
-                if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
-                if (kidx == n_past) {      // the LPK lanes of the new key
+            static_assert(NW == 8, "key j = wave + 8 k sits in lane (wave + 8 k) & 63 of slot k >> 3");
+            constexpr bool SMW = XP_SOFTMAX_WAVE != 0 && KCAP <= 64;      // (measured: -1.5 us per token with 64 keys, +-0 with 128, +1 / +9 us with 192 / 256 -- 2-4 look-ups per lane and 16-32 v_readlane per wave)
+            constexpr int KC = (KCAP + 63) / 64;
+            [[maybe_unused]] float ev[KC];
+            float inv;
+            if constexpr (SMW) {
+                // One exchange instead of two: the scores go to LDS, and behind ONE barrier every wave works the softmax out for itself -- the maximum, the
+                // table look-ups and the sum of all keys (<= 4 per lane), identically in the 8 waves -- so that the PV lanes take their weights from the wave's
+                // own registers (v_readlane).  The sum of the numerators is formed in integers: they are fp16 values <= 1.0 (exp of a non-positive argument),
+                // i.e. multiples of 2^-24, <= 256 of them: sums of the low and high 16 bits of value * 2^24, exact -- as the reference's double sum is.
+                if (ksub == 0) s_S[kidx] = sc;      // every key slot of the variant: -inf beyond the context (and, LATE_KV, for the token's own key)
+                __syncthreads();                    // the scores -- and (LATE_KV) the token's k / v rows in s_cur
+                float scl[KC];
 #pragma unroll
-                    for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
-                    sc = key_score(kr);
+                for (int c = 0; c < KC; c++) scl[c] = s_S[lane + 64 * c];
+                if constexpr (LATE_KV) {
+                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    float4 kn[NF4];                 // the token's own key: every group of LPK lanes of every wave forms its score (the association of the old keys' scores)
+#pragma unroll
+                    for (int m = 0; m < NF4; m++) kn[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                    const float snew = key_score(kn);
+#pragma unroll
+                    for (int c = 0; c < KC; c++) if (lane + 64 * c == n_past) scl[c] = snew;
                 }
-            }
-            float mx = wave_max_f32(sc);
-            if (lane == 0) s_redf[wave] = mx;
-            __syncthreads();
-            mx = s_redf[0];
+                float mx = scl[0];
 #pragma unroll
-            for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
-            XP_WALL(13);
-            double sum = 0.0;
-            if (kidx < T && ksub == 0) {
-                // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
-                const uint32_t ix = f2h(__fsub_rn(sc, mx)), neg = ix - 0x8000u;
-                uint16_t e16;
-                if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
-                else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
-                else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
-                else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
-                const float val = h2f(e16);
-                s_S[kidx] = val;
-                sum = (double)val;
-            }
-            sum = wave_sum_f64(sum);
-            if (lane == 0) s_redd[wave] = sum;
-            __syncthreads();
-            sum = 0.0;
+                for (int c = 1; c < KC; c++) mx = fmaxf(mx, scl[c]);
+                mx = wave_max_f32(mx);
+                XP_WALL(13);
+                uint32_t ulo = 0u, uhi = 0u;
 #pragma unroll
-            for (int w = 0; w < NW; w++) sum += s_redd[w];
-            const float inv = inv_sum_f32(sum);
+                for (int c = 0; c < KC; c++) {
+                    float val = 0.0f;
+                    if (lane + 64 * c < T) {
+                        // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
+                        const uint32_t ix = f2h(__fsub_rn(scl[c], mx)), neg = ix - 0x8000u;
+                        uint16_t e16;
+                        if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
+                        else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
+                        else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
+                        else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
+                        val = h2f(e16);
+                    }
+                    ev[c] = val;
+                    const uint32_t u = (uint32_t)__fmul_rn(val, 16777216.0f);
+                    ulo += u & 0xFFFFu; uhi += u >> 16;
+                }
+                ulo = xp_wave_sum_u32(ulo); uhi = xp_wave_sum_u32(uhi);
+                const double sum = ((double)uhi * 65536.0 + (double)ulo) * 0x1p-24;
+                inv = inv_sum_f32(sum);
+            } else {
+                if constexpr (LATE_KV) {
+                    __syncthreads();      // the token's k / v rows are in s_cur
+                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    if (kidx == n_past) {      // the LPK lanes of the new key
+#pragma unroll
+                        for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
+                        sc = key_score(kr);
+                    }
+                }
+                float mx = wave_max_f32(sc);
+                if (lane == 0) s_redf[wave] = mx;
+                __syncthreads();
+                mx = s_redf[0];
+#pragma unroll
+                for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
+                XP_WALL(13);
+                double sum = 0.0;
+                [[maybe_unused]] uint32_t ulo = 0u, uhi = 0u;
+                if (kidx < T && ksub == 0) {
+                    // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
+                    const uint32_t ix = f2h(__fsub_rn(sc, mx)), neg = ix - 0x8000u;
+                    uint16_t e16;
+                    if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
+                    else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
+                    else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
+                    else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
+                    const float val = h2f(e16);
+                    s_S[kidx] = val;
+                    sum = (double)val;
+                    if constexpr (XP_SUM_INT != 0) { const uint32_t u = (uint32_t)__fmul_rn(val, 16777216.0f); ulo = u & 0xFFFFu; uhi = u >> 16; }
+                }
+                if constexpr (XP_SUM_INT != 0) {      // integer sums of the numerators' low / high 16 bits instead of the double butterfly (measured: +2.4 / -0.8 / +1.8 us per token at 128 / 192 / 256 keys: off)
+                    ulo = xp_wave_sum_u32(ulo); uhi = xp_wave_sum_u32(uhi);
+                    if (lane == 0) reinterpret_cast<uint2 *>(s_redd)[wave] = make_uint2(ulo, uhi);
+                    __syncthreads();
+                    uint32_t tl = 0u, th = 0u;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) { const uint2 t = reinterpret_cast<const uint2 *>(s_redd)[w]; tl += t.x; th += t.y; }
+                    sum = ((double)th * 65536.0 + (double)tl) * 0x1p-24;
+                } else {
+                    sum = wave_sum_f64(sum);
+                    if (lane == 0) s_redd[wave] = sum;
+                    __syncthreads();
+                    sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) sum += s_redd[w];
+                }
+                inv = inv_sum_f32(sum);
+            }
             XP_WALL(14);
             {
                 // all LDS reads first, no branches in the loop: a key past the context adds +0.0 (exact), never its stale weight
                 const float vcur = s_cur[128 + dd];
+                [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                 constexpr int CH = NV < 16 ? NV : (NV % 16 == 0 ? 16 : 8);      // softmax weights fetched at most 16 at a time (register budget)
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int k0 = 0; k0 < NV; k0 += CH) {
                     float pj[CH];
 #pragma unroll
-                    for (int k = 0; k < CH; k++) pj[k] = s_S[sl + NW * (k0 + k)];
+                    for (int k = 0; k < CH; k++) {
+                        if constexpr (SMW) pj[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev[(k0 + k) >> 3]), wave_u + 8 * ((k0 + k) & 7)));      // key sl + 8 (k0 + k)
+                        else pj[k] = s_S[sl + NW * (k0 + k)];
+                    }
 #pragma unroll
                     for (int k = 0; k < CH; k += 2) {
                         const int j0 = sl + NW * (k0 + k), j1 = j0 + NW;
@@ -1450,11 +1537,15 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
         for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
     }
+#ifdef XP_ONLY_ROLE      // (register census of one role: hipcc -Rpass-analysis=kernel-resource-usage -DXP_ONLY_ROLE=r; not a working kernel)
+    xp_run<WT, LPK, NW, KCAP, XP_ONLY_ROLE, true, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+#else
     if constexpr (SPLIT) {
         if (xcd & 1) { xp_run<WT, LPK, NW, KCAP, 2, true, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0); return; }
     }
     if (slot < 16) xp_run<WT, LPK, NW, KCAP, 0, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
     else xp_run<WT, LPK, NW, KCAP, 1, SPLIT, RES>(p, smem, xcd, slot, epoch0, n_past0, n_gen0);
+#endif
 }
 
 // Calibration of the cross-XCD hand-off regions (xpipe_place_hops, once per context): ONE lane on XCD src and ONE on XCD dst play ping-pong over the granule at
