@@ -171,7 +171,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -208,6 +208,7 @@ struct EngineOptions {
         verbose = get("BIOGPT_HIP_VERBOSE", 0);
         eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
+        xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
@@ -747,7 +748,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.pmax_val = c->pmax_val; xp.pmax_idx = c->pmax_idx; xp.nparts = lm_parts;
         xp.n_positions = P; xp.n_vocab = V;
         xp.eps = 1e-5f; xp.q_scale = 1.0f / sqrtf(64.0f);
-        xp.P = P; xp.t_cap = std::min(P, (t_max + 63) & ~63);
+        xp.P = P; xp.t_cap = std::min(P, (t_max + 63) & ~63); xp.dual = (c->opt.xpipe_dual && c->xp_gran_l != nullptr) ? 1 : 0;
         xp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
         xp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
         xp.gelu_p = c->xp_gelu_p; xp.gelu_n = c->xp_gelu_n; xp.gelu_z = c->xp_gelu_z; xp.exp_n = c->xp_exp_n;

@@ -32,10 +32,7 @@
 
 namespace bgk {
 
-// granules of one layer in the long-context buffer (XpParams::gran_l)
-constexpr int XL_G_SC = 0;                     // [16 heads][1024 keys] scores
-constexpr int XL_G_PV = 16 * 1024;             // [16 heads][16 ranges][64 lo + 64 hi] partial sum_j V_jd p_j (double)
-constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
+// (granules of one layer in the long-context buffer, XpParams::gran_l: XL_G_SC / XL_G_PV / XL_G_LAYER in kernels_xpipe.hip.h)
 
 #ifndef XL_COMBINE_HOME
 #define XL_COMBINE_HOME 1

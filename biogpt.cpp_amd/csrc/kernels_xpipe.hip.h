@@ -102,6 +102,7 @@ struct XpParams {
     // resident mode (biogpt_hip_eval, one token per API call): the launch stays on the device after its first token; token tk >= 1 is taken from the
     // pinned mailbox slot (mbox_seq0 + tk) % 64 = {n_past, causal, token, seq} that the NEXT biogpt_eval() call fills -- workgroup 0 of XCD 0 waits for it,
     // at most idle_ticks of the 100 MHz clock -- and every lm_head workgroup reports its share of the host logits row with a word in done_host
+    int32_t dual;              // contexts of 257 .. 512 keys (not resident): 1 = dec_xpipe_kernel's two-workgroups-per-head variant (needs gran_l), 0 = kernels_xlong.hip.h
     int32_t resident;
     int32_t res_tok0, res_n_past0;   // token 0 of a resident launch and its position
     int32_t res_dbg;                 // measurement only (BIOGPT_HIP_RES_DBG): 1 completion word without waiting for the row stores, 2 no sleep in the mailbox poll, 4 no row store
@@ -415,6 +416,11 @@ __device__ __forceinline__ uint32_t xp_pack4(int8_t q) {
     return (uint32_t)b | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24);
 }
 
+// granules of one layer in the long-context buffer (XpParams::gran_l): kernels_xlong.hip.h, and the 512-key variant here (DUAL)
+constexpr int XL_G_SC = 0;                     // [16 heads][1024 keys] scores
+constexpr int XL_G_PV = 16 * 1024;             // [16 heads][16 ranges][64 lo + 64 hi] partial sum_j V_jd p_j (double)
+constexpr int XL_G_LAYER = XL_G_PV + 16 * 16 * 128;
+
 // LDS carve (bytes)
 constexpr int XP_S_X = 0;                        // [1024] f32 layer input (residual of out_proj)
 constexpr int XP_S_X1 = XP_S_X + 4096;           // [1024] f32 (residual of fc2)
@@ -483,8 +489,14 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
-    static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
-    constexpr int NF4 = 16 / LPK, NV = KCAP / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
+    // DUAL (257 .. 512 keys): BOTH workgroups of a head -- h and 16 + h -- are attention workgroups, each with 256 keys' K / V rows in its registers and half
+    // of the head's 192 q / k / v rows to compute; they exchange those rows, their scores and (16 + h -> h) the partial PV sums inside the XCD
+    constexpr bool DUAL = SPLIT && KCAP > 256;
+    constexpr int KW = DUAL ? KCAP / 2 : KCAP;          // keys per workgroup
+    constexpr int HI = (DUAL && ROLE == 1) ? 1 : 0;     // which half of the keys (and of the q / k / v rows)
+    static_assert(!DUAL || !RES, "the two-workgroup variant has no resident form (biogpt_hip_eval beyond 256 keys: kernels_xlong.hip.h)");
+    static_assert(KW % NW == 0 && KW <= NW * 64 / LPK, "key capacity of the launch");
+    constexpr int NF4 = 16 / LPK, NV = KW / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
@@ -546,7 +558,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         // ---- this layer's weights into registers, its small vectors into LDS: issued as soon as the previous layer of this
         //      XCD is done, i.e. seven layers ahead of their use.  Workgroups 0-15 are the layer's attention heads and hold the
         //      head's old keys / values instead of q/k/v weights; workgroup 16 + h computes all 192 q/k/v rows of head h.
-        constexpr bool attn_wg = ATTN;
+        constexpr bool attn_wg = ATTN || (DUAL && ROLE == 1);
         const int head = slot & 15;
         Unit<WT> wo[OS], w1[FS], w2[F2R][2];
         {
@@ -842,14 +854,14 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 // (KV_SC1: unconditional -- a row beyond the cache slice reads as 0, buffer loads are range-checked -- so that no register is left undefined on any path)
                 if (KV_SC1 || kidx < t_cap) {
 #pragma unroll
-                    for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4<KV_SC1>(krs, kb, (kidx * (DK / 4) + ksub + LPK * m) * 4);
+                    for (int m = 0; m < NF4; m++) kr[m] = xp_kv_load4<KV_SC1>(krs, kb, ((HI * KW + kidx) * (DK / 4) + ksub + LPK * m) * 4);
                 } else {
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kr[m] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    const int j = sl + NW * k;
+                    const int j = HI * KW + sl + NW * k;
                     vr[k] = (KV_SC1 || j < t_cap) ? xp_kv_load1<KV_SC1>(vrs, vb, j * DK + dd) : 0.0f;
                 }
             }
@@ -897,6 +909,56 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     }
                 }
                 XP_WALL(1);
+            } else if constexpr (DUAL) {
+                // ---- half of the head's 192 q / k / v rows in here (rows 96 HI .. 96 HI + 95: q and k[0..31], or k[32..63] and v), the other half from the partner ----
+                constexpr int QH = QS / 2;
+                Unit<WT> wq[QH];
+#pragma unroll
+                for (int s = 0; s < QH; s++) {
+                    const int jj = (HI * QH + s) * 2 * NW + wave * 2 + rsub;
+                    load_unit<WT>(wq[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+                }
+#pragma unroll
+                for (int s = 0; s < QH; s++) xp_settle<WT, EXPAND>(wq[s]);
+                const float4 xv = layer_input();
+                XP_WALL(0);
+                float4 lnw = xv, lnb = xv;
+                if (worker) {
+                    reinterpret_cast<float4 *>(s_x)[tid] = xv;
+                    lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
+                }
+                ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                XP_WALL(6);
+                uint32_t ax[8];
+                const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
+                ax[0] = a.x; ax[1] = a.y; ax[2] = a.z; ax[3] = a.w; ax[4] = b.x; ax[5] = b.y; ax[6] = b.z; ax[7] = b.w;
+                const float axd = s_xd[sub];
+                const uint32_t axs = s_xs[sub];
+                float *const part = s_part + wave * 2 * QH * DEC_PS;
+#pragma unroll
+                for (int s = 0; s < QH; s++) part[(s * 2 + rsub) * DEC_PS + sub] = xp_dot<WT, EXPAND>(wq[s], ax, axd, __uint_as_float(axs), (int)axs);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 2 * QH) {
+                    const int jj = (HI * QH + (lane >> 1)) * 2 * NW + wave * 2 + (lane & 1);
+                    float v = __fadd_rn(s_bias[jj], sum32_in_order(part + lane * DEC_PS));
+                    const int which = jj >> 6, d = jj & 63;
+                    if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
+                    s_cur[jj] = v;
+                    xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
+                    if (which != 0) {                                              // KV append (biogpt.cpp:721-727), head-major cache
+                        float *cache = (which == 1) ? Y.kcache : Y.vcache;
+                        cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                    }
+                }
+                XP_WALL(1);
+                if (wave < 2) {       // the partner's 96 rows
+                    uint32_t v[1];
+                    const int jo = (1 - HI) * 96 + (tid < 96 ? tid : 0);
+                    xp_sweep_q<RES, 1>(G + XP_G_QKV + (jo >> 6) * 1024 + head * 64 + (jo & 63), tid < 96, epoch, v, p, etag);
+                    if (tid < 96) s_cur[jo] = __uint_as_float(v[0]);
+                }
             } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
                 // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
                 constexpr int Q0 = QS / 3;
@@ -973,12 +1035,13 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             float sc = -INFINITY;
-            if ((tid & ~63) < LPK * T) {
-                if (!LATE_KV && kidx == n_past) {
+            const int jg = HI * KW + kidx;      // this lane's key
+            if (HI * KW * LPK + (tid & ~63) < LPK * T) {
+                if (!LATE_KV && jg == n_past) {
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
                 }
-                if (kidx < T && !(LATE_KV && kidx == n_past)) sc = key_score(kr);
+                if (jg < T && !(LATE_KV && jg == n_past)) sc = key_score(kr);
             }
             static_assert(NW == 8, "key j = wave + 8 k sits in lane (wave + 8 k) & 63 of slot k >> 3");
             constexpr bool SMW = XP_SOFTMAX_WAVE != 0 && KCAP <= 64;      // (measured: -1.5 us per token with 64 keys, +-0 with 128, +1 / +9 us with 192 / 256 -- 2-4 look-ups per lane and 16-32 v_readlane per wave)
@@ -1040,6 +1103,18 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         sc = key_score(kr);
                     }
                 }
+                bool valid = jg < T && ksub == 0;      // this lane holds a score of the head
+                if constexpr (DUAL) {
+                    // the partner's 256 scores travel to the odd lanes (ksub == 1): maximum, look-ups and sum run over all of the head's keys in both workgroups
+                    static_assert(LPK == 2, "two lanes per key: the second one takes the partner's score of the same index");
+                    xp_u64 *const gsc = p.gran_l + (size_t)L * XL_G_LAYER + XL_G_SC + head * 1024;
+                    if (valid) xp_put_local(gsc + jg, etag, __float_as_uint(sc));
+                    const int jo = (1 - HI) * KW + kidx;
+                    const bool theirs = ksub == 1 && jo < T;
+                    uint32_t v[1];
+                    xp_sweep_q<RES, 1>(gsc + jo, theirs, epoch, v, p, etag);
+                    if (theirs) { sc = __uint_as_float(v[0]); valid = true; }
+                }
                 float mx = wave_max_f32(sc);
                 if (lane == 0) s_redf[wave] = mx;
                 __syncthreads();
@@ -1049,7 +1124,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 XP_WALL(13);
                 double sum = 0.0;
                 [[maybe_unused]] uint32_t ulo = 0u, uhi = 0u;
-                if (kidx < T && ksub == 0) {
+                if (valid) {
                     // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
                     const uint32_t ix = f2h(__fsub_rn(sc, mx)), neg = ix - 0x8000u;
                     uint16_t e16;
@@ -1058,7 +1133,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
                     else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
                     const float val = h2f(e16);
-                    s_S[kidx] = val;
+                    if (ksub == 0) s_S[kidx] = val;
                     sum = (double)val;
                     if constexpr (XP_SUM_INT != 0) { const uint32_t u = (uint32_t)__fmul_rn(val, 16777216.0f); ulo = u & 0xFFFFu; uhi = u >> 16; }
                 }
@@ -1097,7 +1172,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     }
 #pragma unroll
                     for (int k = 0; k < CH; k += 2) {
-                        const int j0 = sl + NW * (k0 + k), j1 = j0 + NW;
+                        const int j0 = HI * KW + sl + NW * (k0 + k), j1 = j0 + NW;
                         const double c0 = (double)__fmul_rn(j0 == n_past ? vcur : vr[k0 + k], __fmul_rn(pj[k], inv));
                         const double c1 = (double)__fmul_rn(j1 == n_past ? vcur : vr[k0 + k + 1], __fmul_rn(pj[k + 1], inv));
                         a0 += (j0 < T) ? c0 : 0.0;
@@ -1112,13 +1187,24 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 double t0 = 0.0, t1 = 0.0;
 #pragma unroll
                 for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
-                const float o = (float)(t0 + t1);
-                int8_t q8; float d8; uint32_t s8;
-                q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
-                const uint32_t packed = xp_pack4(q8);
-                const int blk = head * 2 + (tid >> 5);
-                if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), etag, packed);
-                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, etag, s8); }
+                double tot = t0 + t1;
+                [[maybe_unused]] xp_u64 *const gpv = DUAL ? p.gran_l + (size_t)L * XL_G_LAYER + XL_G_PV + head * 16 * 128 : nullptr;
+                if constexpr (DUAL && HI == 1) {      // the upper keys' partial sums go to the head's first workgroup
+                    xp_put_local(gpv + tid, etag, (uint32_t)__double2loint(tot)); xp_put_local(gpv + 64 + tid, etag, (uint32_t)__double2hiint(tot));
+                } else {
+                    if constexpr (DUAL) {
+                        uint32_t v[2];
+                        xp_sweep_q<RES, 2, 64>(gpv + tid, true, epoch, v, p, etag);
+                        tot += __hiloint2double((int)v[1], (int)v[0]);      // lower keys + upper keys (attn_split_combine_kernel's range order)
+                    }
+                    const float o = (float)tot;
+                    int8_t q8; float d8; uint32_t s8;
+                    q8_block32(o, TI::q81, q8, d8, s8, TI::q81);
+                    const uint32_t packed = xp_pack4(q8);
+                    const int blk = head * 2 + (tid >> 5);
+                    if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), etag, packed);
+                    if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, etag, s8); }
+                }
             }
         }
         XP_WALL(2);
@@ -1483,8 +1569,8 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int D = 1024, DK = 64, NT = NW * 64;
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;     // 2-row steps of qkv / out_proj / fc1 per wave; fc2 rows per wave
-    static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
-    constexpr int NF4 = 16 / LPK, NV = KCAP / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
+    static_assert(KCAP % NW == 0 && (KCAP > 256 ? KCAP / 2 : KCAP) <= NW * 64 / LPK, "key capacity of the launch");
+    constexpr int NF4 = 16 / LPK, NV = (KCAP > 256 ? KCAP / 2 : KCAP) / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
@@ -1533,7 +1619,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
     }
-    if (XP_EXP_LDS != 0 && SPLIT && !(xcd & 1) && slot < 16 && p.exp_n > 0) {      // the attention workgroups: the exp table's slice where the MLP halves keep GELU's
+    if (XP_EXP_LDS != 0 && SPLIT && !(xcd & 1) && (slot < 16 || KCAP > 256) && p.exp_n > 0) {      // the attention workgroups (512-key variant: all 32 of the XCD): the exp table's slice where the MLP halves keep GELU's
         const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
         for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
     }

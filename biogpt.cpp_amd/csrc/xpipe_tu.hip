@@ -1,4 +1,4 @@
-// Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys): 5 block formats x 4 context variants = 20
+// Translation unit of the XCD-pipelined decode launches (kernels_xpipe.hip.h: contexts up to 256 keys): 5 block formats x 5 context variants (<= 64 / 128 / 192 / 256 keys, and 257 .. 512 with two workgroups per head) = 25
 // persistent kernels here, the 20 resident ones in xpipe_res_tu.hip, the 20 long-context ones (kernels_xlong.hip.h) in four units of five (xlong_*_tu.hip), compiled apart
 // from engine.hip so that all of them build in parallel.  The kernel headers define non-inline __global__ functions, so this unit sees them under its own namespace name; the
 // parameter block crosses the boundary as bytes (same header, same layout; the size is checked).
@@ -41,6 +41,7 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), dim3(256), dim3(512), sm, st, xp);   // 24 instead of 32 value registers
     else if (t_cap <= 256) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>), dim3(256), dim3(512), sm, st, xp);
+    else if (t_cap <= 512 && xp.dual != 0 && xp.gran_l != nullptr) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 512, true>), dim3(256), dim3(512), sm, st, xp);   // two workgroups per head, 256 keys each
     else return (hipError_t)bg_xpipe_launch_long(WT, t_cap, sm, st, &xp, sizeof(xp), false);      // beyond 256 keys
     return hipGetLastError();
 }
@@ -48,8 +49,9 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
 template <int WT>
 hipError_t set_lds_t(size_t sm) {
     if (bg_xpipe_set_lds_resident(WT, sm) != (int)hipSuccess || bg_xpipe_set_lds_long(WT, sm) != (int)hipSuccess) return hipErrorInvalidValue;
-    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>)};
+    const void *fns[5] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 512, true>)};
     for (const void *fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
