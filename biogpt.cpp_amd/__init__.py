@@ -83,6 +83,7 @@ SYMBOLS = [
     ("biogpt_hip_eval", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
     ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("biogpt_hip_chunk_launches", C.c_int64, [_P]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
@@ -419,6 +420,10 @@ class BiogptModel:
         if got < 0:
             raise BiogptError(_err())
         return out[:got], secs.value
+
+    def chunk_launches(self):
+        """Evals of 2 .. 8 tokens that went through the column-per-XCD launch (biogpt_hip_chunk_launches)."""
+        return int(lib().biogpt_hip_chunk_launches(self._h))
 
     def xpipe_state(self):
         """1: single-token decode steps of this context run as the XCD-pipelined persistent launch; 0: off / path held by

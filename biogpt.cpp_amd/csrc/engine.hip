@@ -33,6 +33,7 @@
 #include "kernels_fdecode.hip.h"
 #include "kernels_lmhead.hip.h"
 #include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
+#include "kernels_xcols.hip.h"   // (likewise: xcols_tu.hip)
 #include "kernels_quant.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
@@ -171,7 +172,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -209,6 +210,7 @@ struct EngineOptions {
         eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
         xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
+        xcols = get("BIOGPT_HIP_XCOLS", 1);                 // evals of 2 .. 8 tokens (the reference's prompt chunks) as ONE persistent launch, one column per XCD (kernels_xcols.hip.h); 0: the launch chain of kernels_fast.hip.h
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
         xpipe_lm = get("BIOGPT_HIP_XPIPE_LM", 1);           // final LayerNorm + lm_head inside the pipelined launch
@@ -286,6 +288,10 @@ struct biogpt_hip_ctx {
     bgk::xp_u64 *xp_gran = nullptr;
     bgk::xp_u64 *xp_hop = nullptr;         // the hand-off regions that cross XCDs (x1 and x of every layer): two 8 KB candidates each, xpipe_place_hops picks
     bgk::xp_u64 *xp_gran_l = nullptr;      // long-context variant (kernels_xlong.hip.h): scores and partial outputs of the key-range helpers
+    bgk::xp_u64 *xc_gran = nullptr;        // column-per-XCD chunk launches (kernels_xcols.hip.h): [8 columns][n_layer][XP_G_LAYER] granules, allocated (zeroed) at the first such eval
+    int xc_lds = 0;                        // 0 not tried, 1 the kernels' LDS attribute is set, -1 it could not be set (such evals keep the launch chain)
+    int state_n_past = 0, state_chunk = 0; // what the last upload_state put into the device state
+    int64_t xc_launches = 0;               // evals that went through the chunk launch (biogpt_hip_chunk_launches)
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
@@ -841,6 +847,80 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     return true;
 }
 
+// ---- biogpt_eval with 2 .. 8 tokens (the reference's prompt chunks, main.cpp:129-137) as ONE persistent launch: one column per XCD (kernels_xcols.hip.h) ----
+extern "C" int bg_xcols_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
+extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes);
+
+// May this pass go through the chunk launch ?  It is one more launch of the context's pipeline (same control words and tag counter, all 256 compute units held):
+// same conditions and the device's pipeline slot (taken here).  Not under the opt-in causal mask, not for columns that are several reference chunks (DevState::chunk).
+bool xcols_usable(biogpt_hip_ctx *c, int N, int t_max) {
+    const int32_t wt = ftype_to_type(c->hp.ftype);
+    if (!c->opt.xcols || c->opt.causal || c->state_chunk != 0 || N < 2 || N > 8 || t_max > 256 || c->xc_lds < 0) return false;
+    if (!(wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1)) return false;      // Q8_0: 30 units x 9 registers per lane do not fit
+    if (!fused_decode_ok(c, t_max) || c->xp_state != 1) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }      // allocations below; chunk passes are never captured anyway
+    if (!c->xc_gran) {
+        const size_t bytes = (size_t)8 * c->hp.n_layer * bgk::XP_G_LAYER * 8;
+        if (hipMalloc(&c->xc_gran, bytes) != hipSuccess || hipMemsetAsync(c->xc_gran, 0, bytes, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->xc_gran) (void)hipFree(c->xc_gran);
+            c->xc_gran = nullptr; c->xc_lds = -1;
+            return false;
+        }
+    }
+    if (c->xc_lds == 0) {
+        const size_t sm = bgk::xpipe_smem_bytes(c->xp_gelu_p + c->xp_gelu_n);
+        c->xc_lds = (sm <= 64 * 1024 || bg_xcols_set_lds(wt, sm) == (int)hipSuccess) ? 1 : -1;
+        (void)hipGetLastError();
+        if (c->xc_lds < 0) return false;
+    }
+    return xpipe_usable(c, t_max);
+}
+
+// the N columns of the device state (upload_state) through all layers in one launch, then the ordinary final LayerNorm + lm_head launch on the LAST column (F8)
+bool enqueue_xcols(biogpt_hip_ctx *c, int N, int t_max) {
+    t_ctx = c;
+    (void)hipGetLastError();
+    const auto &hp = c->hp;
+    const int D = hp.d_model, V = hp.n_vocab, P = hp.n_positions;
+    const int32_t wt = ftype_to_type(hp.ftype);
+    bgk::XcParams xc{};
+    xc.layers = c->xp_layers; xc.n_layer = hp.n_layer; xc.gran = c->xc_gran; xc.ctl = c->xp_ctl; xc.err_host = c->xp_err_host;
+    xc.st = c->state;
+    xc.tok_emb = dev_matrix(c, c->plan.embed_tokens); xc.pos_emb = dev_matrix(c, c->plan.embed_pos);
+    xc.embed_scale = sqrtf((float)D);
+    xc.n_positions = P; xc.n_vocab = V;
+    xc.eps = 1e-5f; xc.q_scale = 1.0f / sqrtf(64.0f);
+    xc.P = P; xc.t_cap = std::min(P, (t_max + 63) & ~63);
+    xc.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
+    xc.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+    xc.gelu_p = c->xp_gelu_p; xc.gelu_n = c->xp_gelu_n; xc.gelu_z = c->xp_gelu_z;
+    xc.n_cols = N; xc.x_out = c->x;
+    if ((c->opt.dbg & 128) && !c->tstamp) {      // profiling builds: stage stamps (tools/xcols_timeline.py)
+        HIP_TRY(false, hipMalloc(&c->tstamp, (size_t)4 << 20));
+        HIP_TRY(false, hipMemset(c->tstamp, 0, (size_t)4 << 20));
+    }
+    xc.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
+    if (c->unsynced_from < 0) c->unsynced_from = c->state_n_past;      // what a disturbed launch would spoil: this chunk's K / V rows (and every later eval's until the next synchronisation)
+    c->xc_launches++;
+    HIP_TRY(false, (hipError_t)bg_xcols_launch(wt, xc.t_cap, bgk::xpipe_smem_bytes(xc.gelu_p + xc.gelu_n), c->stream, &xc, sizeof(xc)));
+    {  // final LayerNorm + lm_head of the last column + per-workgroup arg-max partials
+        const MatSlot &m = c->plan.lm_head;
+        const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
+        bgk::MatvecParams p = mv_base(c, m, s);
+        p.ln_w = dev_vec(c, c->plan.ln_w); p.ln_b = dev_vec(c, c->plan.ln_b);
+        p.ldx = D; p.ldo = V;
+        p.x = c->x + (size_t)(N - 1) * D; p.N = 1; p.out = c->logits;
+        if (s.grid > c->pmax_cap) BG_FAIL(false, "internal: arg-max partial buffer too small (%d > %d)", s.grid, c->pmax_cap);
+        p.pmax_val = c->pmax_val; p.pmax_idx = c->pmax_idx;
+        int lm_grid = 0;
+        HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, c->stream, &lm_grid)));
+        c->lm_blocks = lm_grid;
+    }
+    return true;
+}
+
 // batch: one column per sequence (decode step).  cols != null: the columns are prompt tokens of several sequences
 // (column states with seq_id / t_vis), no lm_head -- the caller gets the logits from the following decode step.
 bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool batch = false, const bgk::SeqState *cols = nullptr) {
@@ -848,6 +928,7 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
     (void)hipGetLastError();   // a failed call of some OTHER context / API leaves its code behind; the checks below are about these launches
     if (N < 1 || N > c->hp.n_positions) BG_FAIL(false, "internal: a pass of %d columns exceeds the %d-column activation scratch", N, c->hp.n_positions);
     if (N == 1 && !batch && !all_rows && fused_decode_ok(c, t_max)) return enqueue_decode_fused(c, t_max, 1, 0);
+    if (N >= 2 && N <= 8 && !batch && !all_rows && xcols_usable(c, N, t_max)) return enqueue_xcols(c, N, t_max);
     const auto &hp = c->hp;
     const int D = hp.d_model, F = hp.d_ff, V = hp.n_vocab, H = hp.n_head, P = hp.n_positions;
     const int dk = D / H;
@@ -1052,6 +1133,7 @@ bool upload_state(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past, i
     hs->n_gen = 0;
     hs->causal = c->opt.causal;
     hs->chunk = chunk;
+    c->state_n_past = n_past; c->state_chunk = chunk;
     std::memcpy(slot + sizeof(bgk::DevState), tokens, (size_t)n * 4);
     HIP_TRY(false, hipMemcpyAsync(c->state, slot, sizeof(bgk::DevState) + (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     return true;
@@ -1861,6 +1943,7 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     *row_out = rc == 0 ? ctx->row_cur : nullptr;
     return rc;
 }
+int64_t biogpt_hip_chunk_launches(const biogpt_hip_ctx *ctx) { return ctx ? ctx->xc_launches : -1; }
 int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4) {
     if (!ctx || !out4) return -1;
     out4[0] = ctx->spec_hits; out4[1] = ctx->spec_misses; out4[2] = ctx->spec_streak; out4[3] = ctx->spec_need;

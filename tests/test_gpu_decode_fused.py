@@ -697,6 +697,60 @@ def test_xlong_generation_in_multi_token_launches(pkg, oracle, files10, monkeypa
     g.close()
 
 
+@pytest.mark.parametrize("name", XPIPE_TYPES)
+def test_two_workgroups_per_head_step_257_to_512_keys(pkg, oracle, files, monkeypatch, name):
+    """257 .. 512 keys outside the resident launch (single-token graph replays of biogpt_hip_eval_device, generate_greedy's multi-token launches):
+    dec_xpipe_kernel<.., KCAP = 512> -- workgroups h and 16 + h of the layer's XCD hold 256 keys' K / V rows each, compute half of the head's q / k / v rows
+    each and exchange rows, scores and partial PV sums inside the XCD.  Logits and appended K / V rows bit for bit those of the key-range helpers
+    (BIOGPT_HIP_XPIPE_DUAL=0, kernels_xlong.hip.h) and of the five-launch layer; the oracle within the contract.  Positions at both bucket borders, at the
+    256-key border between the two workgroups, and where the upper workgroup holds 1 / 2 / 255 / 256 keys."""
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device (xpipe_state %d)" % g.xpipe_state())
+    o = oracle.OracleModel(files[name], n_threads=16)
+    rng = np.random.default_rng(53)
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 511)]
+    checked = [255, 256, 257, 258, 300, 383, 384, 447, 509, 510, 511]
+    last = (KW["n_layer"] - 1) * KW["n_positions"]
+
+    def step(n_past, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g.refresh_options()
+        for k in env:
+            monkeypatch.delenv(k)
+        g.eval_device([toks[n_past]], n_past)
+        row = g.read_logits()
+        kv = [g.read_kv(w, (last + n_past) * KW["d_model"], KW["d_model"]) for w in (0, 1)]
+        return row, kv
+
+    n_past, worst = 0, 0.0
+    while n_past <= checked[-1]:
+        if n_past in checked:
+            ld, kd = step(n_past, {"BIOGPT_HIP_XPIPE": "1", "BIOGPT_HIP_XPIPE_DUAL": "1"})
+            assert g.xpipe_state() == 1, "pipeline abandoned at n_past %d" % n_past
+            lh, kh = step(n_past, {"BIOGPT_HIP_XPIPE": "1", "BIOGPT_HIP_XPIPE_DUAL": "0"})
+            lf, kf = step(n_past, {"BIOGPT_HIP_XPIPE": "0"})
+            lo = o.eval([toks[n_past]], n_past)
+            assert (ld == lh).all() and (ld == lf).all(), "%s: n_past %d: two workgroups per head vs helpers %g, vs five launches %g" % (
+                name, n_past, np.abs(ld - lh).max(), np.abs(ld - lf).max())
+            for w in (0, 1):
+                assert (kd[w] == kh[w]).all() and (kd[w] == kf[w]).all(), (n_past, w)
+            worst = max(worst, float(np.abs(ld - lo).max()))
+            assert int(ld.argmax()) == int(lo.argmax())
+            n_past += 1
+        else:
+            m = 1
+            while (n_past + m) not in checked and m < 8:
+                m += 1
+            chunk = toks[n_past:n_past + m]
+            g.eval_device(chunk, n_past); g.synchronize(); o.eval(chunk, n_past)
+            n_past += m
+    print("%s: 257 .. 512 keys, two workgroups per head: worst |diff| vs oracle %.2e" % (name, worst))
+    assert worst <= ATOL
+    g.close()
+
+
 def test_tripped_pipeline_with_evals_in_flight_says_where_to_resume(pkg, files, monkeypatch):
     """A pipelined launch that is disturbed while EARLIER asynchronous single-token evals are still in flight has spoiled their K / V rows too: the synchronising
     call must not silently repeat only itself -- it fails and names the position to resume from; resuming there gives the undisturbed logits."""
