@@ -467,6 +467,27 @@ def main():
                                                "bound": "neither peak: the chain is VALU-bound -- every v_mfma_i32_16x16x32_i8 (16 cycles) is followed by the exact per-block f32 scaling of its 4 outputs per lane "
                                                         "(the reference's arithmetic), and the attention (exact double sums) runs on the VALU"},
                                   "note": "512-token prompt, 64 reference evals of n_batch=8 in one pass (bench.py --workload prefill is the full bench line)"}
+            # the reference's OWN prompt loop (main.cpp:129-137): one biogpt_eval per n_batch = 8 tokens, the row copied out every time.  Up to 256 keys such an eval is ONE
+            # persistent launch with one column per XCD (csrc/kernels_xcols.hip.h), beyond that the launch chain of kernels_fast.hip.h
+            try:
+                def chunk_loop(n_tok):
+                    t0 = time.perf_counter()
+                    for at in range(0, n_tok, 8):
+                        model.eval(ptoks[at:at + 8], at)
+                    return time.perf_counter() - t0
+                chunk_loop(256)
+                before = model.chunk_launches()
+                t256 = min(chunk_loop(256) for _ in range(3))
+                per_loop = (model.chunk_launches() - before) // 3
+                t512 = min(chunk_loop(512) for _ in range(2))
+                out["prompt_chunk_evals"] = {"tokens_per_s_0_256_keys": round(256 / t256, 1), "ms_per_eval_0_256_keys": round(t256 / 32 * 1e3, 3),
+                                             "chunk_launches_per_32_evals": int(per_loop),
+                                             "tokens_per_s_512_token_prompt": round(512 / t512, 1), "ms_per_eval_257_512_keys": round((t512 - t256) / 32 * 1e3, 3),
+                                             "note": "biogpt_hip_eval per 8-token chunk from Python (ctypes), rows copied to the host; 0 .. 256 keys: the column-per-XCD launch "
+                                                     "(every XCD streams all weights: bound by what one XCD pulls from the fabric, ~ 0.42 TB/s; profiles/xcols_timeline_r4.txt), "
+                                                     "257 .. 512 keys: the launch chain (round 3: 0.86 ms per eval at every context)"}
+            except Exception as e:
+                out["prompt_chunk_evals"] = {"error": str(e)[:300]}
             # the drop-in API loop as a C++ caller runs it (main.cpp:91-151: one eval call per token, sampler on the host; never
             # `value`): the whole logits row over PCIe + host arg-max, and eval + device top-40 (512 bytes over PCIe)
             pr = make_prompt(hp.n_vocab, 7)

@@ -1834,8 +1834,8 @@ bool enqueue_prompt(biogpt_hip_ctx *c, const int32_t *tokens, int n, int n_past,
     return true;
 }
 
-int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t n_batch,
-                           float *logits_out) {
+static int eval_prompt_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t n_batch, float *logits_out) {
+    XpCallScope xp_scope(ctx);
     clear_error();
     if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
     if (!check_eval_args(ctx, tokens, n_tokens, n_past)) return -1;
@@ -1845,6 +1845,8 @@ int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n
     if (logits_out) {
         HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+        ctx->mbox_synced = ctx->mbox_sent;
+        if (!xpipe_check(ctx)) return -2;      // a prompt of up to 8 tokens is a pipelined launch (kernels_xcols.hip.h; one token: kernels_xpipe.hip.h)
     }
     return 0;
 }
@@ -1948,6 +1950,11 @@ int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4) {
     if (!ctx || !out4) return -1;
     out4[0] = ctx->spec_hits; out4[1] = ctx->spec_misses; out4[2] = ctx->spec_streak; out4[3] = ctx->spec_need;
     return 0;
+}
+int biogpt_hip_eval_prompt(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past, int32_t n_batch, float *logits_out) {
+    int rc = eval_prompt_once(ctx, tokens, n_tokens, n_past, n_batch, logits_out);
+    if (rc != 0 && xpipe_retry(ctx, n_past)) rc = eval_prompt_once(ctx, tokens, n_tokens, n_past, n_batch, logits_out);
+    return rc;
 }
 int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int32_t n_past, float *logits_out) {
     if (!logits_out) BG_FAIL(-1, "null logits buffer");

@@ -411,8 +411,24 @@ def test_xpipe_disturbed_launch_is_repeated_on_the_five_launch_layer(pkg, files,
     monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
     g = pkg.BiogptModel.load(files["q4_0"])
     monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    # (round 4: the 4-token prompt is itself a pipelined launch now -- the column-per-XCD chunk launch of kernels_xcols.hip.h -- so the fault hits the
+    # asynchronous prompt eval: the synchronising call says from where to repeat, the repetition runs on the launch chain)
+    g.eval_device(prompt, 0)
+    with pytest.raises(pkg.BiogptError, match="from position 0 on must be repeated"):
+        g.synchronize()
+    assert g.xpipe_state() == -1
     g.eval_device(prompt, 0); g.synchronize()
     l0 = g.eval([7], 4)
+    assert g.xpipe_state() == -1
+    g.close()
+    # ... and with the chunk launch off the fault hits the single-token eval, which is repeated transparently
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    monkeypatch.setenv("BIOGPT_HIP_XCOLS", "0")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    monkeypatch.delenv("BIOGPT_HIP_XCOLS")
+    g.eval_device(prompt, 0); g.synchronize()
+    assert (g.eval([7], 4) == l0).all()
     assert g.xpipe_state() == -1
     g.close()
     ref = pkg.BiogptModel.load(files["q4_0"])
@@ -761,14 +777,28 @@ def test_tripped_pipeline_with_evals_in_flight_says_where_to_resume(pkg, files, 
     ref.eval_device(prompt, 0); ref.eval_device([7], 4); want = ref.eval([8], 5)
     ref.close()
     monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    monkeypatch.setenv("BIOGPT_HIP_XCOLS", "0")          # the prompt chunk on the launch chain: the first pipelined launch is the single-token eval
     g = pkg.BiogptModel.load(files["q4_0"])
     monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    monkeypatch.delenv("BIOGPT_HIP_XCOLS")
     g.eval_device(prompt, 0)
     g.eval_device([7], 4)                     # pipelined, not synchronised: drains with garbage rows
     with pytest.raises(pkg.BiogptError, match="n_past = 4"):
         g.eval([8], 5)
     assert g.xpipe_state() == -1
     g.eval_device([7], 4)                     # resume where told, now on the five-launch layer
+    assert (g.eval([8], 5) == want).all()
+    g.close()
+    # round 4: the prompt chunk itself is a pipelined launch (kernels_xcols.hip.h) -- then it is the disturbed one, and everything from position 0 on must be repeated
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    g.eval_device(prompt, 0)
+    g.eval_device([7], 4)
+    with pytest.raises(pkg.BiogptError, match="n_past = 0"):
+        g.eval([8], 5)
+    assert g.xpipe_state() == -1 and g.chunk_launches() == 1
+    g.eval_device(prompt, 0); g.eval_device([7], 4)
     assert (g.eval([8], 5) == want).all()
     g.close()
 
