@@ -109,7 +109,11 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     // 256-key variant, attention workgroups: 64 K / V registers + 18 packed units + the dots' temporaries spill 28 .. 47 VGPRs; there the fc1 / fc2 units are requested when
     // the attention is done (one / two stages ahead of their use: the poll in between waits for them) and the head's K / V rows and those 16 units never wait together
     constexpr bool LATE_W2 = ATTN && KCAP > 128;
-    constexpr bool FREE = XC_FREE_WAVES != 0 && !LATE_W2;      // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
+    // bits of XC_FREE_WAVES: 1 the q / k / v workgroups (every unit), 2 the attention workgroups' fc1 / fc2 units, 4 their out_proj units and K / V rows
+    // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
+    constexpr bool FREE = (XC_FREE_WAVES & 1) != 0 && !ATTN;
+    constexpr bool FREE_F = (XC_FREE_WAVES & 2) != 0 && ATTN && !LATE_W2;
+    constexpr bool FREE_O = (XC_FREE_WAVES & 4) != 0 && ATTN;
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
@@ -396,7 +400,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                 }
                 s_pv[tid] = a0 + a1;
             }
-            if (FREE && wave >= 4 && more) request_kv(L + 1, tid);
+            if (FREE_O && wave >= 4 && more) request_kv(L + 1, tid);
             __syncthreads();
             XC_WALL(15);
             if (tid < DK) {
@@ -445,7 +449,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * OS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if (FREE && wave >= 4 && more) request_wo(L + 1, tid);
+            if ((FREE || FREE_O) && wave >= 4 && more) request_wo(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -477,7 +481,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * FS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if (FREE && wave >= 4 && more) request_w1(L + 1, tid);
+            if ((FREE || FREE_F) && wave >= 4 && more) request_w1(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -530,7 +534,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = unit_dot_quant<WT>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
             }
-            if (FREE && wave >= 4 && more) request_w2(L + 1, tid);
+            if ((FREE || FREE_F) && wave >= 4 && more) request_w2(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -557,11 +561,9 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(5);
         if constexpr (ATTN) {      // the burst of the attention workgroups: the next layer's units in the order of their use, the head's old keys / values, the small vectors
             if (more) {
-                if (!FREE || wave < 4) {
-                    request_wo(L + 1, tid);
-                    if constexpr (!LATE_W2) { request_w1(L + 1, tid); request_w2(L + 1, tid); }
-                    request_kv(L + 1, tid);
-                }
+                if (!FREE_O || wave < 4) request_wo(L + 1, tid);
+                if constexpr (!LATE_W2) { if (!FREE_F || wave < 4) { request_w1(L + 1, tid); request_w2(L + 1, tid); } }
+                if (!FREE_O || wave < 4) request_kv(L + 1, tid);
                 request_small(L + 1, tid);
             }
         }
