@@ -209,7 +209,7 @@ struct EngineOptions {
         verbose = get("BIOGPT_HIP_VERBOSE", 0);
         eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
-        xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
+        xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays, resident launches): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
         xcols = get("BIOGPT_HIP_XCOLS", 1);                 // evals of 2 .. 8 tokens (the reference's prompt chunks) as ONE persistent launch, one column per XCD (kernels_xcols.hip.h); 0: the launch chain of kernels_fast.hip.h
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch

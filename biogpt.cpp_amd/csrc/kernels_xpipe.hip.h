@@ -102,7 +102,7 @@ struct XpParams {
     // resident mode (biogpt_hip_eval, one token per API call): the launch stays on the device after its first token; token tk >= 1 is taken from the
     // pinned mailbox slot (mbox_seq0 + tk) % 64 = {n_past, causal, token, seq} that the NEXT biogpt_eval() call fills -- workgroup 0 of XCD 0 waits for it,
     // at most idle_ticks of the 100 MHz clock -- and every lm_head workgroup reports its share of the host logits row with a word in done_host
-    int32_t dual;              // contexts of 257 .. 512 keys (not resident): 1 = dec_xpipe_kernel's two-workgroups-per-head variant (needs gran_l), 0 = kernels_xlong.hip.h
+    int32_t dual;              // contexts of 257 .. 512 keys (every launch form): 1 = dec_xpipe_kernel's two-workgroups-per-head variant (needs gran_l), 0 = kernels_xlong.hip.h
     int32_t resident;
     int32_t res_tok0, res_n_past0;   // token 0 of a resident launch and its position
     int32_t res_dbg;                 // measurement only (BIOGPT_HIP_RES_DBG): 1 completion word without waiting for the row stores, 2 no sleep in the mailbox poll, 4 no row store
@@ -494,7 +494,6 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     constexpr bool DUAL = SPLIT && KCAP > 256;
     constexpr int KW = DUAL ? KCAP / 2 : KCAP;          // keys per workgroup
     constexpr int HI = (DUAL && ROLE == 1) ? 1 : 0;     // which half of the keys (and of the q / k / v rows)
-    static_assert(!DUAL || !RES, "the two-workgroup variant has no resident form (biogpt_hip_eval beyond 256 keys: kernels_xlong.hip.h)");
     static_assert(KW % NW == 0 && KW <= NW * 64 / LPK, "key capacity of the launch");
     constexpr int NF4 = 16 / LPK, NV = KW / NW;        // float4 of a key row per lane; values per lane (key slices of NW)
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
@@ -947,7 +946,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                    if (which != 0) {                                              // KV append (biogpt.cpp:721-727), head-major cache
+                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -958,6 +957,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int jo = (1 - HI) * 96 + (tid < 96 ? tid : 0);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + (jo >> 6) * 1024 + head * 64 + (jo & 63), tid < 96, epoch, v, p, etag);
                     if (tid < 96) s_cur[jo] = __uint_as_float(v[0]);
+                    if (RES && lane == 0) s_kvdead[wave] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
                 // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
@@ -1008,6 +1008,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             __syncthreads();
+            if constexpr (RES && DUAL) { if ((s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u; }
             XP_WALL(7);
             constexpr bool LATE_KV = !MERGE && XP_SPLIT_Q != 0 && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
             auto key_score = [&](const float4 (&kk)[NF4]) __attribute__((always_inline)) -> float {
@@ -1117,10 +1118,17 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
                 float mx = wave_max_f32(sc);
                 if (lane == 0) s_redf[wave] = mx;
+                if (RES && DUAL && lane == 0) reinterpret_cast<uint32_t *>(s_redf)[NW + wave] = (etag == 0u) ? 1u : 0u;      // (resident two-workgroup variant: a wave whose partner scores never came)
                 __syncthreads();
                 mx = s_redf[0];
 #pragma unroll
                 for (int w = 1; w < NW; w++) mx = fmaxf(mx, s_redf[w]);
+                if constexpr (RES && DUAL) {       // ... takes every wave of the workgroup with it: nothing this workgroup publishes from here on carries a valid tag
+                    uint32_t dead = 0u;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) dead |= reinterpret_cast<const uint32_t *>(s_redf)[NW + w];
+                    if (dead != 0u) etag = 0u;
+                }
                 XP_WALL(13);
                 double sum = 0.0;
                 [[maybe_unused]] uint32_t ulo = 0u, uhi = 0u;

@@ -1,5 +1,5 @@
 // Translation unit of the RESIDENT pipelined decode launches (kernels_xpipe.hip.h with RES = true: biogpt_hip_eval's launch that stays on the
-// device between calls): 5 block formats x 4 context variants.  Same arrangement as xpipe_tu.hip (own namespace name, parameter block as bytes).
+// device between calls): 5 block formats x 5 context variants (<= 64 / 128 / 192 / 256 keys, 257 .. 512 with two workgroups per head).  Same arrangement as xpipe_tu.hip (own namespace name, parameter block as bytes).
 #define bgk bgk_xr
 #include <hip/hip_runtime.h>
 
@@ -16,14 +16,16 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 192) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 192, true, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 256) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 256, true, true>), dim3(256), dim3(512), sm, st, xp);
+    else if (t_cap <= 512 && xp.dual != 0 && xp.gran_l != nullptr) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 2, 8, 512, true, true>), dim3(256), dim3(512), sm, st, xp);   // two workgroups per head, 256 keys each
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 template <int WT>
 hipError_t set_lds_t(size_t sm) {
-    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true, true>),
-                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true, true>)};
+    const void *fns[5] = {reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 8, 8, 64, true, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 4, 8, 128, true, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 192, true, true>), reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 256, true, true>),
+                          reinterpret_cast<const void *>(bgk::dec_xpipe_kernel<WT, 2, 8, 512, true, true>)};
     for (const void *fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;

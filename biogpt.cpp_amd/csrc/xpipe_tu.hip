@@ -35,7 +35,7 @@ template <int WT>
 hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &xp) {
     // 8 waves per workgroup: 14-16 weight units per lane, unpacked to 9 registers each, + the head's old keys / values (<= 256 keys) or this
     // workgroup's key range of the next layer (beyond) fit the 256-register budget
-    if (xp.resident != 0 && t_cap > 256) return (hipError_t)bg_xpipe_launch_long(WT, t_cap, sm, st, &xp, sizeof(xp), true);
+    if (xp.resident != 0 && t_cap > 256 && !(t_cap <= 512 && xp.dual != 0 && xp.gran_l != nullptr)) return (hipError_t)bg_xpipe_launch_long(WT, t_cap, sm, st, &xp, sizeof(xp), true);
     if (xp.resident != 0) return (hipError_t)bg_xpipe_launch_resident(WT, t_cap, sm, st, &xp, sizeof(xp));      // its own translation unit (xpipe_res_tu.hip)
     if (t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);
