@@ -13,6 +13,15 @@ if len(sys.argv) > 2 and sys.argv[2] == "prefill":
     g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
 elif len(sys.argv) > 2 and sys.argv[2] == "long":      # the pipelined launch of a 1024-key step (kernels_xlong.hip.h): graph replays at n_past = 1023
     print("T=1024", round(g.bench_decode(1023, 40) * 1e6, 2), "us per token", flush=True)
+elif len(sys.argv) > 2 and sys.argv[2] == "chunk":     # the column-per-XCD chunk launch (kernels_xcols.hip.h): 8-token evals at 0 .. 64 keys
+    rng = np.random.default_rng(7000)
+    toks = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 63)]
+    for rep in range(3):
+        for at in range(0, 64, 8):
+            g.eval(toks[at:at + 8], at)
+    print("chunk launches", g.chunk_launches(), flush=True)
+elif len(sys.argv) > 2 and sys.argv[2] == "dual":      # the two-workgroups-per-head launch at 400 keys: graph replays at n_past = 399
+    print("T=400", round(g.bench_decode(399, 40) * 1e6, 2), "us per token", flush=True)
 elif len(sys.argv) > 2 and sys.argv[2] == "xpipe":     # only the XCD-pipelined single-token launch at 104 keys (bench.py's roofline.traffic pass)
     if g.xpipe_state() == 1:
         s, b = g.bench_matvec(11, 0, 24)

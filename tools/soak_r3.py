@@ -15,7 +15,7 @@ assert g.xpipe_state() == 1, "pipeline not available"
 rng = np.random.default_rng(99)
 long_prompt = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 249)]
 pr = [2, 100, 200, 300]
-want_long = want_api = want_rows = want_api_long = want_dev = None
+want_long = want_api = want_rows = want_api_long = want_dev = want_chunks = None
 api_prompt = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 299)]
 dev_prompt = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 399)]
 rounds = toks = 0
@@ -51,9 +51,19 @@ while time.time() < t_end:
     rows = np.stack(rows)
     if want_dev is None: want_dev = rows
     assert (rows == want_dev).all(), "a long-context logits row differs in round %d" % rounds
+    # (f, round 4) the reference's prompt loop: a 200-token prompt in evals of 8 / 5 / 3 tokens (column-per-XCD chunk launches, kernels_xcols.hip.h), every row compared
+    rows = []
+    n_past = 0
+    for k in range(36):
+        n = (8, 5, 3)[k % 3] if k % 4 == 3 else 8
+        if n_past + n > 200: break
+        rows.append(g.eval(api_prompt[n_past:n_past + n], n_past).copy()); n_past += n
+    rows = np.stack(rows)
+    if want_chunks is None: want_chunks = rows
+    assert (rows == want_chunks).all(), "a chunk eval's logits row differs in round %d" % rounds
     assert g.xpipe_state() == 1, "the pipeline was abandoned in round %d" % rounds
-    rounds += 1; toks += len(ids) + len(api) + 64 + len(apil) + 48
+    rounds += 1; toks += len(ids) + len(api) + 64 + len(apil) + 48 + n_past
     slowest = max(slowest, time.time() - t0)
-print("speculation:", g.resident_stats())
+print("speculation:", g.resident_stats(), " chunk launches:", g.chunk_launches())
 print("format", os.path.basename(q))
 print("soak ok: %d rounds, %d tokens in %.0f s, slowest round %.3f s, pipeline state %d" % (rounds, toks, secs, slowest, g.xpipe_state()))
