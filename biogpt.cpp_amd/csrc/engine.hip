@@ -274,7 +274,7 @@ struct biogpt_hip_ctx {
     std::set<const void *> lds_attr_done;     // kernels whose > 64 KB dynamic-LDS opt-in attribute is set on this device
     unsigned long long *tstamp = nullptr;     // profiling only (opt.dbg & 32)
     int launch_parity = 0;
-    hipGraphExec_t graph_batch[6] = {};   // [context bucket], captured for graph_batch_n sequences
+    hipGraphExec_t graph_batch[12] = {};  // [6 * (steps as column-per-XCD launches) + context bucket], captured for graph_batch_n sequences
     int graph_batch_n = 0;
 
     hipStream_t stream = nullptr;
@@ -292,6 +292,7 @@ struct biogpt_hip_ctx {
     int xc_lds = 0;                        // 0 not tried, 1 the kernels' LDS attribute is set, -1 it could not be set (such evals keep the launch chain)
     int state_n_past = 0, state_chunk = 0; // what the last upload_state put into the device state
     int64_t xc_launches = 0;               // evals that went through the chunk launch (biogpt_hip_chunk_launches)
+    int xc_batch = 0;                      // biogpt_hip_generate_greedy_batch with 2 .. 8 sequences holds the device's pipeline slot: its decode steps run as column-per-XCD launches (streams mode)
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
@@ -853,13 +854,15 @@ extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes);
 
 // May this pass go through the chunk launch ?  It is one more launch of the context's pipeline (same control words and tag counter, all 256 compute units held):
 // same conditions and the device's pipeline slot (taken here).  Not under the opt-in causal mask, not for columns that are several reference chunks (DevState::chunk).
-bool xcols_usable(biogpt_hip_ctx *c, int N, int t_max) {
+// model / device / options fit, and the launch's buffers exist (allocated here: never inside a stream capture)
+bool xcols_prepare(biogpt_hip_ctx *c, int N, int t_max) {
     const int32_t wt = ftype_to_type(c->hp.ftype);
-    if (!c->opt.xcols || c->opt.causal || c->state_chunk != 0 || N < 2 || N > 8 || t_max > 256 || c->xc_lds < 0) return false;
+    if (!c->opt.xcols || c->opt.causal || N < 2 || N > 8 || t_max > 256 || c->xc_lds < 0) return false;
     if (!(wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1)) return false;      // Q8_0: 30 units x 9 registers per lane do not fit
     if (!fused_decode_ok(c, t_max) || c->xp_state != 1) return false;
+    if (c->xc_gran && c->xc_lds == 1) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }      // allocations below; chunk passes are never captured anyway
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
     if (!c->xc_gran) {
         const size_t bytes = (size_t)8 * c->hp.n_layer * bgk::XP_G_LAYER * 8;
         if (hipMalloc(&c->xc_gran, bytes) != hipSuccess || hipMemsetAsync(c->xc_gran, 0, bytes, c->stream) != hipSuccess) {
@@ -875,11 +878,15 @@ bool xcols_usable(biogpt_hip_ctx *c, int N, int t_max) {
         (void)hipGetLastError();
         if (c->xc_lds < 0) return false;
     }
+    return true;
+}
+bool xcols_usable(biogpt_hip_ctx *c, int N, int t_max) {
+    if (c->state_chunk != 0 || !xcols_prepare(c, N, t_max)) return false;
     return xpipe_usable(c, t_max);
 }
 
 // the N columns of the device state (upload_state) through all layers in one launch, then the ordinary final LayerNorm + lm_head launch on the LAST column (F8)
-bool enqueue_xcols(biogpt_hip_ctx *c, int N, int t_max) {
+bool enqueue_xcols(biogpt_hip_ctx *c, int N, int t_max, bool streams = false) {
     t_ctx = c;
     (void)hipGetLastError();
     const auto &hp = c->hp;
@@ -897,14 +904,16 @@ bool enqueue_xcols(biogpt_hip_ctx *c, int N, int t_max) {
     xc.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
     xc.gelu_p = c->xp_gelu_p; xc.gelu_n = c->xp_gelu_n; xc.gelu_z = c->xp_gelu_z;
     xc.n_cols = N; xc.x_out = c->x;
+    if (streams) { xc.seq = c->seq; xc.kroot = c->bk; xc.vroot = c->bv; xc.seq_stride = (int64_t)hp.n_layer * P * D; }
     if ((c->opt.dbg & 128) && !c->tstamp) {      // profiling builds: stage stamps (tools/xcols_timeline.py)
         HIP_TRY(false, hipMalloc(&c->tstamp, (size_t)4 << 20));
         HIP_TRY(false, hipMemset(c->tstamp, 0, (size_t)4 << 20));
     }
     xc.wall = (c->opt.dbg & 128) ? c->tstamp : nullptr;
-    if (c->unsynced_from < 0) c->unsynced_from = c->state_n_past;      // what a disturbed launch would spoil: this chunk's K / V rows (and every later eval's until the next synchronisation)
+    if (c->unsynced_from < 0) c->unsynced_from = streams ? 0 : c->state_n_past;      // what a disturbed launch would spoil: this chunk's K / V rows (and every later eval's until the next synchronisation)
     c->xc_launches++;
     HIP_TRY(false, (hipError_t)bg_xcols_launch(wt, xc.t_cap, bgk::xpipe_smem_bytes(xc.gelu_p + xc.gelu_n), c->stream, &xc, sizeof(xc)));
+    if (streams) return true;      // every sequence's row: the caller's 8-column lm_head chain on c->x
     {  // final LayerNorm + lm_head of the last column + per-workgroup arg-max partials
         const MatSlot &m = c->plan.lm_head;
         const MvShape s = mv_shape(m.type, m.M, m.K, target_wgs(), 1);
@@ -956,10 +965,15 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
     float *const vroot = batch ? c->bv : c->memory_v;
     const int q81 = (wt == T_Q4_1 || wt == T_Q5_1) ? 1 : 0;
 
+    // a decode step of 2 .. 8 sequences while the caller (biogpt_hip_generate_greedy_batch) holds the device's pipeline slot: embedding + all layers as ONE launch,
+    // one sequence per XCD (kernels_xcols.hip.h, streams mode); the rows below on its output
+    const bool xc_streams = batch && !cols && c->xc_batch != 0 && t_max <= 256 && xcols_prepare(c, N, t_max);
+    if (xc_streams) { if (!enqueue_xcols(c, N, t_max, true)) return false; }
+    else
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
                        sqrtf((float)D), c->x, D, batch ? (cols ? cols : c->seq) : nullptr);
-    for (int l = 0; l < hp.n_layer; l++) {
+    for (int l = 0; l < hp.n_layer && !xc_streams; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
             const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw, N);
@@ -1976,8 +1990,10 @@ int biogpt_hip_generate_greedy(biogpt_hip_ctx *ctx, const int32_t *prompt, int32
 
 static int hp_cols(const biogpt_hip_ctx *c) { return c->hp.n_positions; }   // scratch is sized [n_positions] columns
 
-int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_seqs,
-                                     int32_t n_batch, int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+static int generate_greedy_batch_once(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_seqs,
+                                      int32_t n_batch, int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+    XpCallScope xp_scope(ctx);
+    struct XcBatchScope { biogpt_hip_ctx *c; ~XcBatchScope() { if (c) c->xc_batch = 0; } } xc_scope{ctx};
     clear_error();
     if (!ctx || !prompts || !prompt_lens || !out_ids) BG_FAIL(-1, "null argument");
     if (!ctx->ready) BG_FAIL(-1, "model has no tensors loaded (empty model): cannot evaluate");
@@ -2039,6 +2055,10 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     }
     HIP_TRY(-2, hipMemcpy(ctx->seq, hs.data(), sizeof(bgk::SeqState) * n_seqs, hipMemcpyHostToDevice));
 
+    // 2 .. 8 sequences: the decode steps as column-per-XCD launches while this call holds the device's pipeline slot (decided ONCE, before any capture: a graph is
+    // replayed only in the state it was captured for -- graph_batch[6 * pl + bucket])
+    ctx->xc_batch = (n_seqs >= 2 && n_seqs <= 8 && max_len + 1 <= 256 && xcols_prepare(ctx, n_seqs, std::min(256, max_len + 1)) && xpipe_usable(ctx, 256)) ? 1 : 0;
+    const int pl = ctx->xc_batch;
     auto batch_step = [&](int t_max) -> bool {
         if (!enqueue_forward(ctx, n_seqs, false, t_max, true)) return false;
         hipLaunchKernelGGL(bgk::argmax_rows_kernel, dim3(n_seqs), dim3(1024), 0, ctx->stream, ctx->logits_all, V, V, ctx->seq, 0, ctx->seq_gen, P, 1);
@@ -2048,14 +2068,14 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     const bool use_graph = ctx->opt.no_graph == 0;
     if (use_graph) {
         for (int b = graph_bucket(max_len + 1); b <= graph_bucket(std::max(1, max_len + n_predict - 1)); b++) {
-            if (ctx->graph_batch[b]) continue;
+            if (ctx->graph_batch[6 * pl + b]) continue;
             hipGraph_t g = nullptr;
             HIP_TRY(-2, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
             const bool ok = batch_step(bucket_tmax(ctx, b));
             hipError_t e = hipStreamEndCapture(ctx->stream, &g);
             if (!ok) { if (g) (void)hipGraphDestroy(g); return -2; }
             HIP_TRY(-2, e);
-            HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_batch[b], g, nullptr, nullptr, 0));
+            HIP_TRY(-2, hipGraphInstantiate(&ctx->graph_batch[6 * pl + b], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
         }
     }
@@ -2106,16 +2126,23 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
     if (!batch_step(max_len)) return -2;   // last prompt token of every sequence -> first sampled token, n_past = prompt length
     for (int k = 1; k < n_predict; k++) {  // batched decode: one column per sequence
         const int t_max = max_len + k;
-        if (use_graph) HIP_TRY(-2, hipGraphLaunch(ctx->graph_batch[graph_bucket(t_max)], ctx->stream));
+        if (use_graph) HIP_TRY(-2, hipGraphLaunch(ctx->graph_batch[6 * pl + graph_bucket(t_max)], ctx->stream));
         else if (!batch_step(t_max)) return -2;
     }
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
     const auto t1 = std::chrono::steady_clock::now();
+    if (!xpipe_check(ctx)) return -2;      // (steps as column-per-XCD launches: a disturbed one spoils the run -- the caller below repeats it on the launch chain)
     if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
     std::vector<int32_t> gen((size_t)n_seqs * P);
     HIP_TRY(-2, hipMemcpy(gen.data(), ctx->seq_gen, gen.size() * 4, hipMemcpyDeviceToHost));
     for (int s = 0; s < n_seqs; s++) std::memcpy(out_ids + (size_t)s * n_predict, gen.data() + (size_t)s * P, (size_t)n_predict * 4);
     return n_predict;
+}
+int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts, const int32_t *prompt_lens, int32_t n_seqs,
+                                     int32_t n_batch, int32_t n_predict, int32_t *out_ids, double *seconds_out) {
+    int rc = generate_greedy_batch_once(ctx, prompts, prompt_lens, n_seqs, n_batch, n_predict, out_ids, seconds_out);
+    if (rc < 0 && xpipe_retry(ctx, 0)) rc = generate_greedy_batch_once(ctx, prompts, prompt_lens, n_seqs, n_batch, n_predict, out_ids, seconds_out);
+    return rc;
 }
 
 // profiling builds (BIOGPT_HIP_PROFILE_HOOKS + BIOGPT_HIP_DBG=128): the raw 100 MHz stage stamps the pipelined launches left (kernels_xpipe.hip.h XP_WALL / XP_TAIL)

@@ -40,6 +40,11 @@ struct XcParams {
     const uint16_t *exp_tab, *gelu_tab;
     int32_t gelu_p, gelu_n, gelu_z;
     int32_t n_cols;            // 2 .. 8
+    // streams mode (seq != null; biogpt_hip_generate_greedy_batch with 2 .. 8 sequences): column c is the next token of sequence c -- its own position and token
+    // (SeqState), its own K / V cache (kroot / vroot + c * seq_stride), attention over its own n_past + 1 keys only: no exchange between the XCDs at all
+    const SeqState *seq;
+    float *kroot, *vroot;
+    int64_t seq_stride;        // floats between two sequences' caches ([n_layer][P][1024] each)
     float *x_out;              // [n_cols][1024] the last layer's output (input of the final LayerNorm + lm_head launch)
     unsigned long long *wall;  // profiling (BIOGPT_HIP_PROFILE_HOOKS): [n_layer][16] wall clock of workgroups 0 and 16 of column 0
 };
@@ -134,8 +139,12 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
     const uint16_t *const s_gelu = reinterpret_cast<const uint16_t *>(smem + XP_S_TOTAL);
-    const int N = p.n_cols;
-    const int n_old = p.st->n_past, T = n_old + N, pos = n_old + col;      // keys before this eval, keys of the eval (F1: every column sees all N new ones), this column's row
+    const bool streams = p.seq != nullptr;
+    // chunk: keys before this eval, keys of the eval (F1: every column sees all N new ones), this column's row; streams: the sequence's own position, one new key
+    const int n_old = streams ? p.seq[col].n_past : p.st->n_past;
+    const int n_new = streams ? 1 : p.n_cols, c_first = streams ? col : 0;      // whose new K / V rows this column attends to: columns c_first .. c_first + n_new - 1
+    const int T = n_old + n_new, pos = streams ? n_old : n_old + col;
+    const size_t kv_off = streams ? (size_t)col * (size_t)p.seq_stride : 0;
     const int t_cap = p.t_cap;
     const int head = slot & 15;
     xp_u64 *const Gcol = p.gran + (size_t)col * p.n_layer * XP_G_LAYER;
@@ -187,7 +196,8 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     // slice read as 0 (range-checked), streaming hint (nt)
     auto request_kv = [&](int L, int tid) __attribute__((always_inline)) {
         const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
-        const float *kb = p.layers[L].kcache + (size_t)head * p.P * DK, *vb = p.layers[L].vcache + (size_t)head * p.P * DK;
+        const float *kb = (streams ? p.kroot + kv_off + (size_t)L * p.P * 1024 : p.layers[L].kcache) + (size_t)head * p.P * DK;
+        const float *vb = (streams ? p.vroot + kv_off + (size_t)L * p.P * 1024 : p.layers[L].vcache) + (size_t)head * p.P * DK;
         const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
         constexpr int CPOL_NT = 2;
         const int ko = (kidx * DK + 4 * ksub) * 4, vo = (sl * DK + dd) * 4;
@@ -237,7 +247,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         auto layer_input = [&]() __attribute__((always_inline)) {
         if (L == 0) {
             if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[position + 2]
-                int tok = state_tokens(p.st)[col];
+                int tok = streams ? p.seq[col].token : state_tokens(p.st)[col];
                 if (tok < 0 || tok >= p.n_vocab) tok = 0;
                 float e[4];
                 if (p.tok_emb.type == WT && p.pos_emb.type == WT) {
@@ -290,7 +300,8 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                     xp_put_local(G + XP_G_QKV + head * 64 + d, epoch, __float_as_uint(v));
                 } else {
                     xp_put(G + XP_G_QKV + which * 1024 + head * 64 + d, epoch, __float_as_uint(v));      // write-through: the other columns' XCDs poll these
-                    float *cache = (which == 1) ? p.layers[L].kcache : p.layers[L].vcache;    // KV append (biogpt.cpp:721-727), head-major cache: for later evals
+                    float *cache = streams ? ((which == 1) ? p.kroot : p.vroot) + kv_off + (size_t)L * p.P * 1024
+                                           : ((which == 1) ? p.layers[L].kcache : p.layers[L].vcache);    // KV append (biogpt.cpp:721-727), head-major cache: for later evals
                     cache[((size_t)head * p.P + pos) * DK + d] = v;
                 }
             }
@@ -313,8 +324,8 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int h2 = 0; h2 < 4; h2++) {
                     const int idx = tid + 256 * h2, c = idx >> 7, e = idx & 127;
-                    ak[h2] = c < N;
-                    gk[h2] = p.gran + ((size_t)(ak[h2] ? c : col) * p.n_layer + L) * XP_G_LAYER + XP_G_QKV + 1024 * (1 + (e >> 6)) + head * 64 + (e & 63);
+                    ak[h2] = c < n_new;
+                    gk[h2] = p.gran + ((size_t)(ak[h2] ? c_first + c : col) * p.n_layer + L) * XP_G_LAYER + XP_G_QKV + 1024 * (1 + (e >> 6)) + head * 64 + (e & 63);
                 }
                 uint32_t vq = 0u, vk[4] = {0u, 0u, 0u, 0u};
                 for (uint32_t spins = 0;; spins++) {

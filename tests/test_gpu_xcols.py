@@ -157,3 +157,85 @@ def test_24_layers_prompt_in_chunks_of_8(pkg, oracle, tmp_path):
     print("24 layers: worst |diff| vs oracle %.2e" % worst)
     assert worst <= ATOL
     g.close()
+
+
+def test_two_contexts_take_turns_with_chunk_evals(pkg, files, monkeypatch):
+    """Two contexts of one process on one device alternate 8-token evals: the device's pipeline slot goes to whoever asks while the other's stream is idle
+    (csrc/engine_xpipe.inc); whichever path an eval takes, rows and K / V rows are those of the launch chain."""
+    monkeypatch.setenv("BIOGPT_HIP_XCOLS", "0")
+    ref = pkg.BiogptModel.load(files["q4_1"])
+    monkeypatch.delenv("BIOGPT_HIP_XCOLS")
+    a, b = pkg.BiogptModel.load(files["q4_1"]), pkg.BiogptModel.load(files["q4_1"])
+    if a.xpipe_state() < 0:
+        pytest.skip("XCD pipeline not available on this device")
+    rng = np.random.default_rng(71)
+    ta = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 63)]
+    tb = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 63)]
+    want_a, want_b = [], []
+    for at in range(0, 64, 8):
+        want_a.append(ref.eval(ta[at:at + 8], at).copy())
+    ka = _kv(ref, 0, 64)
+    for at in range(0, 64, 8):
+        want_b.append(ref.eval(tb[at:at + 8], at).copy())
+    kb = _kv(ref, 0, 64)
+    for k, at in enumerate(range(0, 64, 8)):
+        ra = a.eval(ta[at:at + 8], at)
+        if k % 2:
+            b.eval_device(tb[at:at + 8], at)          # left in flight while the other context asks for the slot
+            rb = None
+        else:
+            rb = b.eval(tb[at:at + 8], at)
+        assert (ra == want_a[k]).all(), k
+        if rb is not None:
+            assert (rb == want_b[k]).all(), k
+    b.synchronize()
+    for w in (0, 1):
+        assert (_kv(a, 0, 64)[w] == ka[w]).all() and (_kv(b, 0, 64)[w] == kb[w]).all()
+    assert a.chunk_launches() + b.chunk_launches() >= 8      # most evals found the slot free
+    assert a.xpipe_state() >= 0 and b.xpipe_state() >= 0
+    ref.close(); a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+def test_batched_generation_steps_as_column_per_xcd_launches(pkg, oracle, files, monkeypatch, name):
+    """biogpt_hip_generate_greedy_batch with 2 .. 8 sequences: every decode step is ONE launch with one sequence per XCD (streams mode of kernels_xcols.hip.h: own
+    position, own K / V cache, no exchange between the XCDs), replayed from a graph per context bucket.  Ragged prompts, contexts that cross the 64 / 128-key variants and
+    the 256-key border (beyond it the launch chain takes over inside the same call): ids equal the launch chain's (BIOGPT_HIP_XCOLS=0) and, sequence by sequence, the
+    oracle's single-sequence generation."""
+    rng = np.random.default_rng(73)
+    cases = [((4, 9, 17, 5, 8, 30, 2, 11), 70), ((60, 61, 7), 80), ((5, 5), 262), ((120,) * 8, 16)]
+    for lens, n_predict in cases:
+        prompts = [[2] + [int(v) for v in rng.integers(4, KW["n_vocab"], n - 1)] for n in lens]
+        g = pkg.BiogptModel.load(files[name])
+        if g.xpipe_state() != 1:
+            pytest.skip("XCD pipeline not available on this device")
+        ids_x, _ = g.generate_greedy_batch(prompts, n_predict, n_batch=8)
+        assert g.chunk_launches() > 0 and g.xpipe_state() == 1
+        g.close()
+        monkeypatch.setenv("BIOGPT_HIP_XCOLS", "0")
+        g = pkg.BiogptModel.load(files[name])
+        monkeypatch.delenv("BIOGPT_HIP_XCOLS")
+        ids_c, _ = g.generate_greedy_batch(prompts, n_predict, n_batch=8)
+        assert g.chunk_launches() == 0
+        g.close()
+        assert (np.asarray(ids_x) == np.asarray(ids_c)).all(), (name, lens)
+        for s in (0, len(lens) - 1):
+            ref, _ = oracle.OracleModel(files[name], n_threads=16).generate_greedy(prompts[s], min(n_predict, 24), n_batch=8)
+            assert list(np.asarray(ids_x)[s][:len(ref)]) == list(ref), (name, lens, s)
+
+
+def test_disturbed_batched_generation_is_repeated_on_the_launch_chain(pkg, files, monkeypatch, capfd):
+    ref = pkg.BiogptModel.load(files["q4_0"])
+    if ref.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompts = [[2, 10 + s, 200, 3000 + s] for s in range(6)]
+    want, _ = ref.generate_greedy_batch(prompts, 12, n_batch=8)
+    ref.close()
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["q4_0"])
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_FAULT")
+    got, _ = g.generate_greedy_batch(prompts, 12, n_batch=8)
+    assert (np.asarray(got) == np.asarray(want)).all()
+    assert g.xpipe_state() == -1
+    assert "pipelined decode step failed" in capfd.readouterr().err
+    g.close()
