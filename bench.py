@@ -430,7 +430,7 @@ def main():
             out["xpipe_state"] = model.xpipe_state()   # 1: the pipelined launches are in use (a hand-off time-out or a disturbed launch would have left -1 and the five-launch layer)
             multi = os.environ.get("BIOGPT_HIP_XPIPE_MULTI", "1") != "0"
             out["decode_path"] = (("xcd-pipeline: layers + lm_head + greedy sampler in ONE persistent launch per context bucket (64 / 128 / 192 / 256 keys: a head's K / V rows in its workgroup's "
-                                   "registers; 512 / 1024 keys: every head's keys spread over 16 helper workgroups of XCD head / 2, csrc/kernels_xlong.hip.h)" if multi else
+                                   "registers; 257 .. 512 keys: two workgroups per head; 513 .. 1024 keys: every head's keys spread over 16 helper workgroups of XCD head / 2, csrc/kernels_xlong.hip.h)" if multi else
                                    "xcd-pipeline: layers + lm_head in ONE persistent launch per token") if model.xpipe_state() == 1 else "five launches per layer + lm_head")
             # batched multi-sequence decode on this one GPU (biogpt_hip_generate_greedy_batch): S independent
             # 200-token continuations decoded together, weights read once per step for all S -- NOT the headline
@@ -446,6 +446,8 @@ def main():
                     run_bytes = sum(w_bytes + S * (pkg.decode_bytes_per_token(hp, 4 + k) - w_bytes) for k in range(1, n_predict + 1))
                     ms["S=%d" % S] = {"tokens_per_s": round(S * n_predict / secs_b, 1), "ms_per_step_all_seqs": round(secs_b / n_predict * 1e3, 4),
                                       "GBps": round(run_bytes / secs_b / 1e9, 1), "frac_of_peak": round(run_bytes / secs_b / 1e9 / HBM_PEAK_GBS, 4)}
+                ms["note"] = ("S = 8: every decode step is ONE launch with one sequence per XCD (csrc/kernels_xcols.hip.h, streams mode; each XCD streams all weights: the algorithmic bytes "
+                              "of GBps count them once); S >= 32: the launch chain, from 48 sequences on the int8 matrix cores")
                 out["multi_stream"] = ms
             # prompt ingestion (configs[2] in short): a 512-token prompt with -b 8 semantics through biogpt_hip_eval_prompt
             rngp = np.random.default_rng(7000)
