@@ -486,7 +486,7 @@ def main():
                                              "chunk_launches_per_32_evals": int(per_loop),
                                              "tokens_per_s_512_token_prompt": round(512 / t512, 1), "ms_per_eval_257_512_keys": round((t512 - t256) / 32 * 1e3, 3),
                                              "note": "biogpt_hip_eval per 8-token chunk from Python (ctypes), rows copied to the host; 0 .. 256 keys: the column-per-XCD launch "
-                                                     "(every XCD streams all weights: bound by what one XCD pulls from the fabric, ~ 0.42 TB/s; profiles/xcols_timeline_r4.txt), "
+                                                     "(every XCD streams all weights: 16.7 us per layer against 9.8 us of pure weight stream and ~ 11 us of dependent chain, DESIGN 4.1f; profiles/xcols_timeline_r4.txt), "
                                                      "257 .. 512 keys: the launch chain (round 3: 0.86 ms per eval at every context)"}
             except Exception as e:
                 out["prompt_chunk_evals"] = {"error": str(e)[:300]}
