@@ -239,3 +239,35 @@ def test_disturbed_batched_generation_is_repeated_on_the_launch_chain(pkg, files
     assert g.xpipe_state() == -1
     assert "pipelined decode step failed" in capfd.readouterr().err
     g.close()
+
+
+def test_chunk_launch_with_a_short_position_table(pkg, oracle, tmp_path, monkeypatch):
+    """n_positions = 100 (biogpt.h:25-35 allows any >= the context): the 128-key variant runs with its loads bounded by the table's end (range-checked buffer loads
+    for the K / V rows), 2 layers, a small vocabulary; chunks up to the last position; rows and K / V rows against the chain and the oracle."""
+    kw = dict(KW, n_layer=2, n_positions=100, n_vocab=5000, n_merges=100)
+    f32, q = str(tmp_path / "f32.bin"), str(tmp_path / "q5_0.bin")
+    pkg.write_synthetic(f32, seed=100, **kw)
+    pkg.quantize_file(f32, q, "q5_0")
+    g = pkg.BiogptModel.load(q)
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    o = oracle.OracleModel(q, n_threads=16)
+    rng = np.random.default_rng(72)
+    toks = [2] + [int(v) for v in rng.integers(4, kw["n_vocab"], 99)]
+    n_past = 0
+    for n in (8, 8, 8, 8, 8, 8, 8, 8, 6, 8, 8, 7, 7):
+        chunk = toks[n_past:n_past + n]
+        _opts(g, monkeypatch, BIOGPT_HIP_XCOLS="1")
+        before = g.chunk_launches()
+        lx = g.eval(chunk, n_past)
+        assert g.chunk_launches() == before + 1 and g.xpipe_state() == 1
+        kx = [g.read_kv(w, (kw["n_positions"] + n_past) * kw["d_model"], n * kw["d_model"]) for w in (0, 1)]
+        _opts(g, monkeypatch, BIOGPT_HIP_XCOLS="0")
+        lc = g.eval(chunk, n_past)
+        kc = [g.read_kv(w, (kw["n_positions"] + n_past) * kw["d_model"], n * kw["d_model"]) for w in (0, 1)]
+        lo = o.eval(chunk, n_past)
+        assert (lx == lc).all() and (kx[0] == kc[0]).all() and (kx[1] == kc[1]).all(), n_past
+        assert np.abs(lx - lo).max() <= ATOL and int(lx.argmax()) == int(lo.argmax())
+        n_past += n
+    assert n_past == 100
+    g.close()
