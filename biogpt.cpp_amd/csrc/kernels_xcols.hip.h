@@ -95,6 +95,12 @@ __device__ __forceinline__ void xc_load_unit(Unit<WT> &u, const DevMatrix &W, in
     load_unit<WT>(u, W, idx);
 #endif
 }
+// XC_PW: how many waves of a workgroup poll (all sweeps are theirs): 4 = waves 0 .. 3 (each LayerNorm worker takes its own 4 elements in), 1 = wave 0 alone (16 .. 20
+// granules per lane, the values go through LDS to the LayerNorm workers).  With 1 and XC_FREE_WAVES = 7 only wave 0 -- an eighth of the workgroup's bytes -- keeps the
+// burst discipline, waves 1 .. 7 stream freely: tools/microbench21.hip measures what a hand-off costs beside streaming waves (0.46 - 0.57 us one way against 0.24 idle)
+#ifndef XC_PW
+#define XC_PW 4
+#endif
 // XC_FREE_WAVES: waves 4 .. 7 never poll (every sweep is waves 0 .. 3's), so nothing of theirs waits behind their loads: they re-request a stage's units for the
 // next layer right behind the use -- a continuous stream over the whole layer -- and only waves 0 .. 3 keep the burst discipline described in xc_run
 #ifndef XC_FREE_WAVES
@@ -116,6 +122,8 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     constexpr bool LATE_W2 = ATTN && KCAP > 128;
     // bits of XC_FREE_WAVES: 1 the q / k / v workgroups (every unit), 2 the attention workgroups' fc1 / fc2 units, 4 their out_proj units and K / V rows
     // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
+    constexpr int PW = XC_PW;      // polling waves
+    static_assert(PW == 1 || PW == 4, "polling waves");
     constexpr bool FREE = (XC_FREE_WAVES & 1) != 0 && !ATTN;
     constexpr bool FREE_F = (XC_FREE_WAVES & 2) != 0 && ATTN && !LATE_W2;
     constexpr bool FREE_O = (XC_FREE_WAVES & 4) != 0 && ATTN;
@@ -227,7 +235,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         request_small(0, tid);
         if constexpr (!ATTN) {
             request_qkv(0, tid);      // (waves 0 .. 3: the other units in layer 0's burst)
-            if (FREE && tid >= 256) { request_wo(0, tid); request_w1(0, tid); request_w2(0, tid); }
+            if (FREE && tid >= 64 * PW) { request_wo(0, tid); request_w1(0, tid); request_w2(0, tid); }
         } else {
             request_wo(0, tid);
             if constexpr (!LATE_W2) { request_w1(0, tid); request_w2(0, tid); }
@@ -275,6 +283,16 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         auto layer_input = [&]() __attribute__((always_inline)) {
         if (L == 0) {
             if (worker) xv = reinterpret_cast<const float4 *>(s_x)[tid];      // the embedding: computed in front of the loop (this thread's own LDS write)
+        } else if constexpr (PW == 1) {
+            if (wave == 0) {      // granule lane + 64 k holds element 4 (g & 255) + (g >> 8) (xp_col_slot)
+                uint32_t v[16];
+                xc_sweep<16, 64>(G - XP_G_LAYER + XP_G_X + lane, true, epoch, v, p);
+#pragma unroll
+                for (int k = 0; k < 16; k++) s_x[4 * ((lane + 64 * k) & 255) + ((lane + 64 * k) >> 8)] = __uint_as_float(v[k]);
+            }
+            __syncthreads();
+            if (worker) xv = reinterpret_cast<const float4 *>(s_x)[tid];
+            return;
         } else if (wave < 4) {
             uint32_t v[4];
             xc_sweep<4, 256>(G - XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
@@ -297,7 +315,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * QS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if (FREE && wave >= 4 && more) request_qkv(L + 1, tid);
+            if (FREE && wave >= PW && more) request_qkv(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -317,7 +335,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             }
             XC_WALL(1);
             // the burst: this layer's other units in the order of their use, then the next layer's q / k / v units and small vectors -- the attention takes microseconds
-            if (!FREE || wave < 4) {
+            if (!FREE || wave < PW) {
                 request_wo(L, tid); request_w1(L, tid); request_w2(L, tid);
                 if (more) request_qkv(L + 1, tid);
             }
@@ -326,23 +344,26 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             // ================= stage B (workgroups 0-15): attention of head `head`, query = this column (biogpt.cpp:729-764, no mask inside the eval: F1) =================
             const int ksub = tid & (LPK - 1), kidx = tid / LPK;
             const int dd = tid & (DK - 1), sl = tid >> 6;
-            if (wave < 4) {   // this column's q row (own XCD) and the k / v rows of ALL columns (their XCDs): up to 64 + 1024 granules, at most five per lane, in ONE poll loop
+            if (wave < PW) {   // this column's q row (own XCD) and the k / v rows of ALL columns (their XCDs): up to 64 + 1024 granules, at most five per lane, in ONE poll loop
                 const xp_u64 *gq = G + XP_G_QKV + head * 64 + (tid & 63);
                 const bool aq = tid < 64;
-                const xp_u64 *gk[4];
-                bool ak[4];
+                constexpr int NKV = 16 / PW;
+                const xp_u64 *gk[NKV];
+                bool ak[NKV];
 #pragma unroll
-                for (int h2 = 0; h2 < 4; h2++) {
-                    const int idx = tid + 256 * h2, c = idx >> 7, e = idx & 127;
+                for (int h2 = 0; h2 < NKV; h2++) {
+                    const int idx = tid + 64 * PW * h2, c = idx >> 7, e = idx & 127;
                     ak[h2] = c < n_new;
                     gk[h2] = p.gran + ((size_t)(ak[h2] ? c_first + c : col) * p.n_layer + L) * XP_G_LAYER + XP_G_QKV + 1024 * (1 + (e >> 6)) + head * 64 + (e & 63);
                 }
-                uint32_t vq = 0u, vk[4] = {0u, 0u, 0u, 0u};
+                uint32_t vq = 0u, vk[NKV];
+#pragma unroll
+                for (int h2 = 0; h2 < NKV; h2++) vk[h2] = 0u;
                 for (uint32_t spins = 0;; spins++) {
                     bool ok = true;
                     if (aq) { const xp_u64 x = __hip_atomic_load(gq, XP_RLX); vq = (uint32_t)x; ok &= (uint32_t)(x >> 32) == epoch; }
 #pragma unroll
-                    for (int h2 = 0; h2 < 4; h2++)
+                    for (int h2 = 0; h2 < NKV; h2++)
                         if (ak[h2]) { const xp_u64 x = __hip_atomic_load(gk[h2], XP_RLX); vk[h2] = (uint32_t)x; ok &= (uint32_t)(x >> 32) == epoch; }
                     if (__all(ok)) break;
                     if (spins >= XP_SPIN_MAX) { if (lane == 0) xc_fail(p, 1u); break; }
@@ -350,7 +371,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                 }
                 if (aq) s_cur[tid] = __uint_as_float(vq);
 #pragma unroll
-                for (int h2 = 0; h2 < 4; h2++) if (ak[h2]) s_new[tid + 256 * h2] = __uint_as_float(vk[h2]);
+                for (int h2 = 0; h2 < NKV; h2++) if (ak[h2]) s_new[tid + 64 * PW * h2] = __uint_as_float(vk[h2]);
             }
             __syncthreads();
             XC_WALL(7);
@@ -421,7 +442,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                 }
                 s_pv[tid] = a0 + a1;
             }
-            if (FREE_O && wave >= 4 && more) request_kv(L + 1, tid);
+            if (FREE_O && wave >= PW && more) request_kv(L + 1, tid);
             __syncthreads();
             XC_WALL(15);
             if (tid < DK) {
@@ -441,6 +462,16 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(2);
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if constexpr (LATE_W2) { request_w1(L, tid); request_w2(L, tid); }
+        if constexpr (PW == 1) {
+            if (wave == 0) {      // 256 + 32 + 32 granules, five per lane
+                uint32_t v[5];
+                xc_sweep<5, 64>(G + XP_G_ATT + lane, true, epoch, v, p);
+#pragma unroll
+                for (int k = 0; k < 4; k++) s_xq[lane + 64 * k] = v[k];
+                if (lane < 32) s_xd[lane] = __uint_as_float(v[4]);
+                else s_xs[lane - 32] = v[4];
+            }
+        } else
         if (wave < 4) {      // 256 + 32 + 32 granules: two per lane in wave 0, one elsewhere
             uint32_t v[1], w[1] = {0u};
             if (wave == 0) {
@@ -470,7 +501,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * OS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if ((FREE || FREE_O) && wave >= 4 && more) request_wo(L + 1, tid);
+            if ((FREE || FREE_O) && wave >= PW && more) request_wo(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -483,6 +514,20 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(3);
         // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
+        if constexpr (PW == 1) {
+            if (wave == 0) {
+                uint32_t v[16];
+                xc_sweep<16, 64>(G + XP_G_X1 + lane, true, epoch, v, p);
+#pragma unroll
+                for (int k = 0; k < 16; k++) s_x1[4 * ((lane + 64 * k) & 255) + ((lane + 64 * k) >> 8)] = __uint_as_float(v[k]);
+            }
+            __syncthreads();
+            if (worker) {
+                x1v = reinterpret_cast<const float4 *>(s_x1)[tid];
+                XC_WALL(9);
+                lnw = reinterpret_cast<const float4 *>(s_ln + 2048)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 3072)[tid];
+            }
+        } else
         if (wave < 4) {
             uint32_t v[4];
             xc_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
@@ -502,7 +547,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * FS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if ((FREE || FREE_F) && wave >= 4 && more) request_w1(L + 1, tid);
+            if ((FREE || FREE_F) && wave >= PW && more) request_w1(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -531,6 +576,16 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         }
         XC_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
+        if constexpr (PW == 1) {
+            if (wave == 0) {   // 1024 + 128 + 128 granules in ONE poll loop, twenty per lane
+                uint32_t v[20];
+                xc_sweep<20, 64>(G + XP_G_H + lane, true, epoch, v, p);
+#pragma unroll
+                for (int k = 0; k < 16; k++) s_hq[lane + 64 * k] = v[k];
+                s_hd[lane] = __uint_as_float(v[16]); s_hd[lane + 64] = __uint_as_float(v[17]);
+                s_hs[lane] = v[18]; s_hs[lane + 64] = v[19];
+            }
+        } else
         if (wave < 4) {   // 1024 + 128 + 128 granules in ONE poll loop, five per lane: every pass has all of a lane's loads in flight together
             uint32_t v[5];
             const xp_u64 *g = G + XP_G_H + tid;
@@ -555,7 +610,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = unit_dot_quant<WT>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
             }
-            if ((FREE || FREE_F) && wave >= 4 && more) request_w2(L + 1, tid);
+            if ((FREE || FREE_F) && wave >= PW && more) request_w2(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -582,9 +637,9 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(5);
         if constexpr (ATTN) {      // the burst of the attention workgroups: the next layer's units in the order of their use, the head's old keys / values, the small vectors
             if (more) {
-                if (!FREE_O || wave < 4) request_wo(L + 1, tid);
-                if constexpr (!LATE_W2) { if (!FREE_F || wave < 4) { request_w1(L + 1, tid); request_w2(L + 1, tid); } }
-                if (!FREE_O || wave < 4) request_kv(L + 1, tid);
+                if (!FREE_O || wave < PW) request_wo(L + 1, tid);
+                if constexpr (!LATE_W2) { if (!FREE_F || wave < PW) { request_w1(L + 1, tid); request_w2(L + 1, tid); } }
+                if (!FREE_O || wave < PW) request_kv(L + 1, tid);
                 request_small(L + 1, tid);
             }
         }
