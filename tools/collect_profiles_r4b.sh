@@ -33,4 +33,8 @@ timeout 200 python tools/api_loop_modes.py > $OUT/api_loop_modes_r4b.txt 2>&1 < 
 timeout 200 python tools/api_loop_long.py 300 200 > $OUT/api_loop_long_r4b.txt 2>&1; timeout 200 python tools/api_loop_long.py 700 200 >> $OUT/api_loop_long_r4b.txt 2>&1
 bash tools/ref_cli_timing.sh > $OUT/ref_cli_timing_r4b.txt 2>&1
 timeout 400 python tools/soak_r3.py 150 > $OUT/soak_r4b.txt 2>&1
+timeout 300 python tools/dbg_streams.py 2>&1 | grep -v loading > $OUT/xcols_streams_r4b.txt
+for b in 20 21; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/microbench$b tools/microbench$b.hip 2> /dev/null; done
+timeout 100 ./tools/microbench20 > $OUT/microbench20_xcd_stream_r4b.txt 2>&1
+timeout 100 ./tools/microbench21 > $OUT/microbench21_handoff_beside_stream_r4b.txt 2>&1
 ls -la $OUT
