@@ -858,7 +858,7 @@ extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes);
 bool xcols_prepare(biogpt_hip_ctx *c, int N, int t_max) {
     const int32_t wt = ftype_to_type(c->hp.ftype);
     if (!c->opt.xcols || c->opt.causal || N < 2 || N > 8 || t_max > 256 || c->xc_lds < 0) return false;
-    if (!(wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1)) return false;      // Q8_0: 30 units x 9 registers per lane do not fit
+    if (!(wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1 || wt == T_Q8_0)) return false;
     if (!fused_decode_ok(c, t_max) || c->xp_state != 1) return false;
     if (c->xc_gran && c->xc_lds == 1) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

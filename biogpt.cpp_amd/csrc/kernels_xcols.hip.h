@@ -18,7 +18,7 @@
 // tickets and leave.  Workgroups 16 .. 31 of an XCD: LayerNorm -> Q8 -> the 192 q / k / v rows of head slot - 16 (+ KV append at row n_past + column);
 // workgroups 0 .. 15: attention of head `slot` over the n_past old keys (registers, requested a layer ahead) and the N new ones (LDS); all 32: out_proj rows,
 // LayerNorm + fc1 + GELU, fc2 rows.  The final LayerNorm + lm_head of the LAST column (F8) is the ordinary stand-alone launch behind this one.
-// Contexts up to 256 keys (n_past + N <= 256), the four nibble formats (Q8_0: 30 units x 9 registers do not fit).
+// Contexts up to 256 keys (n_past + N <= 256), all five block formats (Q8_0 with its q / k / v units requested late: 9 registers per unit).
 #pragma once
 
 #include "kernels_xpipe.hip.h"
@@ -109,7 +109,10 @@ __device__ __forceinline__ void xc_load_unit(Unit<WT> &u, const DevMatrix &W, in
 template <int WT, int LPK, int KCAP, int ROLE>
 __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, const int col, const int slot, const uint32_t epoch) {
     using TI = TypeInfo<WT>;
-    static_assert(WT == W_Q4_0 || WT == W_Q4_1 || WT == W_Q5_0 || WT == W_Q5_1, "nibble formats: 30 packed units per lane");
+    static_assert(TI::quant, "block-quantized weights");
+    // Q8_0 units are 9 registers: the q / k / v workgroups' 30 units do not fit at once -- their 12 q / k / v units of the NEXT layer are requested at the end of the layer
+    // (when out_proj / fc1 / fc2 units are dead) instead of in the burst; that request sits in front of the next layer's input poll (exposed: ~ 3 us per layer)
+    constexpr bool QKV_LATE = WT == W_Q8_0;
     static_assert(ROLE == 0 || ROLE == 1, "0 attention head, 1 q/k/v rows");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8, "lanes per key");
     constexpr bool ATTN = ROLE == 0;
@@ -117,9 +120,13 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;
     static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
     constexpr int NF4 = 16 / LPK, NV = KCAP / NW;
-    // 256-key variant, attention workgroups: 64 K / V registers + 18 packed units + the dots' temporaries spill 28 .. 47 VGPRs; there the fc1 / fc2 units are requested when
-    // the attention is done (one / two stages ahead of their use: the poll in between waits for them) and the head's K / V rows and those 16 units never wait together
-    constexpr bool LATE_W2 = ATTN && KCAP > 128;
+    // 256-key variant (Q8_0, 9 registers per unit: beyond 64 keys), attention workgroups: the head's K / V rows + 18 units + the dots' temporaries do not fit; there the fc1 /
+    // fc2 units are requested when the attention is done (one / two stages ahead of their use: the poll in between waits for them) and never wait beside the K / V rows.
+    // UNCOND (Q8_0): the end-of-layer requests are unconditional (the last layer asks for its own units once more): a request under `if (more)` keeps the OLD registers alive
+    // through the whole layer -- 151 spilled VGPRs in the q / k / v workgroups.  For the nibble formats it is the other way round: measured, everything unconditional and no
+    // late requests at all (161 - 252 VGPRs, no spills either) is 7 % slower (0.540 against 0.505 ms per 8-token eval): bigger bursts in front of the long poll.
+    constexpr bool UNCOND = WT == W_Q8_0;
+    constexpr bool LATE_W2 = ATTN && (KCAP > 128 || (WT == W_Q8_0 && KCAP > 64));
     // bits of XC_FREE_WAVES: 1 the q / k / v workgroups (every unit), 2 the attention workgroups' fc1 / fc2 units, 4 their out_proj units and K / V rows
     // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
     constexpr int PW = XC_PW;      // polling waves
@@ -315,7 +322,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * QS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if (FREE && wave >= PW && more) request_qkv(L + 1, tid);
+            if (FREE && !QKV_LATE && wave >= PW && more) request_qkv(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -337,7 +344,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             // the burst: this layer's other units in the order of their use, then the next layer's q / k / v units and small vectors -- the attention takes microseconds
             if (!FREE || wave < PW) {
                 request_wo(L, tid); request_w1(L, tid); request_w2(L, tid);
-                if (more) request_qkv(L + 1, tid);
+                if (more && !QKV_LATE) request_qkv(L + 1, tid);
             }
             if (more) request_small(L + 1, tid);
         } else {
@@ -635,12 +642,14 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             }
         }
         XC_WALL(5);
+        if constexpr (!ATTN && QKV_LATE) request_qkv(more ? L + 1 : L, tid);      // (unconditional: a conditional request would keep the old units alive through the whole layer)
         if constexpr (ATTN) {      // the burst of the attention workgroups: the next layer's units in the order of their use, the head's old keys / values, the small vectors
-            if (more) {
-                if (!FREE_O || wave < PW) request_wo(L + 1, tid);
-                if constexpr (!LATE_W2) { if (!FREE_F || wave < PW) { request_w1(L + 1, tid); request_w2(L + 1, tid); } }
-                if (!FREE_O || wave < PW) request_kv(L + 1, tid);
-                request_small(L + 1, tid);
+            if (more || UNCOND) {
+                const int Ln = more ? L + 1 : L;
+                if (!FREE_O || wave < PW) request_wo(Ln, tid);
+                if constexpr (!LATE_W2) { if (!FREE_F || wave < PW) { request_w1(Ln, tid); request_w2(Ln, tid); } }
+                if (!FREE_O || wave < PW) request_kv(Ln, tid);
+                if (more) request_small(L + 1, tid);
             }
         }
         __syncthreads();       // s_ln / s_bias / s_x / s_x1 / s_part are rewritten by the next layer

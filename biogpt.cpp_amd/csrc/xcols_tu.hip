@@ -1,4 +1,4 @@
-// Translation unit of the column-per-XCD chunk launches (kernels_xcols.hip.h: biogpt_eval with 2 .. 8 tokens as one persistent launch): 4 nibble formats x 3 context
+// Translation unit of the column-per-XCD chunk launches (kernels_xcols.hip.h: biogpt_eval with 2 .. 8 tokens as one persistent launch): 5 block formats x 3 context
 // variants (<= 64 / 128 / 256 keys).  Same arrangement as xpipe_tu.hip: own namespace name for the headers' non-inline kernels, the parameter block crosses as bytes.
 #define bgk bgk_xc
 #include <hip/hip_runtime.h>
@@ -32,7 +32,7 @@ hipError_t set_lds_t(size_t sm) {
 
 }  // namespace
 
-// wt: the kernels' WType value (2, 3, 6, 7); params: a bgk::XcParams
+// wt: the kernels' WType value (2, 3, 6, 7, 8); params: a bgk::XcParams
 extern "C" int bg_xcols_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes) {
     if (!params || params_bytes != sizeof(bgk::XcParams)) return (int)hipErrorInvalidValue;
     const bgk::XcParams &xc = *static_cast<const bgk::XcParams *>(params);
@@ -42,6 +42,7 @@ extern "C" int bg_xcols_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t
         case bgk::W_Q4_1: return (int)launch_t<bgk::W_Q4_1>(t_cap, smem_bytes, st, xc);
         case bgk::W_Q5_0: return (int)launch_t<bgk::W_Q5_0>(t_cap, smem_bytes, st, xc);
         case bgk::W_Q5_1: return (int)launch_t<bgk::W_Q5_1>(t_cap, smem_bytes, st, xc);
+        case bgk::W_Q8_0: return (int)launch_t<bgk::W_Q8_0>(t_cap, smem_bytes, st, xc);
 #endif
         default: return (int)hipErrorInvalidValue;
     }
@@ -55,6 +56,7 @@ extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes) {
         case bgk::W_Q4_1: return (int)set_lds_t<bgk::W_Q4_1>(smem_bytes);
         case bgk::W_Q5_0: return (int)set_lds_t<bgk::W_Q5_0>(smem_bytes);
         case bgk::W_Q5_1: return (int)set_lds_t<bgk::W_Q5_1>(smem_bytes);
+        case bgk::W_Q8_0: return (int)set_lds_t<bgk::W_Q8_0>(smem_bytes);
 #endif
         default: return (int)hipErrorInvalidValue;
     }

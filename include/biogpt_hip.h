@@ -156,8 +156,8 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
  * running, calls that named a different token than the running pass, current run of matching calls, matches needed}. */
 int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4);
 
-/* biogpt_eval with 2 .. 8 tokens -- the chunks of the reference's prompt loop (main.cpp:129-137, n_batch = 8) -- of a BioGPT-base-shaped Q4_0 / Q4_1 / Q5_0 /
- * Q5_1 model at up to 256 keys runs as ONE persistent launch with one column per XCD (csrc/kernels_xcols.hip.h; BIOGPT_HIP_XCOLS=0: the launch chain of
+/* biogpt_eval with 2 .. 8 tokens -- the chunks of the reference's prompt loop (main.cpp:129-137, n_batch = 8) -- of a BioGPT-base-shaped block-quantized
+ * (Q4_0 .. Q8_0) model at up to 256 keys runs as ONE persistent launch with one column per XCD (csrc/kernels_xcols.hip.h; BIOGPT_HIP_XCOLS=0: the launch chain of
  * kernels_fast.hip.h; same results bit for bit).  biogpt_hip_generate_greedy_batch with 2 .. 8 sequences runs its decode steps through the same kernel (one sequence per
  * XCD, its own K / V cache: no exchange between XCDs) while contexts stay within 256 keys.  Returns how many such launches this context has enqueued or captured (evals;
  * batched generation: one per captured context bucket + the first step) (-1: null context). */

@@ -1,7 +1,7 @@
 """biogpt_eval with 2 .. 8 tokens -- the chunks of the reference's prompt loop (main.cpp:129-137; no mask inside an eval, F1; biogpt.cpp:664-811) -- through the
 column-per-XCD persistent launch (csrc/kernels_xcols.hip.h) against (a) the launch chain it replaces (BIOGPT_HIP_XCOLS=0) bit for bit, logits and appended
-K / V rows, and (b) the oracle within the contract; all four nibble formats, chunk sizes 2 .. 8, every context variant (<= 64 / 128 / 256 keys) and the border
-where the chain takes over (n_past + N > 256); Q8_0 keeps the chain; the full 24-layer model; a disturbed launch."""
+K / V rows, and (b) the oracle within the contract; all five block formats, chunk sizes 2 .. 8, every context variant (<= 64 / 128 / 256 keys) and the border
+where the chain takes over (n_past + N > 256); float files keep the chain; the full 24-layer model; a disturbed launch."""
 import numpy as np
 import pytest
 
@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-3
 KW = dict(n_vocab=42384, n_layer=3, n_head=16, n_positions=1024, d_ff=4096, d_model=1024, n_merges=40000)
 NIBBLE = ["q4_0", "q4_1", "q5_0", "q5_1"]
+BLOCK = NIBBLE + ["q8_0"]
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +19,7 @@ def files(pkg, tmp_path_factory):
     f32 = str(d / "f32.bin")
     pkg.write_synthetic(f32, seed=77, **KW)
     out = {"f32": f32}
-    for name in NIBBLE + ["q8_0"]:
+    for name in BLOCK:
         out[name] = str(d / (name + ".bin"))
         pkg.quantize_file(f32, out[name], name)
     return out
@@ -37,7 +38,7 @@ def _kv(g, n_past, n):
     return [g.read_kv(w, (last + n_past) * KW["d_model"], n * KW["d_model"]) for w in (0, 1)]
 
 
-@pytest.mark.parametrize("name", NIBBLE)
+@pytest.mark.parametrize("name", BLOCK)
 def test_chunk_launch_equals_the_launch_chain_and_the_oracle(pkg, oracle, files, monkeypatch, name):
     g = pkg.BiogptModel.load(files[name])
     if g.xpipe_state() != 1:
@@ -76,10 +77,10 @@ def test_chunk_launch_equals_the_launch_chain_and_the_oracle(pkg, oracle, files,
     g.close()
 
 
-def test_q8_0_chunks_keep_the_launch_chain(pkg, oracle, files):
-    """30 weight units of 9 registers per lane do not fit: Q8_0 evals of 2 .. 8 tokens stay on the chain (and are still right)."""
-    g = pkg.BiogptModel.load(files["q8_0"])
-    o = oracle.OracleModel(files["q8_0"], n_threads=16)
+def test_float_files_keep_the_launch_chain(pkg, oracle, files):
+    """F32 / F16 files (biogpt.cpp:160-165) have no pipelined launches: their evals of 2 .. 8 tokens stay on the generic chain (and are still right)."""
+    g = pkg.BiogptModel.load(files["f32"])
+    o = oracle.OracleModel(files["f32"], n_threads=16)
     chunk = [2, 100, 2000, 37, 4000, 5, 77, 901]
     lg, lo = g.eval(chunk, 0), o.eval(chunk, 0)
     assert g.chunk_launches() == 0
@@ -196,7 +197,7 @@ def test_two_contexts_take_turns_with_chunk_evals(pkg, files, monkeypatch):
     ref.close(); a.close(); b.close()
 
 
-@pytest.mark.parametrize("name", ["q4_0", "q5_1"])
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
 def test_batched_generation_steps_as_column_per_xcd_launches(pkg, oracle, files, monkeypatch, name):
     """biogpt_hip_generate_greedy_batch with 2 .. 8 sequences: every decode step is ONE launch with one sequence per XCD (streams mode of kernels_xcols.hip.h: own
     position, own K / V cache, no exchange between the XCDs), replayed from a graph per context bucket.  Ragged prompts, contexts that cross the 64 / 128-key variants and
