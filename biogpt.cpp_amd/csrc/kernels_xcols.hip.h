@@ -18,7 +18,7 @@
 // tickets and leave.  Workgroups 16 .. 31 of an XCD: LayerNorm -> Q8 -> the 192 q / k / v rows of head slot - 16 (+ KV append at row n_past + column);
 // workgroups 0 .. 15: attention of head `slot` over the n_past old keys (registers, requested a layer ahead) and the N new ones (LDS); all 32: out_proj rows,
 // LayerNorm + fc1 + GELU, fc2 rows.  The final LayerNorm + lm_head of the LAST column (F8) is the ordinary stand-alone launch behind this one.
-// Contexts up to 256 keys (n_past + N <= 256), all five block formats (Q8_0 with its q / k / v units requested late: 9 registers per unit).
+// Contexts up to 256 keys (n_past + N <= 256; the one-lane-per-key path for 257 .. 512 keys -- LPK = 1, KCAP = 512 -- is slower than the launch chain there and not instantiated), all five block formats (Q8_0 with its q / k / v units requested late: 9 registers per unit).
 #pragma once
 
 #include "kernels_xpipe.hip.h"
@@ -114,7 +114,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     // (when out_proj / fc1 / fc2 units are dead) instead of in the burst; that request sits in front of the next layer's input poll (exposed: ~ 3 us per layer)
     constexpr bool QKV_LATE = WT == W_Q8_0;
     static_assert(ROLE == 0 || ROLE == 1, "0 attention head, 1 q/k/v rows");
-    static_assert(LPK == 2 || LPK == 4 || LPK == 8, "lanes per key");
+    static_assert(LPK == 1 || LPK == 2 || LPK == 4 || LPK == 8, "lanes per key");
     constexpr bool ATTN = ROLE == 0;
     constexpr int NW = 8, NT = 512, DK = 64;
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     // UNCOND (Q8_0): the end-of-layer requests are unconditional (the last layer asks for its own units once more): a request under `if (more)` keeps the OLD registers alive
     // through the whole layer -- 151 spilled VGPRs in the q / k / v workgroups.  For the nibble formats it is the other way round: measured, everything unconditional and no
     // late requests at all (161 - 252 VGPRs, no spills either) is 7 % slower (0.540 against 0.505 ms per 8-token eval): bigger bursts in front of the long poll.
-    constexpr bool UNCOND = WT == W_Q8_0;
+    constexpr bool UNCOND = WT == W_Q8_0 || KCAP > 256;      // (512-key variant: 128 K / V registers must not stay alive through the layer)
     constexpr bool LATE_W2 = ATTN && (KCAP > 128 || (WT == W_Q8_0 && KCAP > 64));
     // bits of XC_FREE_WAVES: 1 the q / k / v workgroups (every unit), 2 the attention workgroups' fc1 / fc2 units, 4 their out_proj units and K / V rows
     // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
@@ -149,7 +149,8 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     float *const s_ln = reinterpret_cast<float *>(smem + XP_S_LN);
     float *const s_bias = reinterpret_cast<float *>(smem + XP_S_BIAS);
     float *const s_cur = reinterpret_cast<float *>(smem + XP_S_CUR);
-    float *const s_S = reinterpret_cast<float *>(smem + XP_S_S);
+    // [KCAP] softmax numerators; the 512-key variant's do not fit XP_S_S (256 floats): behind s_new in the block-term region, which no dot stage uses during the attention
+    float *const s_S = KCAP > 256 ? reinterpret_cast<float *>(smem + XP_S_PART) + 1024 : reinterpret_cast<float *>(smem + XP_S_S);
     float *const s_redf = reinterpret_cast<float *>(smem + XP_S_REDF);
     double *const s_redd = reinterpret_cast<double *>(smem + XP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + XP_S_PV);
@@ -397,7 +398,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                         a2 += (double)__fmul_rn(kr[m].z, qm.z); a3 += (double)__fmul_rn(kr[m].w, qm.w);
                     }
                     double acc = (a0 + a1) + (a2 + a3);
-                    acc += dpp_d<DPP_QUAD_XOR1>(acc);
+                    if (LPK >= 2) acc += dpp_d<DPP_QUAD_XOR1>(acc);
                     if (LPK >= 4) acc += dpp_d<DPP_QUAD_XOR2>(acc);
                     if (LPK >= 8) acc += dpp_d<DPP_ROW_HALF_MIRROR>(acc);
                     sc = (float)acc;
