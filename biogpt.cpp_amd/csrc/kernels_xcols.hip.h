@@ -10,8 +10,9 @@
 //   * the ONLY exchange between columns is the layer's N new K / V rows: workgroup 16 + h publishes head h's rows write-through, the attention workgroups of the
 //     other XCDs poll them at the memory side -- one cross-XCD hop per layer, which is also the only synchronisation between the columns;
 //   * every XCD streams ALL weights (7 MB per layer through its own L2: the eight XCDs read the same lines within microseconds of each other, the Infinity
-//     Cache serves seven of the eight reads); a stage's units are requested again -- for the next layer -- right behind their use, a whole layer (~ 11 us)
-//     ahead, so no stage waits for weights.  Units stay packed (5 .. 6 registers per unit, 30 units per lane in the q / k / v workgroups).
+//     Cache serves seven of the eight reads).  Units stay packed (5 .. 6 registers per unit, 30 units per lane in the q / k / v workgroups; Q8_0: 9) and are
+//     requested in ONE burst per layer and role, in front of the one poll that waits for microseconds anyway (see xc_run: a wave's loads return in order, a poll
+//     behind a weight request waits for the fabric) -- 16.7 us per layer against 9.8 us of pure weight stream (tools/microbench20.hip) and ~ 11 us of chain.
 //
 // Shape: grid = 256 workgroups x 512 threads; XCD and rank inside the XCD as in kernels_xpipe.hip.h (HW_REG_XCC_ID + per-XCD ticket, same control words, same
 // hand-off tag counter: a chunk launch is one more launch of the context's pipeline and holds the device's pipeline slot like one).  XCDs >= N take their
