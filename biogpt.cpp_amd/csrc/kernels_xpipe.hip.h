@@ -236,23 +236,49 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
     if (__hip_atomic_compare_exchange_strong(p.ctl + 1, &expected, XP_QUIT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         __hip_atomic_store(p.err_host, XP_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// A value every lane of the wave holds alike although the compiler cannot know it (read from one LDS word): as a scalar (XP_UNI 1).  The publishing tag of the
+// resident instantiations is set from such values.  Measured at the end of round 4 (profiles/res_instantiation_ab_r4c.txt): no gain (256.5 against 255.5 us per
+// token through the RES instantiations) -- the tag's tests are not what the resident form costs; 0 = off in the product.
+// XP_RES_AB (measurement builds only, tools/exp_res_ab_r4c.sh): pieces of the resident form compiled out of the RES instantiations, to find what they cost the
+// chain when such a kernel runs an ORDINARY launch (BIOGPT_HIP_XPIPE_AS_RES=1): 1 plain sweeps, 2 no resident-mode code, 4 no "dead wave" flags in LDS, 8 the ordinary
+// lm_head epilogue.  0 in the product.
+#ifndef XP_RES_AB
+#define XP_RES_AB 0
+#endif
+#define XP_RESIDENT(p) (!(XP_RES_AB & 2) && (p).resident != 0)
+#ifndef XP_UNI
+#define XP_UNI 0
+#endif
+__device__ __forceinline__ uint32_t xp_uni(uint32_t v) {
+#if XP_UNI
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
 // Sweep with a publishing tag: etag is the tag this wave publishes with (the token's epoch), or 0 once the wave has seen the error / quit word -- from
 // then on it polls nothing and publishes only tag 0, which no poller accepts: a draining launch can never hand valid-looking garbage downstream (the
 // host may be waiting for exactly that token's completion words).
 template <bool RES, int N, int S = 1, bool CROSS = false>
 __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t &etag) {
-    if constexpr (!RES) {       // ordinary launches: the plain sweep (declared below), etag stays the epoch
+    if constexpr (!RES || (XP_RES_AB & 1) != 0) {       // ordinary launches: the plain sweep (declared below), etag stays the epoch
         if constexpr (CROSS && XP_CROSS_PIPE != 0) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
         else xp_sweep<N, S>(g, active, epoch, v, p);
         return;
     }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
+    etag = xp_uni(etag);
     if (etag == 0u) return;
     if constexpr (CROSS && XP_CROSS_PIPE != 0) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];
 #pragma unroll
         for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+#if XP_CROSS_PIPE >= 2
+        xp_u64 mid[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) mid[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+#endif
         for (uint32_t spins = 0;; spins++) {
             xp_u64 nxt[N];
 #pragma unroll
@@ -267,8 +293,13 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
             }
             if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
             if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+#if XP_CROSS_PIPE >= 2
+#pragma unroll
+            for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
+#else
 #pragma unroll
             for (int k = 0; k < N; k++) cur[k] = nxt[k];
+#endif
         }
     }
     for (uint32_t spins = 0;; spins++) {
@@ -294,6 +325,11 @@ __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active,
     xp_u64 cur[N];
 #pragma unroll
     for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+#if XP_CROSS_PIPE >= 2      // (three passes in flight: measured at the end of round 4, profiles/res_instantiation_ab_r4c.txt)
+    xp_u64 mid[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) mid[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+#endif
     for (uint32_t spins = 0;; spins++) {
         xp_u64 nxt[N];
 #pragma unroll
@@ -304,8 +340,13 @@ __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active,
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
+#if XP_CROSS_PIPE >= 2
+#pragma unroll
+        for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
+#else
 #pragma unroll
         for (int k = 0; k < N; k++) cur[k] = nxt[k];
+#endif
     }
 }
 // every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
@@ -653,8 +694,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (bi < 0 || bi >= p.n_vocab) bi = 0;
                     return bi;
                 };
-                if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
-                if (RES && p.resident != 0 && tk > 0) {
+                if (RES && XP_RESIDENT(p) && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                if (RES && XP_RESIDENT(p) && tk > 0) {
                     // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox -- or, speculating, the device's own
                     // arg-max of the previous one, which that post must then confirm.  Workgroup 0 decides and hands the token to the XCD's other workgroups
                     // as a granule; a wait for the host lasts at most idle_ticks, then the launch ends cleanly (xp_quit)
@@ -754,7 +795,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         tokens[0] = tok;
                     }
                 } else {
-                    tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
+                    tok = (RES && XP_RESIDENT(p)) ? p.res_tok0 : state_tokens(p.st)[0];
                 }
                 if (slot == 0) XP_TAIL(tk, 5);
                 if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
@@ -781,7 +822,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
             // read behind LayerNorm's barriers
-            if (RES && wave < 4 && lane == 0) s_dead[wave] = (etag == 0u) ? 1u : 0u;
+            if (RES && !(XP_RES_AB & 4) && wave < 4 && lane == 0) s_dead[wave] = (etag == 0u) ? 1u : 0u;
             return xv;
         };
         if constexpr (FIRST) {
@@ -832,7 +873,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int which = jj >> 6, d = jj & 63;
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                     float *cache = (which == 1) ? Y.kcache : Y.vcache;
                     cache[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
@@ -902,7 +943,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = jj >> 6, d = jj & 63;
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
-                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -946,7 +987,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -957,7 +998,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int jo = (1 - HI) * 96 + (tid < 96 ? tid : 0);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + (jo >> 6) * 1024 + head * 64 + (jo & 63), tid < 96, epoch, v, p, etag);
                     if (tid < 96) s_cur[jo] = __uint_as_float(v[0]);
-                    if (RES && lane == 0) s_kvdead[wave] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && !(XP_RES_AB & 4) && lane == 0) s_kvdead[wave] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
                 // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
@@ -1008,7 +1049,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             __syncthreads();
-            if constexpr (RES && DUAL) { if ((s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u; }
+            if constexpr (RES && DUAL) { if (xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u; }
             XP_WALL(7);
             constexpr bool LATE_KV = !MERGE && XP_SPLIT_Q != 0 && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
             auto key_score = [&](const float4 (&kk)[NF4]) __attribute__((always_inline)) -> float {
@@ -1032,7 +1073,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = wave - (NW - 3);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + which * 1024 + head * 64 + lane, true, epoch, v, p, etag);
                     s_cur[which * 64 + lane] = __uint_as_float(v[0]);
-                    if (RES && lane == 0) s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && !(XP_RES_AB & 4) && lane == 0) s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             }
             float sc = -INFINITY;
@@ -1060,7 +1101,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int c = 0; c < KC; c++) scl[c] = s_S[lane + 64 * c];
                 if constexpr (LATE_KV) {
-                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    if (RES && !(XP_RES_AB & 4) && xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
                     float4 kn[NF4];                 // the token's own key: every group of LPK lanes of every wave forms its score (the association of the old keys' scores)
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kn[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1097,7 +1138,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             } else {
                 if constexpr (LATE_KV) {
                     __syncthreads();      // the token's k / v rows are in s_cur
-                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    if (RES && !(XP_RES_AB & 4) && xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
                     if (kidx == n_past) {      // the LPK lanes of the new key
 #pragma unroll
                         for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1127,7 +1168,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     uint32_t dead = 0u;
 #pragma unroll
                     for (int w = 0; w < NW; w++) dead |= reinterpret_cast<const uint32_t *>(s_redf)[NW + w];
-                    if (dead != 0u) etag = 0u;
+                    if (xp_uni(dead) != 0u) etag = 0u;
                 }
                 XP_WALL(13);
                 double sum = 0.0;
@@ -1444,7 +1485,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         constexpr int LMS = 128 / NW;                                         // 2-row steps per wave: 256 rows per workgroup
         const int row0 = lm_rank * 256;
         // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
-        const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
+        const bool alt = RES && XP_RESIDENT(p) && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
         float *const lg_dev = alt ? p.logits_alt : p.logits;
         float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
         Unit<WT> wl[LMS];
@@ -1458,7 +1499,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         for (int s = 0; s < LMS; s++) xp_settle<WT, EXPAND>(wl[s]);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
         if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
-        if (RES && p.resident != 0 && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
+        if (RES && XP_RESIDENT(p) && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
             uint32_t go[1];
             xp_sweep_q<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, etag);
         }
@@ -1488,7 +1529,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
             if (row < p.n_vocab) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
-                if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
+                if constexpr (RES && !(XP_RES_AB & 8)) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
                 else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
                 best_val = v; best_idx = row;
             }
@@ -1501,7 +1542,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
         if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
         bool row_ok = true;
-        if constexpr (RES) row_ok = __syncthreads_and(etag != 0u);
+        if constexpr (RES && !(XP_RES_AB & 8)) row_ok = __syncthreads_and(etag != 0u);
         else __syncthreads();
         // the host's copy of the row (biogpt_eval's output): wave 1 writes the workgroup's 256 logits as ONE kilobyte of 16-byte write-through stores
         // (four-byte stores from the finisher lanes were one PCIe write each: 42 k per token); a resident launch follows them with the workgroup's
@@ -1516,7 +1557,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             } else {
                 for (int j = r; j < p.n_vocab; j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
             }
-            if (p.resident != 0) {
+            if (XP_RESIDENT(p)) {
                 if (lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (the same maxima tid < 4 records below)
                     float bm = s_redf[lane * NW];
 #pragma unroll
@@ -1569,8 +1610,38 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     }
 }
 
+// XP_PIN_PARAMS 1 (measurement builds): the parameter block of the resident instantiations, every word of it read ONCE at the kernel's entry and passed through
+// an empty asm statement.  A kernel argument is an invariant scalar load and the register allocator rematerialises such loads instead of spilling them: the
+// ordinary instantiations keep all 21 s_loads in the entry block, the resident ones (more live words: mailbox, completion words, alternate buffers) have 99 of
+// them inside the token loop and 57 inside the LAYER loop.  A value that comes out of an asm statement cannot be rematerialised (it goes to a vector register's
+// lane instead, as in the ordinary instantiations): with it the loops hold 0 .. 3 such loads -- and the launch is no faster (64-key bucket 244.5 against 245.7 us
+// per token, 192- / 256-key buckets 8 / 5 us slower: profiles/res_instantiation_ab_r4c.txt).  The rematerialised loads are not what the resident form costs; off.
+#ifndef XP_PIN_PARAMS
+#define XP_PIN_PARAMS 0
+#endif
+template <typename T>
+__device__ __forceinline__ void xp_pin(T &v) {
+    if constexpr (sizeof(T) == 4 && !__is_pointer(T) && !__is_integral(T)) { uint32_t u = __float_as_uint(v); asm volatile("" : "+s"(u)); v = __uint_as_float(u); }
+    else asm volatile("" : "+s"(v));
+}
+__device__ __forceinline__ void xp_pin(DevMatrix &m) { xp_pin(m.qs); xp_pin(m.sc); xp_pin(m.qh); xp_pin(m.type); xp_pin(m.M); xp_pin(m.K); }
+__device__ __forceinline__ void xp_pin_params(XpParams &q) {
+    xp_pin(q.layers); xp_pin(q.n_layer); xp_pin(q.gran); xp_pin(q.gran_l); xp_pin(q.ctl); xp_pin(q.err_host); xp_pin(q.st); xp_pin(q.tok_emb); xp_pin(q.pos_emb);
+    xp_pin(q.embed_scale); xp_pin(q.tok_src); xp_pin(q.pmax_val); xp_pin(q.pmax_idx); xp_pin(q.nparts); xp_pin(q.n_positions); xp_pin(q.n_vocab); xp_pin(q.eps);
+    xp_pin(q.q_scale); xp_pin(q.P); xp_pin(q.t_cap); xp_pin(q.exp_tab); xp_pin(q.gelu_tab); xp_pin(q.gelu_p); xp_pin(q.gelu_n); xp_pin(q.gelu_z); xp_pin(q.exp_n);
+    xp_pin(q.x_final); xp_pin(q.lm); xp_pin(q.lm_blocks); xp_pin(q.adv); xp_pin(q.n_tok); xp_pin(q.samp); xp_pin(q.Wlm); xp_pin(q.lm_ln_w); xp_pin(q.lm_ln_b);
+    xp_pin(q.logits); xp_pin(q.logits_host); xp_pin(q.pmax_out_val); xp_pin(q.pmax_out_idx); xp_pin(q.dual); xp_pin(q.resident); xp_pin(q.res_tok0);
+    xp_pin(q.res_n_past0); xp_pin(q.res_dbg); xp_pin(q.mbox); xp_pin(q.mbox_seq0); xp_pin(q.idle_ticks); xp_pin(q.done_host); xp_pin(q.res_spec0); xp_pin(q.spec_rec);
+    xp_pin(q.logits_alt); xp_pin(q.logits_host_alt); xp_pin(q.pmax_alt_val); xp_pin(q.pmax_alt_idx); xp_pin(q.wall);
+}
+
 template <int WT, int LPK, int NW, int KCAP, bool SPLIT, bool RES = false>
-__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
+__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p_in) {
+    XpParams p_pinned;
+    const XpParams &p = [&]() -> const XpParams & {
+        if constexpr (RES && XP_PIN_PARAMS != 0) { p_pinned = p_in; xp_pin_params(p_pinned); return p_pinned; }
+        else return p_in;
+    }();
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "Q8_0 (9 registers per weight unit) runs with split layers");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
@@ -1616,7 +1687,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past0 = (RES && p.resident != 0) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
+    const int n_past0 = (RES && XP_RESIDENT(p)) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
     const int t_cap = p.t_cap;
 
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
