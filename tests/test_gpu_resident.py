@@ -358,3 +358,32 @@ def test_two_contexts_interleave_single_token_evals_on_one_device(pkg, files, mo
             order = np.lexsort((np.arange(t.size), -t))[:5]
             assert list(ids) == [int(v) for v in order] and (vals == t[order]).all(), ("second context, top-k", n_past)
     r.close()
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
+def test_resident_instantiations_as_ordinary_multi_token_launches(pkg, oracle, files, monkeypatch, name):
+    """BIOGPT_HIP_XPIPE_AS_RES=1 (measurement switch, xpipe_tu.hip) sends ORDINARY pipelined launches -- the device-resident greedy loop's multi-token launches --
+    through the RES = true instantiations of dec_xpipe_kernel with resident = 0 (profiles/res_instantiation_ab_r4c.txt measures what that form costs the chain).
+    Same arithmetic, so: the same 250 ids (64- / 128- / 192- / 256-key variants) as the ordinary instantiations, and the oracle's first 24.  A context of its own for
+    each arm: launches are captured into graphs per context."""
+    prompt = [2, 900, 17, 4211, 8]
+    g = pkg.BiogptModel.load(files[name])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    ids_ord, _ = g.generate_greedy(prompt, 250, n_batch=8)
+    g.close()
+    monkeypatch.setenv("BIOGPT_HIP_XPIPE_AS_RES", "1")
+    r = pkg.BiogptModel.load(files[name])
+    ids_res, _ = r.generate_greedy(prompt, 250, n_batch=8)
+    assert r.xpipe_state() == 1
+    r.close()
+    monkeypatch.delenv("BIOGPT_HIP_XPIPE_AS_RES")
+    assert [int(t) for t in ids_ord] == [int(t) for t in ids_res]
+    o = oracle.OracleModel(files[name], n_threads=16)
+    lo = o.eval(prompt, 0)
+    n_past = len(prompt)
+    for k in range(min(24, len(ids_res))):
+        tok = int(lo.argmax())
+        assert tok == int(ids_res[k]), "%s: token %d: oracle %d, RES instantiation %d" % (name, k, tok, int(ids_res[k]))
+        lo = o.eval([tok], n_past)
+        n_past += 1
