@@ -246,6 +246,12 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
 #define XP_RES_AB 0
 #endif
 #define XP_RESIDENT(p) (!(XP_RES_AB & 2) && (p).resident != 0)
+// XP_DEAD_STICKY 1: the "dead wave" words of the resident form (a wave whose layer input / k, v rows never came tells the workgroup's other waves, which append K / V rows
+// or publish) are raised ONCE and stay up for the rest of the launch (a draining launch never recovers: its quit / error word stays) -- no store per layer and wave, one
+// word to look at instead of four / two.  0: the round-3 form (a word per wave, rewritten every layer).
+#ifndef XP_DEAD_STICKY
+#define XP_DEAD_STICKY 0
+#endif
 #ifndef XP_UNI
 #define XP_UNI 0
 #endif
@@ -822,7 +828,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
             // read behind LayerNorm's barriers
-            if (RES && !(XP_RES_AB & 4) && wave < 4 && lane == 0) s_dead[wave] = (etag == 0u) ? 1u : 0u;
+            if (RES && !(XP_RES_AB & 4) && wave < 4 && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_dead[0] = 1u; } else s_dead[wave] = (etag == 0u) ? 1u : 0u; }
             return xv;
         };
         if constexpr (FIRST) {
@@ -873,7 +879,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int which = jj >> 6, d = jj & 63;
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                     float *cache = (which == 1) ? Y.kcache : Y.vcache;
                     cache[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
@@ -943,7 +949,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = jj >> 6, d = jj & 63;
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -987,7 +993,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -998,7 +1004,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int jo = (1 - HI) * 96 + (tid < 96 ? tid : 0);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + (jo >> 6) * 1024 + head * 64 + (jo & 63), tid < 96, epoch, v, p, etag);
                     if (tid < 96) s_cur[jo] = __uint_as_float(v[0]);
-                    if (RES && !(XP_RES_AB & 4) && lane == 0) s_kvdead[wave] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && !(XP_RES_AB & 4) && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_kvdead[0] = 1u; } else s_kvdead[wave] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
                 // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
@@ -1049,7 +1055,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             __syncthreads();
-            if constexpr (RES && DUAL) { if (xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u; }
+            if constexpr (RES && DUAL) { if (xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u; }
             XP_WALL(7);
             constexpr bool LATE_KV = !MERGE && XP_SPLIT_Q != 0 && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
             auto key_score = [&](const float4 (&kk)[NF4]) __attribute__((always_inline)) -> float {
@@ -1073,7 +1079,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = wave - (NW - 3);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + which * 1024 + head * 64 + lane, true, epoch, v, p, etag);
                     s_cur[which * 64 + lane] = __uint_as_float(v[0]);
-                    if (RES && !(XP_RES_AB & 4) && lane == 0) s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u;      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && !(XP_RES_AB & 4) && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_kvdead[0] = 1u; } else s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             }
             float sc = -INFINITY;
@@ -1101,7 +1107,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int c = 0; c < KC; c++) scl[c] = s_S[lane + 64 * c];
                 if constexpr (LATE_KV) {
-                    if (RES && !(XP_RES_AB & 4) && xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    if (RES && !(XP_RES_AB & 4) && xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u;
                     float4 kn[NF4];                 // the token's own key: every group of LPK lanes of every wave forms its score (the association of the old keys' scores)
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kn[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1138,7 +1144,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             } else {
                 if constexpr (LATE_KV) {
                     __syncthreads();      // the token's k / v rows are in s_cur
-                    if (RES && !(XP_RES_AB & 4) && xp_uni(s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
+                    if (RES && !(XP_RES_AB & 4) && xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u;
                     if (kidx == n_past) {      // the LPK lanes of the new key
 #pragma unroll
                         for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1685,6 +1691,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p_in)
     }
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
+    if (RES && XP_DEAD_STICKY != 0 && threadIdx.x < 16) reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 64)[threadIdx.x] = 0u;      // s_kvdead / s_dead (xp_run): raised once, never lowered
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
     const int n_past0 = (RES && XP_RESIDENT(p)) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
