@@ -245,6 +245,7 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
 #ifndef XP_RES_AB
 #define XP_RES_AB 0
 #endif
+#define XP_RES_CADENCE ((XP_RES_AB & 16) ? 1023u : 255u)      // poll passes between two looks at the error word in the resident sweeps
 #define XP_RESIDENT(p) (!(XP_RES_AB & 2) && (p).resident != 0)
 // XP_DEAD_STICKY 1: the "dead wave" words of the resident form (a wave whose layer input / k, v rows never came tells the workgroup's other waves, which append K / V rows
 // or publish) are raised ONCE and stay up for the rest of the launch (a draining launch never recovers: its quit / error word stays) -- no store per layer and wave, one
@@ -275,7 +276,7 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
     etag = xp_uni(etag);
-    if (etag == 0u) return;
+    if (!(XP_RES_AB & 32) && etag == 0u) return;
     if constexpr (CROSS && XP_CROSS_PIPE != 0) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];
 #pragma unroll
@@ -297,8 +298,8 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
                 for (int k = 0; k < N; k++) v[k] = active ? (uint32_t)cur[k] : 0u;
                 return;
             }
-            if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
-            if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+            if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
+            if ((spins & XP_RES_CADENCE) == XP_RES_CADENCE && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
 #if XP_CROSS_PIPE >= 2
 #pragma unroll
             for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
@@ -319,8 +320,8 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
             }
         }
         if (__all(ok)) return;
-        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
-        if ((spins & 255u) == 255u && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
+        if ((spins & XP_RES_CADENCE) == XP_RES_CADENCE && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
         xp_poll_pause();
     }
 }
