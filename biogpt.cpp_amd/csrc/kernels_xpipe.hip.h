@@ -246,6 +246,15 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
 #define XP_RES_AB 0
 #endif
 #define XP_RES_CADENCE ((XP_RES_AB & 16) ? 1023u : 255u)      // poll passes between two looks at the error word in the resident sweeps
+// XP_RES_EXPECT 1: the exits of the resident sweeps marked unlikely (block placement: the drain paths out of the polling loops' line) -- A/B arm, see profiles/res_instantiation_ab_r4c.txt
+#ifndef XP_RES_EXPECT
+#define XP_RES_EXPECT 0
+#endif
+#if XP_RES_EXPECT
+#define XP_COLD(c) __builtin_expect(!!(c), 0)
+#else
+#define XP_COLD(c) (c)
+#endif
 #define XP_RESIDENT(p) (!(XP_RES_AB & 2) && (p).resident != 0)
 // XP_DEAD_STICKY 1: the "dead wave" words of the resident form (a wave whose layer input / k, v rows never came tells the workgroup's other waves, which append K / V rows
 // or publish) are raised ONCE and stay up for the rest of the launch (a draining launch never recovers: its quit / error word stays) -- no store per layer and wave, one
@@ -276,7 +285,7 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
     etag = xp_uni(etag);
-    if (!(XP_RES_AB & 32) && etag == 0u) return;
+    if (!(XP_RES_AB & 32) && XP_COLD(etag == 0u)) return;
     if constexpr (CROSS && XP_CROSS_PIPE != 0) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];
 #pragma unroll
@@ -298,8 +307,8 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
                 for (int k = 0; k < N; k++) v[k] = active ? (uint32_t)cur[k] : 0u;
                 return;
             }
-            if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
-            if ((spins & XP_RES_CADENCE) == XP_RES_CADENCE && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
+            if (XP_COLD(spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
+            if (XP_COLD((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
 #if XP_CROSS_PIPE >= 2
 #pragma unroll
             for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
@@ -320,8 +329,8 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
             }
         }
         if (__all(ok)) return;
-        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
-        if ((spins & XP_RES_CADENCE) == XP_RES_CADENCE && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
+        if (XP_COLD(spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
+        if (XP_COLD((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
         xp_poll_pause();
     }
 }
