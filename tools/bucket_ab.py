@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--arm":
     import numpy as np
     import _pkg
     pkg = _pkg.load()
-    q = os.path.join(os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"), "synthetic-L24-q4_0.bin")
+    q = os.path.join(os.environ.get("BIOGPT_BENCH_DIR", "/tmp/biogpt_amd_bench"), "synthetic-L24-%s.bin" % os.environ.get("BUCKET_AB_FTYPE", "q4_0"))
     m = pkg.BiogptModel.load(q)
     rng = np.random.default_rng(5)
     out = {}
