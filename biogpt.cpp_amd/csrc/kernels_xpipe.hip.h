@@ -259,6 +259,11 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
 // XP_DEAD_STICKY 1: the "dead wave" words of the resident form (a wave whose layer input / k, v rows never came tells the workgroup's other waves, which append K / V rows
 // or publish) are raised ONCE and stay up for the rest of the launch (a draining launch never recovers: its quit / error word stays) -- no store per layer and wave, one
 // word to look at instead of four / two.  0: the round-3 form (a word per wave, rewritten every layer).
+// XP_DEAD_EARLY 1: the dead-wave words are read right behind LayerNorm's barriers (with the activation's other LDS reads) instead of at the K / V append, where the
+// read and its wait stand between the rows and their stores.  A/B arm (profiles/res_instantiation_ab_r4c.txt).
+#ifndef XP_DEAD_EARLY
+#define XP_DEAD_EARLY 0
+#endif
 #ifndef XP_DEAD_STICKY
 #define XP_DEAD_STICKY 0
 #endif
@@ -871,6 +876,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
             }
             ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+            const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
             XP_WALL(6);
             uint32_t ax[8];
             const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -889,7 +895,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int which = jj >> 6, d = jj & 63;
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                     float *cache = (which == 1) ? Y.kcache : Y.vcache;
                     cache[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
@@ -940,6 +946,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                 }
                 ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
                 XP_WALL(6);
                 if (L == 0 && slot == 0) XP_TAIL(tk, 7);
                 uint32_t ax[8];
@@ -959,7 +966,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = jj >> 6, d = jj & 63;
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -984,6 +991,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                 }
                 ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
+                const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
                 XP_WALL(6);
                 uint32_t ax[8];
                 const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -1003,7 +1011,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
