@@ -172,7 +172,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, mfma_nt2_min, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, mfma_nt2_rows;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -217,8 +217,6 @@ struct EngineOptions {
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
-        mfma_nt2_min = get("BIOGPT_HIP_MFMA_NT2_MIN", 64);
-        mfma_nt2_rows = get("BIOGPT_HIP_MFMA_NT2_ROWS", 2048);   // ... for matrices of at least this many rows (1024-row matrices: one wave per SIMD at 512 columns -- measured slower)
         eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
@@ -254,6 +252,7 @@ struct biogpt_hip_ctx {
     size_t logits_all_rows = 0;
     float *pmax_val = nullptr;
     float *sp_scores = nullptr, *sp_max = nullptr;   // key-split decode attention scratch (kernels_fast.hip.h)
+    bool tile_img_failed = false;  // the image did not fit: passes stay on the VALU chain
     uint8_t *tile_img = nullptr;   // row-tiled copy of the chain matrices for the MFMA kernels (same offsets as the arena), built on first use
     double *sp_pv = nullptr;
     int32_t *pmax_idx = nullptr;
@@ -482,25 +481,17 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
 }
 // many columns (prompt passes, batched sequences): the same chain on the int8 matrix cores, reading the row-tiled
 // weight image (kernels_mfma.hip.h)
-template <int WT, int EPI, int K, int NT>
-hipError_t launch_mfma_nt(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    const size_t sm = bgk::matmul_mfma_smem_bytes(K, EPI == bgk::EPI_GELU_Q8, NT);
-    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K, NT>);
+template <int WT, int EPI, int K>
+hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    const size_t sm = bgk::matmul_mfma_smem_bytes(K, bgk::TypeInfo<WT>::q81, EPI == bgk::EPI_GELU_Q8);
+    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>);
     if (sm > 64 * 1024 && !t_ctx->lds_attr_done.count(fn)) {   // > 64 KB of dynamic LDS needs the opt-in attribute, per device
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
         t_ctx->lds_attr_done.insert(fn);
     }
-    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K, NT>), dim3((p.W.M + 63) / 64, (p.N + 16 * NT - 1) / (16 * NT)), dim3(256), sm, st, p, img);
+    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(bgk::mfma_threads(K)), sm, st, p, img);
     return hipGetLastError();
-}
-// two 16-column tiles per wave (the weight-side work of a block is shared) from mfma_nt2_min columns (default 64), for
-// matrices of >= 2048 rows only: measured at 512 columns (profiles/mfma_nt2_r2.txt) fc1 28.5 -> 26.5 us, q/k/v 18.7 -> 16.1 us,
-// but fc2 25.3 -> 28.6 us and out_proj 8.6 -> 9.3 us -- 1024 rows x 512 columns are only 1024 such waves, one per SIMD
-template <int WT, int EPI, int K>
-hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    if (opt().mfma_nt2_min > 0 && p.N >= opt().mfma_nt2_min && p.W.M >= opt().mfma_nt2_rows) return launch_mfma_nt<WT, EPI, K, 2>(p, img, st);
-    return launch_mfma_nt<WT, EPI, K, 1>(p, img, st);
 }
 template <int WT>
 hipError_t launch_chain_mfma(ChainOp op, const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
@@ -627,7 +618,7 @@ void retile_one(biogpt_hip_ctx *c, const MatSlot &m) {
     hipLaunchKernelGGL((bgk::retile_kernel<WT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_matrix(c, m), c->tile_img + m.xq, c->tile_img + m.xs);
 }
 bool ensure_tile_images(biogpt_hip_ctx *c) {
-    if (c->tile_img) return true;
+    if (c->tile_img || c->tile_img_failed) return true;
     size_t off = 0;
     auto place = [&](MatSlot &m) {
         if (!is_quantized(m.type)) return;
@@ -638,7 +629,13 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
     };
     for (auto &L : c->plan.layers) { place(L.qkv); place(L.o); place(L.fc1); place(L.fc2); }
     place(c->plan.lm_head);
-    HIP_TRY(false, hipMalloc(&c->tile_img, std::max<size_t>(off, 256)));
+    if (hipMalloc(&c->tile_img, std::max<size_t>(off, 256)) != hipSuccess) {
+        // no room for the image (several contexts / replicas on one device): the passes stay on the VALU chain, which needs none
+        (void)hipGetLastError();
+        c->tile_img = nullptr; c->tile_img_failed = true;
+        if (c->opt.verbose) fprintf(stderr, "biogpt_hip: no memory for the %zu-byte row-tiled weight image; many-column passes stay on the 8-column kernels\n", off);
+        return true;
+    }
     auto one = [&](const MatSlot &m) {
         switch (m.type) {
             case T_Q4_0: retile_one<bgk::W_Q4_0>(c, m); break;

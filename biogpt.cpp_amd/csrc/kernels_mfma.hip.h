@@ -1,54 +1,55 @@
 // Block-quantized weights x many activation columns on the matrix cores (gfx950 v_mfma_i32_16x16x32_i8).
 //
-// With 32+ columns in flight (prompt passes of 128 tokens, dozens of sequences decoded together) the 8-column
-// mat-vec kernels of kernels_fast.hip.h are instruction-bound: ~12 VALU instructions per (row, column, block),
-// fc2 at 128 columns = 42 us.  One MFMA does the 32-element integer dot of a weight block against an activation
-// block for 16 rows x 16 columns at once -- exactly ggml's per-block "sumi" -- and everything after it is the
-// unchanged scalar arithmetic:
+// With 48+ columns in flight (prompt passes, dozens of sequences decoded together) the 8-column mat-vec kernels of
+// kernels_fast.hip.h are instruction-bound.  One MFMA does the 32-element integer dot of a weight block against an
+// activation block for 16 rows x 16 columns at once -- exactly ggml's per-block "sumi" -- and everything after it is
+// the unchanged scalar arithmetic:
 //
 //   per wave = one 16 x 16 output tile, for block b = 0 .. K/32-1 IN ORDER:
 //     A = 16 rows x 32 weights of block b      (int8 from the expanded image: Q4_0 / Q5_0 signed, q - 8 / q - 16)
 //     B = 32 activations x 16 columns          (the producer's Q8_0 / Q8_1 blocks)
 //     C = A x B (int32, zero-initialised)      -> sumi[row][col] of THIS block, 4 per lane
-//     acc[row][col] += ggml's per-type term    (sumi - 8*sum(x)) * d_w * d_x  etc. (unit_dot_quant; sumi - 8*sum(x) IS the signed dot)
+//     acc[row][col] += ggml's per-type term    (mfma_block_term: the reference's mul / mul / add, unfused)
 //
-// The accumulation runs over the blocks in block order inside one lane -- the association of the reference's
-// scalar vec_dot loop -- and the integer sums are exact: results are bit-identical to the VALU kernels and to
-// the oracle.
+// The accumulation runs over the blocks in block order inside one lane -- the association of the reference's scalar
+// vec_dot loop -- and the integer sums are exact: results are bit-identical to the VALU kernels and to the oracle.
 //
-// What makes it fast is where the operands come from (a first version that loaded them straight from the SoA
-// weight arrays was bound by the texture addresser: every 8-byte operand load touched 16 cache lines):
-//   * weights: a second, ROW-TILED copy of the matrix (retile_kernel, built once on first use): the 16 rows of
-//     a tile are contiguous per block, so an A-operand load of a wave covers 256 contiguous bytes and the four
-//     scales a lane needs are 8 contiguous bytes;
-//   * activations: the 16 columns of the workgroup are staged in LDS with coalesced 16-byte loads (up to 2048
-//     elements of K at a time: K = 4096 goes in two phases, 41 KB, three workgroups per compute unit) and shared
-//     by its 4 waves (= 4 row tiles); the row pitch + 16 bytes makes the 8-byte operand reads conflict-free
-//     (4 lanes per bank pair, the minimum for 512 bytes).
-// Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)).  A loads are batched 4 blocks at a
-// time and double-buffered against the arithmetic.
+// Round 5: the loop is a SOFTWARE PIPELINE.  Across blocks the only true dependence is the one f32 add per output; a
+// 1024-row matrix at 512 columns is 2048 wave tiles = two waves per SIMD, so nothing but the wave itself can hide its
+// latencies.  Round 4's loop (LDS read -> MFMA -> cvt -> mul -> mul -> add, batch by batch) ran ~340 cycles per block
+// against ~40 of arithmetic.  Now, per batch of 4 blocks, three stages are in flight in one wave:
+//     global A-operand loads        3 batches ahead of their MFMAs  (L2-hit latency ~200-330 cycles),
+//     LDS reads (B operand, scales) 1 batch ahead of their use,
+//     the 4 MFMAs of batch n+1      issued among the cvt/mul/mul/add of batch n.
+// and what a lane loads per block shrank: the four row scales a lane needs used to be a 16-byte GLOBAL load per lane
+// (1 KB through the texture addresser per wave and block for 64 unique bytes -- twice the weight bytes themselves);
+// they now go global -> LDS by DMA once per phase (each wave its own tile's 2 KB) and are read back as one
+// ds_read_b128 broadcast.  The activation block scales ride the same DMA.
+//
+// Operand sources:
+//   * weights: a second, ROW-TILED, EXPANDED copy of the matrix (retile_kernel, built once on first use): the 16 rows
+//     of a tile are contiguous per block, so an A-operand load of a wave covers 512 contiguous bytes;
+//   * activations: the 16 columns of the workgroup are staged in LDS by global_load_lds (no registers), 1024 elements
+//     of K per phase, DOUBLE-BUFFERED: phase ph + 1 lands while phase ph is consumed (K = 4096: four phases, 54 KB;
+//     K = 1024: one phase, 27 KB); the row pitch + 16 bytes makes the 8-byte operand reads conflict-free.
+// Workgroup = 4 waves = 64 rows x 16 columns; grid = (M/64, ceil(N/16)); linear workgroup id mod 8 = blockIdx.x mod 8
+// (M/64 is a multiple of 8 for every BioGPT matrix but lm_head), so an XCD's L2 holds 1/8 of the weight image.
 #pragma once
 
 #include "kernels_fast.hip.h"
+#include <type_traits>
 
 namespace bgk {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
-// weight batches (4 blocks each) in flight per wave: 2 (round 2) or 3 (round 4 experiment, profiles/prefill_mfma_depth_r4.txt)
-#ifndef MFMA_DEPTH
-#define MFMA_DEPTH 2
-#endif
-
-// ---- row-tiled, EXPANDED weight image (round 4) ---------------------------------------------------------------
+// ---- row-tiled, EXPANDED weight image -------------------------------------------------------------------------
 // src (SoA arena): qs[(row*BPR + b) * QB], sc[(row*BPR + b)], qh[(row*BPR + b)]
-// dst (image)    : index i = (tile*BPR + b)*16 + r  with tile = row / 16, r = row % 16   (M is a multiple of 16):
-//                  q[i * 32 .. +31]  the block's 32 weights as int8 in element order -- Q4_0: q - 8, Q5_0: q - 16 (signed: the MFMA's integer dot is then
-//                                    sum_j (q_j - 8) x_j itself, no block sum of the activations is needed), Q4_1 / Q5_1: q (0 .. 15 / 0 .. 31), Q8_0: as stored;
-//                  s[i]              the block's scale as f32 (Q4_1 / Q5_1: {d, m} as two f32)
-// Round 2's image kept the file's nibbles and fp16 scales (16 + 2 bytes per block) and every MFMA was followed by ~35 VALU instructions per lane, of which the
-// operand unpack, the fp16 -> f32 conversions of four row scales and the "- 8 sum(x)" corrections were half; they are done once, here.  The image doubles (Q4: 36 bytes
-// per block instead of 18): 340 MB for BioGPT-base, read once per prompt pass.
+// dst (image)    : (tile, b, r) with tile = row / 16, r = row % 16   (M is a multiple of 16), i = (tile*BPR + b)*16 + r:
+//                  q[i * 32 .. +31]   the block's 32 weights as int8 in element order -- Q4_0: q - 8, Q5_0: q - 16 (signed: the MFMA's integer dot is then
+//                                     sum_j (q_j - 8) x_j itself, no block sum of the activations is needed), Q4_1 / Q5_1: q (0 .. 15 / 0 .. 31), Q8_0: as stored;
+//                  scales             f32, per (tile, b) one 64-byte group d[16 rows]; Q4_1 / Q5_1: 128 bytes, d[16 rows] then m[16 rows]
+//                                     (a lane's rows 4g .. 4g+3 are one aligned 16-byte piece of each)
 template <int WT>
 __global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq, uint8_t *ds) {
     using TI = TypeInfo<WT>;
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq,
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // source block index row*BPR + b
     if (idx >= (int64_t)src.M * BPR) return;
     const int row = (int)(idx / BPR), b = (int)(idx - (int64_t)row * BPR);
-    const int64_t dst = ((int64_t)(row >> 4) * BPR + b) * 16 + (row & 15);
+    const int64_t grp = (int64_t)(row >> 4) * BPR + b;                 // (tile, b)
+    const int64_t dst = grp * 16 + (row & 15);
     const uint4 *q = reinterpret_cast<const uint4 *>(src.qs + idx * QB);
     uint4 *o = reinterpret_cast<uint4 *>(dq + dst * 32);
     if (WT == W_Q8_0) { o[0] = q[0]; o[1] = q[1]; }
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq,
     }
     if (TI::q81) {
         const uint32_t dm = reinterpret_cast<const uint32_t *>(src.sc)[idx];
-        reinterpret_cast<float2 *>(ds)[dst] = make_float2(h2f((uint16_t)(dm & 0xFFFFu)), h2f((uint16_t)(dm >> 16)));
+        float *const s = reinterpret_cast<float *>(ds) + grp * 32 + (row & 15);
+        s[0] = h2f((uint16_t)(dm & 0xFFFFu));
+        s[16] = h2f((uint16_t)(dm >> 16));
     } else {
         reinterpret_cast<float *>(ds)[dst] = h2f(reinterpret_cast<const uint16_t *>(src.sc)[idx]);
     }
@@ -88,239 +92,235 @@ __global__ __launch_bounds__(256) void retile_kernel(DevMatrix src, uint8_t *dq,
 
 // ggml's block term from the integer dot (the expressions of unit_dot_quant; the symmetric formats' dots come out of the signed image already corrected)
 template <int WT>
-__device__ __forceinline__ float mfma_block_term(int dot, float dw, float mw, float xd, uint32_t xs) {
-    if (WT == W_Q8_0) return __fmul_rn((float)dot, __fmul_rn(dw, xd));
-    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn((float)dot, dw), xd);
-    if (WT == W_Q5_0) return __fmul_rn(__fmul_rn(dw, xd), (float)dot);
-    return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), (float)dot), __fmul_rn(mw, __uint_as_float(xs)));
+__device__ __forceinline__ float mfma_block_term(float dot, float dw, float mw, float xd, float xs) {    // dot: the integer dot, converted (exact)
+    if (WT == W_Q8_0) return __fmul_rn(dot, __fmul_rn(dw, xd));
+    if (WT == W_Q4_0) return __fmul_rn(__fmul_rn(dot, dw), xd);
+    if (WT == W_Q5_0) return __fmul_rn(__fmul_rn(dw, xd), dot);
+    return __fadd_rn(__fmul_rn(__fmul_rn(dw, xd), dot), __fmul_rn(mw, xs));
 }
 
-template <int WT>
-struct MfmaBatch {                       // one lane's weight-side operands for CH consecutive blocks
-    static constexpr int CH = 4;         // blocks per load batch (8 costs ~60 more VGPRs and an occupancy step)
-    static constexpr int SW = TypeInfo<WT>::q81 ? 8 : 4;   // dwords of the lane's 4 row scales per block (f32 d, or {d, m})
-    uint2 q[CH];                         // the A operand itself: 8 int8 of row (lane & 15), elements 8 g .. 8 g + 7
-    uint32_t sc[CH][SW];                 // scales of rows 4g .. 4g+3
+// LDS of one staged phase of the workgroup (KP = 1024 elements of K for 16 columns and the 4 waves' 16-row tiles)
+template <bool Q81>
+struct MfmaLds {
+    static constexpr int KP = 1024, BPP = KP / QK;
+    static constexpr int PITCH = KP + 16;                    // bytes per activation column: the 8-byte operand reads of 32 lanes cover all 64 banks
+    static constexpr int SWF = Q81 ? 32 : 16;                // floats per (tile, block) of weight scales
+    static constexpr int OFF_Q = 0;
+    static constexpr int OFF_D = OFF_Q + 16 * PITCH;         // [8 batches][16 columns][4 blocks] activation block scales d: a batch's read is 256 contiguous bytes
+    static constexpr int OFF_S = OFF_D + 16 * BPP * 4;       // the same for the Q8_1 block sums d * sum(q) (Q4_1 / Q5_1 only)
+    static constexpr int OFF_W = OFF_S + (Q81 ? 16 * BPP * 4 : 0);   // [4 waves][BPP][SWF] weight scales of the waves' tiles
+    static constexpr int BYTES = OFF_W + 4 * BPP * SWF * 4;
 };
-
-// this lane's two image pointers at block 0 of its tile; block b is a CONSTANT stride further (512 bytes of weights, 64 / 128 bytes of scales),
-// so a batch is one base address plus immediate offsets
-template <int WT>
-struct MfmaLanePtrs {
-    const uint8_t *q, *sc;
-};
-template <int WT>
-__device__ __forceinline__ MfmaLanePtrs<WT> mfma_lane_ptrs(const DevMatrix &img, int64_t base, int li, int g) {
-    using TI = TypeInfo<WT>;
-    MfmaLanePtrs<WT> p;
-    p.q = img.qs + (base + li) * 32 + 8 * g;
-    p.sc = img.sc + (base + 4 * g) * (TI::q81 ? 8 : 4);
-    return p;
+__host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool q81, bool gelu_q8) {
+    const size_t buf = q81 ? (size_t)MfmaLds<true>::BYTES : (size_t)MfmaLds<false>::BYTES;
+    const size_t act = buf * (K > 1024 ? 2 : 1);
+    const size_t tail = gelu_q8 ? (size_t)16 * 64 * 4 : 0;   // the GELU_Q8 exchange reuses the area after the last block
+    return (act > tail ? act : tail);
 }
-template <int WT>
-__device__ __forceinline__ void mfma_load_batch(MfmaBatch<WT> &t, const MfmaLanePtrs<WT> &lp, int b0) {
-    using TI = TypeInfo<WT>;
-    constexpr int QS = 512, SS = TI::q81 ? 128 : 64;   // bytes per block of one tile
-    const uint8_t *q = lp.q + (size_t)b0 * QS, *sc = lp.sc + (size_t)b0 * SS;
-#pragma unroll
-    for (int j = 0; j < MfmaBatch<WT>::CH; j++) {
-        t.q[j] = *reinterpret_cast<const uint2 *>(q + j * QS);
-        const uint4 v = *reinterpret_cast<const uint4 *>(sc + j * SS);
-        t.sc[j][0] = v.x; t.sc[j][1] = v.y; t.sc[j][2] = v.z; t.sc[j][3] = v.w;
-        if (TI::q81) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(sc + j * SS + 16);
-            t.sc[j][4] = w.x; t.sc[j][5] = w.y; t.sc[j][6] = w.z; t.sc[j][7] = w.w;
-        }
-    }
-}
+// K = 1024 is one phase: 4 computing waves.  Longer rows add the staging wave (phases 1 .. are requested while the computing waves consume the one before).
+__host__ __device__ constexpr int mfma_threads(int K) { return K > 1024 ? 320 : 256; }
 
-template <int WT>
-__device__ __forceinline__ long mfma_a_operand(const MfmaBatch<WT> &t, int j, int g) {
-    return (long)(((unsigned long)t.q[j].y << 32) | t.q[j].x);
-}
+// MFMA_STAMPS (tools/microbench22.hip only): shader-clock stamps per wave at four points, p.tstamp[(workgroup * 5 + wave) * 8 + k]; k >= 4: the 100 MHz wall clock
+#ifdef MFMA_STAMPS
+#define MFMA_STAMP(k) do { if (lane == 0) p.tstamp[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 5 + wv) * 8 + (k)] = (k) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFMA_STAMP(k) do { } while (0)
+#endif
 
-// NT = 16-column tiles per wave.  NT = 2: the weight-side work of a block (operand unpack, the four fp16 row scales) feeds
-// two MFMAs and two sets of per-output terms, and the two tiles' dependency chains interleave.
-__host__ __device__ inline int matmul_mfma_kp(int K, int nt) { const int cap = nt == 1 ? 2048 : 1024; return K > cap ? cap : K; }
-__host__ __device__ inline size_t matmul_mfma_smem_bytes(int K, bool gelu_q8, int nt = 1) {
-    const int kp = matmul_mfma_kp(K, nt), nc = 16 * nt;                        // staged K phase, columns per workgroup
-    const size_t act = (size_t)nc * (kp + 16) + 2 * (size_t)nc * (kp / QK + 1) * 4;
-    const size_t tail = gelu_q8 ? (size_t)nc * 64 * 4 : 0;
-    return (act > tail ? act : tail) + 64;    // the GELU_Q8 exchange reuses the activation area after the last block
-}
+typedef __attribute__((address_space(1))) const void mfma_gl_ptr;
+typedef __attribute__((address_space(3))) void mfma_lds_ptr;
 
-template <int WT, int EPI, int K, int NT = 1>
-__global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
+// registers: 4 waves per SIMD (<= 128) for the formats without a min term -- at 136 the second workgroup of a compute unit only started when the first one's staging wave
+// had left (5-wave workgroups at 3 waves per SIMD do not pack: fc2 18 us instead of 10, tools/microbench22.hip); Q4_1 / Q5_1 hold twice the scales: 3 waves per SIMD (<= 168)
+template <int WT, int EPI, int K>
+__global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
-    static_assert(NT == 1 || NT == 2, "column tiles per wave");
-    // KP: columns of K staged in LDS at a time (K = 4096 goes in phases: 41 KB instead of 82 KB, so three workgroups
-    // fit a compute unit instead of one; the accumulators simply carry over, block order is unchanged)
-    constexpr int KP = (NT == 1) ? (K > 2048 ? 2048 : K) : (K > 1024 ? 1024 : K), NPH = K / KP, BPP = KP / QK, NC = 16 * NT;
-    constexpr int CH = MfmaBatch<WT>::CH, BPR = K / QK, NB = BPP / CH, PITCH = KP + 16, SP = BPP + 1;   // SP: per-column pitch of the scale arrays (bank skew)
-    static_assert(NB % 2 == 0, "K must be a multiple of 512");
+    constexpr bool Q81 = TI::q81;
+    using L = MfmaLds<Q81>;
+    constexpr int KP = L::KP, NPH = K / KP, BPP = L::BPP, BPR = K / QK, CH = 4, NB = BPP / CH, NBT = NPH * NB;
+    constexpr int PITCH = L::PITCH, SWF = L::SWF;
+    constexpr int QDEPTH = 3;                                // A-operand batches requested ahead of their MFMAs
+    constexpr int NW = mfma_threads(K) / 64;                 // waves of the workgroup
+    static_assert(K % KP == 0 && NB == 8, "phases of 1024 elements, 8 batches of 4 blocks");
+    static_assert(NBT > QDEPTH, "the prologue requests QDEPTH batches");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint8_t *const s_q = smem_raw;                                              // [NC columns][PITCH] int8
-    float *const s_d = reinterpret_cast<float *>(smem_raw + NC * PITCH);        // [NC][SP] activation block scales
-    uint32_t *const s_s = reinterpret_cast<uint32_t *>(s_d + NC * SP);          // [NC][SP] block sums (Q8_0: int, Q8_1: d*sum)
-    float *const s_tail = reinterpret_cast<float *>(smem_raw);                  // GELU_Q8: [NC columns][64 rows], after the loop
+    float *const s_tail = reinterpret_cast<float *>(smem_raw);                  // GELU_Q8: [16 columns][64 rows], after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int M = p.W.M;
-    const int tile = blockIdx.x * 4 + wave;                                     // 16-row tile of this wave
-    const int row0 = tile * 16, col0 = blockIdx.y * NC;
-    const bool tile_ok = row0 < M;
-    const int tile_c = tile_ok ? tile : 0;                                      // waves past the last row keep the barriers company
-    const int64_t base = (int64_t)tile_c * BPR * 16;
-    const int orow = row0 + 4 * g;                                              // outputs: rows 4g .. 4g+3, columns col0 + 16t + (lane & 15)
-
-    const MfmaLanePtrs<WT> lp = mfma_lane_ptrs<WT>(img, base, li, g);
-    MfmaBatch<WT> t0, t1;
-#if MFMA_DEPTH == 3
-    MfmaBatch<WT> t2;
+    const int col0 = blockIdx.y * 16;
+    MFMA_STAMP(0); MFMA_STAMP(4);
+#ifdef MFMA_STAMPS
+    if (lane == 0) p.tstamp[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 5 + wv) * 8 + 6] = ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));   // XCC_ID, HW_ID
 #endif
-    mfma_load_batch<WT>(t0, lp, 0);
-    // epilogue inputs (independent loads); M is a multiple of 4 everywhere
-    const int orc = min(orow, M - 4);
-    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res[NT];
-    if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc);
-    int e_npast[NT], e_seq[NT], colv[NT];
-    bool col_ok[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        colv[t] = col0 + 16 * t + li;
-        col_ok[t] = colv[t] < p.N;
-        const int colc = min(colv[t], p.N - 1);
-        e_res[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == EPI_RESID) e_res[t] = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc * p.ldr + orc);
-        e_npast[t] = 0; e_seq[t] = 0;
-        if (EPI == EPI_QKV) {
-            e_npast[t] = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
-            e_seq[t] = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
-        }
-    }
 
-    const uint8_t *bq = s_q + li * PITCH + 8 * g;                               // B operand: column = lane & 15 (+ 16 t), k-group g
-    const float *bd = s_d + li * SP;
-    const uint32_t *bs = s_s + li * SP;
-    float acc[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[t][r] = 0.0f;
-    auto consume = [&](const MfmaBatch<WT> &tb, int b0) {                       // b0: block index inside the staged phase
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int b = b0 + j;
-            const long aop = mfma_a_operand<WT>(tb, j, g);
-            float dwr[4], mwr[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                dwr[r] = __uint_as_float(TI::q81 ? tb.sc[j][2 * r] : tb.sc[j][r]);
-                mwr[r] = TI::q81 ? __uint_as_float(tb.sc[j][2 * r + 1]) : 0.0f;
-            }
-            i32x4 c[NT];
-            float xd[NT];
-            uint32_t xs[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const long bop = *reinterpret_cast<const long *>(bq + t * 16 * PITCH + b * QK);
-                xd[t] = bd[t * 16 * SP + b];
-                xs[t] = TI::q81 ? bs[t * 16 * SP + b] : 0u;      // the block sums only serve the min term of Q4_1 / Q5_1
-                const i32x4 zero = {0, 0, 0, 0};
-                c[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop, zero, 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[t][r] = __fadd_rn(acc[t][r], mfma_block_term<WT>(c[t][r], dwr[r], mwr[r], xd[t], xs[t]));
+    // ---- staging: a phase of the workgroup goes global -> LDS by DMA (global_load_lds: no registers), in NITEMS wave-instructions of 1 KB ----
+    //   items 0 .. 15: the 16 activation columns (1 KB of int8 each); then the four tiles' weight scales (2 / 4 KB contiguous in the image each);
+    //   then the activation block scales (and Q8_1 sums): 16-byte piece (batch j, column c) to [j][c], a lane per piece
+    // A wave issues a DMA every ~130 cycles (microbench22: 26 of them 3000 - 4300 cycles, as long as a phase's arithmetic), so phase 0 -- which nothing overlaps --
+    // is requested by ALL waves, an item each in turn.
+    constexpr int NI_W = 4 * (SWF / 8), NI_X = Q81 ? 4 : 2, NITEMS = 16 + NI_W + NI_X;
+    const int ntile = M / 16;
+    auto stage_item = [&](int ph, int it, int lane) {
+        unsigned char *const base = smem_raw + (ph & 1) * L::BYTES;
+        if (it < 16) {
+            const int cc = min(col0 + it, p.N - 1);                             // idle columns re-read the last one
+            __builtin_amdgcn_global_load_lds((mfma_gl_ptr *)(p.aq_q + (size_t)cc * K + ph * KP + lane * 16), (mfma_lds_ptr *)(base + L::OFF_Q + it * PITCH), 16, 0, 0);
+        } else if (it < 16 + NI_W) {
+            const int w = (it - 16) / (SWF / 8), i = (it - 16) % (SWF / 8);
+            const int t = min((int)blockIdx.x * 4 + w, ntile - 1);
+            const uint8_t *const src = img.sc + ((size_t)t * BPR + (size_t)ph * BPP) * (SWF * 4) + lane * 16;
+            __builtin_amdgcn_global_load_lds((mfma_gl_ptr *)(src + i * 1024), (mfma_lds_ptr *)(base + L::OFF_W + w * (BPP * SWF * 4) + i * 1024), 16, 0, 0);
+        } else {
+            const int x = it - 16 - NI_W, i = x & 1;
+            const int pos = lane + 64 * i, j = pos >> 4, c = pos & 15;
+            const int cc = min(col0 + c, p.N - 1);
+            if (x < 2) __builtin_amdgcn_global_load_lds((mfma_gl_ptr *)(p.aq_d + (size_t)cc * BPR + ph * BPP + 4 * j), (mfma_lds_ptr *)(base + L::OFF_D + i * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((mfma_gl_ptr *)(p.aq_s + (size_t)cc * BPR + ph * BPP + 4 * j), (mfma_lds_ptr *)(base + L::OFF_S + i * 1024), 16, 0, 0);
         }
     };
 #pragma unroll 1
-    for (int ph = 0; ph < NPH; ph++) {
-        // ---- stage this phase of the NC activation columns in LDS (coalesced 16-byte pieces) ----
-        if (ph > 0) __syncthreads();                                            // the previous phase has been consumed
-        {
-            // The activation bytes go from global memory STRAIGHT into LDS (global_load_lds_dwordx4, gfx950: 16 bytes per lane, a wave-instruction moves 1 KB of ONE
-            // column to 1 KB of that column's LDS row): no registers, every piece of the phase in flight at once.  Round 4: written as "load 16 bytes, store them to
-            // LDS" the compiler waited for each piece before it asked for the next (s_waitcnt vmcnt(0) between them, whatever the source order: it sinks every
-            // load to its LDS write) -- nine dependent L2 round trips per phase, a third of fc2's 26 us (profiles/prefill_mfma_staging_r4.txt).
-            constexpr int PPC = KP / 16;                                        // 16-byte pieces per column
-            constexpr int NPIECE = NC * PPC / 256, NSC = (NC * BPP + 255) / 256;
-            static_assert(PPC % 64 == 0, "a wave's 64 pieces lie in one column");
-            typedef __attribute__((address_space(1))) const void gl_ptr;
-            typedef __attribute__((address_space(3))) void lds_ptr;
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-            for (int i = 0; i < NPIECE; i++) {
-                const int pc0 = 64 * wv + 256 * i, c = pc0 / PPC, o0 = (pc0 - c * PPC) * 16;      // wave-uniform: the lane's piece is pc0 + lane
-                const int cc = min(col0 + c, p.N - 1);                          // idle columns re-read the last one
-                __builtin_amdgcn_global_load_lds((gl_ptr *)(p.aq_q + (size_t)cc * K + ph * KP + o0 + lane * 16), (lds_ptr *)(s_q + c * PITCH + o0), 16, 0, 0);
-            }
-            float sd[NSC];
-            uint32_t ss[NSC];
-#pragma unroll
-            for (int i = 0; i < NSC; i++) {
-                const int e = min(tid + 256 * i, NC * BPP - 1);
-                const int c = e / BPP, b = e - c * BPP;
-                const int cc = min(col0 + c, p.N - 1);
-                sd[i] = p.aq_d[(size_t)cc * BPR + ph * BPP + b];
-                ss[i] = TI::q81 ? p.aq_s[(size_t)cc * BPR + ph * BPP + b] : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < NSC; i++) {
-                const int e = tid + 256 * i;
-                if (e < NC * BPP) {
-                    const int c = e / BPP, b = e - c * BPP;
-                    s_d[c * SP + b] = sd[i];
-                    if (TI::q81) s_s[c * SP + b] = ss[i];
-                }
-            }
-        }
-        if (ph > 0) mfma_load_batch<WT>(t0, lp, ph * BPP);
-        __builtin_amdgcn_s_waitcnt(0x0f70);                                     // vmcnt(0): the direct-to-LDS loads of this wave have landed (the barrier publishes them)
-        __syncthreads();
-#if MFMA_DEPTH == 3
-        // three weight batches in flight: a batch is requested two consume steps (8 blocks) before its MFMAs
-        mfma_load_batch<WT>(t1, lp, ph * BPP + CH);
+    for (int it = wv; it < NITEMS; it += NW) stage_item(0, it, lane);
+    MFMA_STAMP(1);
+
+    // ---- the staging wave (K > 1024): phases 1 .. NPH - 1, one ahead of the computing waves ----
+    // Barrier ph (one per phase, all waves): a wave arrives when ITS DMAs of phase ph have landed and its LDS reads of phase ph - 1 are done; phase ph + 1 is
+    // requested right behind it into the buffer phase ph - 1 occupied.  The DMAs of the later phases live in a wave of their own because every wait on vmcnt is in
+    // order: inside a computing wave a wait for an A operand would also wait for whatever DMA was issued before it (and the compiler, seeing LDS written by VMEM,
+    // drains vmcnt before the next ds_read of any address).
+    if (NW == 5 && wv == 4) {
+        int ls = threadIdx.x & 63; asm volatile("" : "+v"(ls));                 // (the compiler lays this block out BEHIND the computing waves' code and would hold the lane index over all of it)
 #pragma unroll 1
-        for (int nb = 0; nb < NB; nb += 3) {
-            if (nb + 2 < NB) mfma_load_batch<WT>(t2, lp, ph * BPP + (nb + 2) * CH);
-            consume(t0, nb * CH);
-            if (nb + 1 < NB) {
-                if (nb + 3 < NB) mfma_load_batch<WT>(t0, lp, ph * BPP + (nb + 3) * CH);
-                consume(t1, (nb + 1) * CH);
-            }
-            if (nb + 2 < NB) {
-                if (nb + 4 < NB) mfma_load_batch<WT>(t1, lp, ph * BPP + (nb + 4) * CH);
-                consume(t2, (nb + 2) * CH);
+        for (int ph = 0; ph < NPH; ph++) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);                                 // vmcnt(0): landed
+            if (ph == 0) MFMA_STAMP(2);
+            __builtin_amdgcn_s_barrier();
+            if (ph + 1 < NPH) {
+#pragma unroll
+                for (int it = 0; it < NITEMS; it++) stage_item(ph + 1, it, ls);
             }
         }
-#else
-#pragma unroll 1
-        for (int nb = 0; nb < NB; nb += 2) {
-            mfma_load_batch<WT>(t1, lp, ph * BPP + (nb + 1) * CH);
-            consume(t0, nb * CH);
-            if (nb + 2 < NB) mfma_load_batch<WT>(t0, lp, ph * BPP + (nb + 2) * CH);
-            consume(t1, (nb + 1) * CH);
-        }
-#endif
+        MFMA_STAMP(3); MFMA_STAMP(5);
+        return;
     }
 
+    const int li = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * 4 + wave;                                     // 16-row tile of this wave
+    const int row0 = tile * 16;
+    const bool tile_ok = row0 < M;
+    const int tile_c = tile_ok ? tile : 0;                                      // waves past the last row keep the barriers company
+    // outputs of this lane: rows row0 + 4g .. + 3, column col0 + (lane & 15)
+
+    // ---- A operands: 8 int8 of row (lane & 15), elements 8 g .. 8 g + 7 of each block; block b of the tile is 512 bytes further ----
+    const uint8_t *const aq = img.qs + ((size_t)tile_c * BPR * 16 + li) * 32 + 8 * g;
+    uint2 qa[4][CH];                                                            // batch gb lives in qa[gb & 3]
+    auto load_a = [&](int gb, uint2 (&dst)[CH]) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) dst[j] = *reinterpret_cast<const uint2 *>(aq + (size_t)(gb * CH + j) * 512);
+    };
+    load_a(0, qa[0]); load_a(1, qa[1]); load_a(2, qa[2]);
+
+    // epilogue inputs (independent loads); M is a multiple of 4 everywhere
+    float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_res = make_float4(0.f, 0.f, 0.f, 0.f);   // requested inside the LAST phase: held from here they are spilled over the loop
+    const int colc = min(col0 + li, p.N - 1);
+    int e_npast = 0, e_seq = 0;
+    if (EPI == EPI_QKV) {
+        e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
+        e_seq = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
+    }
+
+    // this lane's LDS addresses inside a buffer
+    const int o_b = L::OFF_Q + li * PITCH + 8 * g;                              // B operand: column lane & 15, k-group g; block b is 32 bytes further
+    const int o_d = L::OFF_D + li * 16, o_s = L::OFF_S + li * 16;               // the column's block scales / sums; batch n is 256 bytes further
+    const int o_w = L::OFF_W + wv * (BPP * SWF * 4) + 16 * g;                   // rows 4g .. 4g+3 of the tile's scales; block b is SWF * 4 bytes further
+
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    long sb[2][CH];                                                             // B operands of batch n: sb[n & 1]
+    float4 sw[2][CH], sm[2][CH], xd[2], xs[2];                                  // weight scales / mins, activation scales / sums of batch n
+    i32x4 cc[CH];                                                               // integer dots: block j of batch n until step n has converted them, then block j of batch n + 1
+    const i32x4 zero = {0, 0, 0, 0};
+
+    // one phase; LAST (compile time): the epilogue's inputs are requested inside it (the last phase is peeled off the loop so that they are not loop-carried)
+    auto phase = [&](const int ph, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned char *const base = smem_raw + (ph & 1) * L::BYTES;
+        // barrier ph: phase ph has landed, this wave is done with phase ph - 1 (a bare s_barrier: __syncthreads() carries a release fence that drains EVERY
+        // load, the A-operand prefetch included)
+        if (ph == 0) __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0): this wave's share of phase 0 has landed (and the first A operands with it)
+        else __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0); vmcnt / expcnt untouched
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        auto lds_b = [&](int n, long (&dst)[CH]) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) dst[j] = *reinterpret_cast<const long *>(base + o_b + (n * CH + j) * QK);
+        };
+        auto lds_s = [&](int n, int s) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                sw[s][j] = *reinterpret_cast<const float4 *>(base + o_w + (n * CH + j) * (SWF * 4));
+                if (Q81) sm[s][j] = *reinterpret_cast<const float4 *>(base + o_w + (n * CH + j) * (SWF * 4) + 64);
+            }
+            xd[s] = *reinterpret_cast<const float4 *>(base + o_d + n * 256);
+            if (Q81) xs[s] = *reinterpret_cast<const float4 *>(base + o_s + n * 256);
+        };
+        // pipeline fill: operands of batches 0 and 1, scales of batch 0, the MFMAs of batch 0
+        lds_b(0, sb[0]); lds_s(0, 0); lds_b(1, sb[1]);
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            cc[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(((unsigned long)qa[0][j].y << 32) | qa[0][j].x), sb[0][j], zero, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NB; n++) {
+            const int gb = ph * NB + n;                                         // batch of the whole row
+            __builtin_amdgcn_sched_barrier(0);                                  // the stages of one step stay in their step (left alone the scheduler hoists every load of the phase and spills)
+            if (!(LAST && n + QDEPTH >= NB)) load_a(gb + QDEPTH, qa[(n + QDEPTH) & 3]);   // (compile time: the row ends with this phase)
+            if (n + 1 < NB) lds_s(n + 1, (n + 1) & 1);
+            if (n + 2 < NB) lds_b(n + 2, sb[n & 1]);                           // batch n's operands went into its MFMAs one step ago
+            if (n == NB - QDEPTH && LAST) {                                     // the A-operand registers of the batches past the end are free from here
+                int t2 = threadIdx.x; asm volatile("" : "+v"(t2));              // indices recomputed, not held over the loop (the pipeline fills all 128 registers)
+                const int orc2 = min((int)(blockIdx.x * 4 + (t2 >> 6)) * 16 + ((t2 >> 2) & 12), M - 4), colc2 = min(col0 + (t2 & 15), p.N - 1);
+                if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc2);
+                if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc2 * p.ldr + orc2);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const float cf[4] = {(float)cc[j][0], (float)cc[j][1], (float)cc[j][2], (float)cc[j][3]};
+                if (n + 1 < NB) {                                              // the same registers take the next batch's dots (one set of 16 instead of two: 128 registers hold the pipeline)
+                    const uint2 a = qa[(n + 1) & 3][j];
+                    cc[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(((unsigned long)a.y << 32) | a.x), sb[(n + 1) & 1][j], zero, 0, 0, 0);
+                }
+                const float4 dw = sw[n & 1][j];
+                const float4 mw = Q81 ? sm[n & 1][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float xdj = j == 0 ? xd[n & 1].x : j == 1 ? xd[n & 1].y : j == 2 ? xd[n & 1].z : xd[n & 1].w;
+                const float xsj = !Q81 ? 0.0f : j == 0 ? xs[n & 1].x : j == 1 ? xs[n & 1].y : j == 2 ? xs[n & 1].z : xs[n & 1].w;
+                acc[0] = __fadd_rn(acc[0], mfma_block_term<WT>(cf[0], dw.x, mw.x, xdj, xsj));
+                acc[1] = __fadd_rn(acc[1], mfma_block_term<WT>(cf[1], dw.y, mw.y, xdj, xsj));
+                acc[2] = __fadd_rn(acc[2], mfma_block_term<WT>(cf[2], dw.z, mw.z, xdj, xsj));
+                acc[3] = __fadd_rn(acc[3], mfma_block_term<WT>(cf[3], dw.w, mw.w, xdj, xsj));
+            }
+            // the step's arithmetic is DONE in the step: without a side effect that names the sums, instruction selection sinks all of a one-phase kernel's
+            // cvt / mul / add behind its last MFMA (the sums are only used by the epilogue) and every block's integer dots and scales stay live -- spills
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        }
+    };
+#pragma unroll 1
+    for (int ph = 0; ph < NPH - 1; ph++) phase(ph, std::false_type{});
+    phase(NPH - 1, std::true_type{});
+
+    MFMA_STAMP(2); MFMA_STAMP(5);
     if (EPI == EPI_GELU_Q8) {
         __syncthreads();                                                        // everyone is done reading the activation area
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
+        {
             float4 v;
-            v.x = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.x, acc[t][0]))]); v.y = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.y, acc[t][1]))]);
-            v.z = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.z, acc[t][2]))]); v.w = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.w, acc[t][3]))]);
-            *reinterpret_cast<float4 *>(s_tail + (16 * t + li) * 64 + wave * 16 + 4 * g) = v;
+            v.x = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.x, acc[0]))]); v.y = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.y, acc[1]))]);
+            v.z = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.z, acc[2]))]); v.w = h2f(p.gelu_tab[f2h(__fadd_rn(e_bias.w, acc[3]))]);
+            *reinterpret_cast<float4 *>(s_tail + li * 64 + wave * 16 + 4 * g) = v;
         }
         __syncthreads();
         // the workgroup's 64 rows are two Q8 blocks of fc2's activation row per column: quantize_row_q8_0 / _q8_1,
         // a half-wave per (column, block)
-        for (int u = wave * 2 + (lane >> 5); u < 2 * NC; u += 8) {
+        for (int u = wave * 2 + (lane >> 5); u < 32; u += 8) {
             const int c = u >> 1, half = u & 1;
             if (col0 + c >= p.N) continue;
             const float v1 = s_tail[c * 64 + half * 32 + (lane & 31)];
@@ -338,36 +338,34 @@ __global__ __launch_bounds__(256) void matmul_mfma_kernel(const MatvecParams p, 
             const size_t blk = (size_t)(col0 + c) * (M / 32) + blockIdx.x * 2 + half;   // column-major [N][d_ff/32]
             p.oq_q[blk * 32 + (lane & 31)] = (int8_t)q;
             if ((lane & 31) == 0) {
-                if (TI::q81) { p.oq_d[blk] = d; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
+                if (Q81) { p.oq_d[blk] = d; p.oq_s[blk] = __float_as_uint(__fmul_rn((float)isum, d)); }
                 else { p.oq_d[blk] = h2f(f2h(d)); p.oq_s[blk] = (uint32_t)isum; }
             }
         }
         return;
     }
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        if (!(col_ok[t] && tile_ok)) continue;
-        const int col = colv[t];
-        if (EPI == EPI_QKV) {
-            float4 v;
-            v.x = __fadd_rn(e_bias.x, acc[t][0]); v.y = __fadd_rn(e_bias.y, acc[t][1]); v.z = __fadd_rn(e_bias.z, acc[t][2]); v.w = __fadd_rn(e_bias.w, acc[t][3]);
-            const int which = orow / K, rr = orow - which * K;             // d_model == K for the q/k/v projection
-            if (which == 0) {
-                v.x = __fmul_rn(v.x, p.q_scale); v.y = __fmul_rn(v.y, p.q_scale); v.z = __fmul_rn(v.z, p.q_scale); v.w = __fmul_rn(v.w, p.q_scale);
-                *reinterpret_cast<float4 *>(p.q_out + (size_t)col * K + rr) = v;
-            } else {
-                float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq[t] * p.kv_seq_stride : 0);
-                const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);       // head-major cache: [H][P][dk]; 4 | dk
-                *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast[t]) << p.dk_log2) + dd) = v;
-            }
-        } else if (EPI == EPI_RESID) {
-            float4 v;
-            v.x = __fadd_rn(__fadd_rn(acc[t][0], e_bias.x), e_res[t].x); v.y = __fadd_rn(__fadd_rn(acc[t][1], e_bias.y), e_res[t].y);
-            v.z = __fadd_rn(__fadd_rn(acc[t][2], e_bias.z), e_res[t].z); v.w = __fadd_rn(__fadd_rn(acc[t][3], e_bias.w), e_res[t].w);
-            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = v;
+    int t3 = threadIdx.x; asm volatile("" : "+v"(t3));                          // (as above)
+    const int orow = (int)(blockIdx.x * 4 + (t3 >> 6)) * 16 + ((t3 >> 2) & 12), col = col0 + (t3 & 15);
+    if (!(col < p.N && orow < M)) return;
+    if (EPI == EPI_QKV) {
+        float4 v;
+        v.x = __fadd_rn(e_bias.x, acc[0]); v.y = __fadd_rn(e_bias.y, acc[1]); v.z = __fadd_rn(e_bias.z, acc[2]); v.w = __fadd_rn(e_bias.w, acc[3]);
+        const int which = orow / K, rr = orow - which * K;                 // d_model == K for the q/k/v projection
+        if (which == 0) {
+            v.x = __fmul_rn(v.x, p.q_scale); v.y = __fmul_rn(v.y, p.q_scale); v.z = __fmul_rn(v.z, p.q_scale); v.w = __fmul_rn(v.w, p.q_scale);
+            *reinterpret_cast<float4 *>(p.q_out + (size_t)col * K + rr) = v;
         } else {
-            *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            float *cache = ((which == 1) ? p.kcache : p.vcache) + (p.seq ? (size_t)e_seq * p.kv_seq_stride : 0);
+            const int hh = rr >> p.dk_log2, dd = rr & (p.dk - 1);           // head-major cache: [H][P][dk]; 4 | dk
+            *reinterpret_cast<float4 *>(cache + (((size_t)hh * p.P + e_npast) << p.dk_log2) + dd) = v;
         }
+    } else if (EPI == EPI_RESID) {
+        float4 v;
+        v.x = __fadd_rn(__fadd_rn(acc[0], e_bias.x), e_res.x); v.y = __fadd_rn(__fadd_rn(acc[1], e_bias.y), e_res.y);
+        v.z = __fadd_rn(__fadd_rn(acc[2], e_bias.z), e_res.z); v.w = __fadd_rn(__fadd_rn(acc[3], e_bias.w), e_res.w);
+        *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = v;
+    } else {
+        *reinterpret_cast<float4 *>(p.out + (size_t)col * p.ldo + orow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
