@@ -838,6 +838,13 @@ __host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
 // shortest) per workgroup for perfect balance 55 us (half the waves per SIMD); register double-buffering of the operands under
 // the 128-register bound spills (262 us).  The instruction stream itself (v_pk_mul_f32 + 2 v_cvt_f64_f32 + 2 v_add_f64 per two
 // products) costs 8.5-9.2 SIMD cycles per wave-MAC in isolation (tools/microbench10): ~17 us for this layer if nothing waited.
+// ATTN_STAMPS (tools/microbench23.hip only): wave 0 of every workgroup stamps the shader clock at the phase borders (0 entry, 1 scores done, 2 softmax done, 3 PV loop done,
+// 4 end) and the 100 MHz wall clock at entry / end (5, 6); 7: XCC_ID << 32 | HW_ID
+#ifdef ATTN_STAMPS
+#define ATTN_STAMP(k) do { if (threadIdx.x == 0) p.tstamp[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = ((k) == 5 || (k) == 6) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
 template <int G>
 __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
     constexpr int DK = 64, NW = 8;
@@ -859,6 +866,10 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
     const int ny = (int)gridDim.y, yb = (int)blockIdx.y, nhalf = (ny + 1) / 2;
     const int i0 = ((yb < nhalf) ? ny - 1 - yb : yb - nhalf) * G;
 
+    ATTN_STAMP(0); ATTN_STAMP(5);
+#ifdef ATTN_STAMPS
+    if (threadIdx.x == 0) p.tstamp[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
     // queries of this tile -> LDS (row-major), 4 floats per thread of the first four waves
     if (tid < 256) {
         const int q = tid >> 4, d4 = tid & 15;
@@ -921,6 +932,7 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
+    ATTN_STAMP(1);
 
     // ---- softmax (ggml_soft_max: fp16-table exp, double row sum, p = fl(e * (float)(1/sum))) ----
     {
@@ -959,6 +971,7 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
         for (int j = slot; j < Tmax; j += 32) S[(size_t)j * G + q] = (j < Tw) ? __fmul_rn(S[(size_t)j * G + q], inv) : 0.0f;
     }
     __syncthreads();
+    ATTN_STAMP(2);
 
     // ---- PV: wave = key slice (j mod 8), lane = (4 queries, 4 dims) ----
     double acc[4][4];
@@ -990,6 +1003,7 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
             }
         }
     }
+    ATTN_STAMP(3);
     __syncthreads();                                      // every read of S is done: the area becomes pvp
     {
         const int qg = lane >> 4, dg = lane & 15;
@@ -1012,6 +1026,7 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
             store_head_output(p, i0 + q, h, lane, (float)(t0 + t1), p.oq_q != nullptr);
         }
     }
+    ATTN_STAMP(4); ATTN_STAMP(6);
 }
 
 // (A matrix-core version of this contraction -- v_mfma_f32_16x16x4_f32 for QK^T and PV -- was built in round 1 and removed in

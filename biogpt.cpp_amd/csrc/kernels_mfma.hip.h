@@ -283,22 +283,58 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
                 if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc2);
                 if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc2 * p.ldr + orc2);
             }
+            // The arithmetic of the step in stages that the scheduler may not mix (sched_barrier): inside a stage every instruction is independent of its neighbours
+            // (left to itself the compiler walks block by block -- cvt, mul, mul, add back to back, each waiting out the latency of the one before).
+            float t[CH][4];
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                const float cf[4] = {(float)cc[j][0], (float)cc[j][1], (float)cc[j][2], (float)cc[j][3]};
-                if (n + 1 < NB) {                                              // the same registers take the next batch's dots (one set of 16 instead of two: 128 registers hold the pipeline)
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) t[j][r] = (float)cc[j][r];          // stage 1: the 16 conversions; the dots' registers are free
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {                                      // stage 2: the next batch's MFMAs, one per four first products
+                if (n + 1 < NB) {
                     const uint2 a = qa[(n + 1) & 3][j];
                     cc[j] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(((unsigned long)a.y << 32) | a.x), sb[(n + 1) & 1][j], zero, 0, 0, 0);
                 }
                 const float4 dw = sw[n & 1][j];
-                const float4 mw = Q81 ? sm[n & 1][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float xdj = j == 0 ? xd[n & 1].x : j == 1 ? xd[n & 1].y : j == 2 ? xd[n & 1].z : xd[n & 1].w;
+                const float dwr[4] = {dw.x, dw.y, dw.z, dw.w};
+                if (WT == W_Q4_0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t[j][r] = __fmul_rn(t[j][r], dwr[r]);          // (dot * d_w) ...
+                } else {                                                        // d_w * d_x first: both products here, four apart (16 more registers if they waited for stage 3)
+                    float dx[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dx[r] = __fmul_rn(dwr[r], xdj);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t[j][r] = (WT == W_Q8_0) ? __fmul_rn(t[j][r], dx[r]) : __fmul_rn(dx[r], t[j][r]);   // dot * (d_w d_x) / (d_w d_x) * dot
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {                                      // stage 3: Q4_0's second product; the min term of Q4_1 / Q5_1
                 const float xdj = j == 0 ? xd[n & 1].x : j == 1 ? xd[n & 1].y : j == 2 ? xd[n & 1].z : xd[n & 1].w;
                 const float xsj = !Q81 ? 0.0f : j == 0 ? xs[n & 1].x : j == 1 ? xs[n & 1].y : j == 2 ? xs[n & 1].z : xs[n & 1].w;
-                acc[0] = __fadd_rn(acc[0], mfma_block_term<WT>(cf[0], dw.x, mw.x, xdj, xsj));
-                acc[1] = __fadd_rn(acc[1], mfma_block_term<WT>(cf[1], dw.y, mw.y, xdj, xsj));
-                acc[2] = __fadd_rn(acc[2], mfma_block_term<WT>(cf[2], dw.z, mw.z, xdj, xsj));
-                acc[3] = __fadd_rn(acc[3], mfma_block_term<WT>(cf[3], dw.w, mw.w, xdj, xsj));
+                const float4 mw = Q81 ? sm[n & 1][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float mwr[4] = {mw.x, mw.y, mw.z, mw.w};
+                if (WT == W_Q4_0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t[j][r] = __fmul_rn(t[j][r], xdj);             // ... * d_x
+                }
+                if (Q81) {
+                    float ms[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) ms[r] = __fmul_rn(mwr[r], xsj);                // m_w * s_x
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t[j][r] = __fadd_rn(t[j][r], ms[r]);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; j++)                                        // stage 4: the sums, in block order (the one true dependence across blocks)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = __fadd_rn(acc[r], t[j][r]);
             // the step's arithmetic is DONE in the step: without a side effect that names the sums, instruction selection sinks all of a one-phase kernel's
             // cvt / mul / add behind its last MFMA (the sums are only used by the epilogue) and every block's integer dots and scales stay live -- spills
             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
