@@ -84,6 +84,7 @@ SYMBOLS = [
     ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
     ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_chunk_launches", C.c_int64, [_P]),
+    ("biogpt_hip_lineage_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
@@ -358,6 +359,13 @@ class BiogptModel:
         if lib().biogpt_hip_resident_stats(self._h, out) != 0:
             raise BiogptError(_err())
         return dict(hits=int(out[0]), misses=int(out[1]), streak=int(out[2]), need=int(out[3]))
+
+    def lineage_stats(self):
+        """{graph_evals, stale_rows}: single-token evals replayed as captured five-launch steps / rows found to be another call's and repeated (biogpt_hip_lineage_stats)."""
+        out = (C.c_int64 * 2)()
+        if lib().biogpt_hip_lineage_stats(self._h, out) != 0:
+            raise BiogptError(_err())
+        return dict(graph_evals=int(out[0]), stale_rows=int(out[1]))
 
     def synchronize(self):
         if lib().biogpt_hip_synchronize(self._h) != 0:

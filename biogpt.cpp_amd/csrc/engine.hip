@@ -172,7 +172,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -217,6 +217,9 @@ struct EngineOptions {
         xpipe_fault = get("BIOGPT_HIP_XPIPE_FAULT", 0);   // test hook: the first pipelined launch finds a 33rd workgroup on XCD 0 and drains
         xpipe = get("BIOGPT_HIP_XPIPE", 1);             // the XCD-pipelined single-launch decode step (kernels_xpipe.hip.h)
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
+        graph_contended = get("BIOGPT_HIP_GRAPH_CONTENDED", 0);   // test switch: replay the five-launch eval graph even while ANOTHER context holds the pipeline slot (the arrangement of profiles/two_contexts_r4.txt)
+        fault_stale = get("BIOGPT_HIP_FAULT_STALE", 0);           // test switch: every k-th replayed eval starts from the PREVIOUS mailbox slot (the stale-row symptom, injected)
+        xpipe_as_res = get("BIOGPT_HIP_XPIPE_AS_RES", 0);          // measurement only: ordinary pipelined launches through the RES instantiations (tests/test_gpu_resident.py)
         eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
     }
     int mfma_min(int dflt) const { return mfma_min_cols >= 0 ? mfma_min_cols : dflt; }
@@ -303,6 +306,12 @@ struct biogpt_hip_ctx {
     uint8_t *topk_host = nullptr;          // pinned, device-visible [64 floats][64 ints][count]: biogpt_hip_eval_topk's kernel writes it directly
     int32_t *mbox_host = nullptr;          // pinned ring of 64 x {n_past, causal, token}: inputs of the graph-replayed single-token evals
     uint32_t *mbox_ctr = nullptr;          // device: replays consumed
+    uint32_t *seq_dev = nullptr;           // device [4]: lineage words of a replayed single-token eval (kernels.hip.h, SEQ_*)
+    uint32_t call_seq = 0;                 // host: sequence number of the last replayed eval (never 0)
+    uint32_t dev_stamp_expect = 0; int32_t dev_stamp_tok = 0, dev_stamp_n_past = 0;   // the same for a row left on the device (biogpt_hip_eval_device + biogpt_hip_read_logits)
+    uint32_t stamp_expect = 0;             // != 0: the pinned row of the eval in flight must carry this number (five-launch graph, form 1)
+    int64_t stale_rows = 0, graph_evals = 0;   // rows found to be another call's and repaired / single-token evals replayed as five-launch graphs
+    bool plain_inflight = false;           // (guarded by g_xp_mu) five-launch graphs of this context may be in flight: no OTHER context takes the pipeline slot meanwhile
     uint32_t mbox_sent = 0, mbox_synced = 0;
     int unsynced_from = -1;                // position of the first single-token eval enqueued since the stream was last synchronised (-1: none): what a tripped pipeline may have spoiled
     int lm_blocks = 0;
@@ -748,7 +757,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         xp.st = c->state;
         xp.tok_emb = dev_matrix(c, c->plan.embed_tokens); xp.pos_emb = dev_matrix(c, c->plan.embed_pos);
         xp.embed_scale = sqrtf((float)D);
-        xp.tok_src = tok_src;
+        xp.tok_src = tok_src; xp.as_res = c->opt.xpipe_as_res;
         xp.pmax_val = c->pmax_val; xp.pmax_idx = c->pmax_idx; xp.nparts = lm_parts;
         xp.n_positions = P; xp.n_vocab = V;
         xp.eps = 1e-5f; xp.q_scale = 1.0f / sqrtf(64.0f);
@@ -816,6 +825,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         f2.W2 = dev_matrix(c, L.fc2); f2.aq_q = c->aq_q[1]; f2.aq_d = c->aq_d[1]; f2.aq_s = c->aq_s[1];
         f2.bias = dev_vec(c, L.fc2_b); f2.resid = c->x1; f2.out = c->x;
         f2.tstamp = ts ? ts + 64 : nullptr; f2.wall = wall; f2.wall_slot = 5 * l + 4;
+        f2.seq = (l == hp.n_layer - 1) ? c->seq_dev : nullptr;
         hipError_t e = hipErrorInvalidValue;
         switch (wt) {
             case T_Q4_0: e = launch_decode_layer<bgk::W_Q4_0>(c, a, at, op, f1, f2, only); break;
@@ -837,6 +847,7 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
         p.ldx = D; p.ldo = V; p.x = c->x; p.N = 1; p.out = c->logits;
         p.pmax_val = c->pmax_val; p.pmax_idx = c->pmax_idx;
         p.st_adv = c->state; p.adv = advance;
+        p.lineage = c->seq_dev;
         int lm_grid = 0;
         HIP_TRY(false, (launch_mv<bgk::PRO_LN, bgk::EPI_LOGITS>(p, s, c->stream, &lm_grid)));
         if (lm_grid != lm_parts) BG_FAIL(false, "internal: lm_head grid %d != expected %d", lm_grid, lm_parts);
@@ -1344,6 +1355,8 @@ void destroy(biogpt_hip_ctx *c) {
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->mbox_host) (void)hipHostFree(c->mbox_host);
     if (c->mbox_ctr) (void)hipFree(c->mbox_ctr);
+    if (c->seq_dev) (void)hipFree(c->seq_dev);
+    plain_graph_end(c);
     for (void *p : {(void *)c->bk, (void *)c->bv, (void *)c->seq, (void *)c->seq_gen, (void *)c->cols}) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1663,10 +1676,29 @@ static int eval_topk_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n,
     hipLaunchKernelGGL(bgk::topk_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->hp.n_vocab, k, ctx->pmax_val, ctx->lm_blocks,
                        out_val, out_idx, out_idx + 64);
     HIP_TRY(-2, hipGetLastError());
+    uint32_t *const got = (ctx->dev_stamp_expect != 0 && ctx->mbox_host) ? reinterpret_cast<uint32_t *>(ctx->mbox_host + 64 * 8) + 1 : nullptr;
+    if (got) HIP_TRY(-2, hipMemcpyAsync(got, ctx->seq_dev + bgk::SEQ_LM_HEAD, 4, hipMemcpyDeviceToHost, ctx->stream));   // the device row's lineage (a replayed five-launch step)
     // low-latency wait: poll the stream instead of sleeping on it (the caller is blocked on this token anyway)
     if (!poll_stream(ctx)) return -2;
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
+    if (got) {
+        const uint32_t want = ctx->dev_stamp_expect;
+        ctx->dev_stamp_expect = 0;
+        if (*got != want) {      // the row is another call's: the call again on eager launches, the selection again
+            ctx->stale_rows++;
+            if (ctx->opt.verbose) fprintf(stderr, "biogpt_hip[%p]: the replayed eval at position %d left the row of call %u instead of %u on the device: repeated on eager launches\n", (void *)ctx, n_past, *got, want);
+            uint32_t *const fix = reinterpret_cast<uint32_t *>(ctx->mbox_host + 64 * 8);
+            *fix = ctx->mbox_sent;
+            HIP_TRY(-2, hipMemcpyAsync(ctx->mbox_ctr, fix, 4, hipMemcpyHostToDevice, ctx->stream));
+            if (!upload_state(ctx, tokens, n, n_past) || !enqueue_forward(ctx, n, false, n_past + n)) return -2;
+            hipLaunchKernelGGL(bgk::topk_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->logits, ctx->hp.n_vocab, k, ctx->pmax_val, ctx->lm_blocks,
+                               out_val, out_idx, out_idx + 64);
+            HIP_TRY(-2, hipGetLastError());
+            if (!poll_stream(ctx)) return -2;
+            if (!xpipe_check(ctx)) return -2;
+        }
+    }
     const float *hv = reinterpret_cast<const float *>(ctx->topk_host);
     const int32_t *hi = reinterpret_cast<const int32_t *>(ctx->topk_host + 64 * 4);
     if (hi[64] == k) {
@@ -1758,8 +1790,36 @@ int biogpt_hip_read_logits(biogpt_hip_ctx *ctx, float *out) {
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
     HIP_TRY(-2, hipMemcpyAsync(out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *const got = ctx->mbox_host ? reinterpret_cast<uint32_t *>(ctx->mbox_host + 64 * 8) + 1 : nullptr;
+    if (ctx->dev_stamp_expect != 0 && got) HIP_TRY(-2, hipMemcpyAsync(got, ctx->seq_dev + bgk::SEQ_LM_HEAD, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
-    return xpipe_check(ctx) ? 0 : -2;
+    ctx->mbox_synced = ctx->mbox_sent;
+    if (!xpipe_check(ctx)) return -2;
+    if (ctx->dev_stamp_expect != 0 && got) {
+        // the device row of a replayed five-launch eval (biogpt_hip_eval_device): the same lineage check as eval_once's, the same repair
+        const uint32_t want = ctx->dev_stamp_expect;
+        ctx->dev_stamp_expect = 0;
+        if (*got != want) {
+            ctx->stale_rows++;
+            if (ctx->opt.verbose) fprintf(stderr, "biogpt_hip[%p]: the replayed eval at position %d left the row of call %u instead of %u on the device: repeated on eager launches\n", (void *)ctx, ctx->dev_stamp_n_past, *got, want);
+            uint32_t *const fix = reinterpret_cast<uint32_t *>(ctx->mbox_host + 64 * 8);
+            *fix = ctx->mbox_sent;
+            HIP_TRY(-2, hipMemcpyAsync(ctx->mbox_ctr, fix, 4, hipMemcpyHostToDevice, ctx->stream));
+            const int32_t tok = ctx->dev_stamp_tok;
+            if (!upload_state(ctx, &tok, 1, ctx->dev_stamp_n_past) || !enqueue_forward(ctx, 1, false, ctx->dev_stamp_n_past + 1)) return -2;
+            HIP_TRY(-2, hipMemcpyAsync(out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
+            if (!xpipe_check(ctx)) return -2;
+        }
+    }
+    return 0;
+}
+
+// {single-token evals replayed as captured five-launch steps, rows found to be another call's and repeated} (kernels.hip.h: SEQ_*)
+int biogpt_hip_lineage_stats(biogpt_hip_ctx *ctx, int64_t *out2) {
+    if (!ctx || !out2) BG_FAIL(-1, "null argument");
+    out2[0] = ctx->graph_evals; out2[1] = ctx->stale_rows;
+    return 0;
 }
 
 int biogpt_hip_synchronize(biogpt_hip_ctx *ctx) {
@@ -1798,6 +1858,25 @@ static int eval_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, int3
     if (!poll_stream(ctx)) return -2;   // poll: the caller is blocked on this token anyway
     ctx->mbox_synced = ctx->mbox_sent;
     if (!xpipe_check(ctx)) return -2;
+    if (in_graph && ctx->stamp_expect != 0) {
+        // the row of a replayed five-launch graph carries the sequence number its FIRST node fetched, forwarded by the last layer and the lm_head as they started: any
+        // other number means that the row is not this call's (profiles/two_contexts_r4.txt, profiles/stale_row_r5.txt).  Repair: the device's replay counter is put
+        // right and the call is repeated on eager launches (same token, same position: the K / V row is written again with the same values).
+        const uint32_t got = reinterpret_cast<const uint32_t *>(ctx->logits_host)[host_stamp_index(ctx)];
+        const uint32_t want = ctx->stamp_expect;
+        ctx->stamp_expect = 0;
+        if (got != want) {
+            ctx->stale_rows++;
+            if (ctx->opt.verbose) fprintf(stderr, "biogpt_hip[%p]: the replayed eval at position %d returned the row of call %u instead of %u: repeated on eager launches\n", (void *)ctx, n_past, got, want);
+            uint32_t *const fix = reinterpret_cast<uint32_t *>(ctx->mbox_host + 64 * 8);
+            *fix = ctx->mbox_sent;
+            HIP_TRY(-2, hipMemcpyAsync(ctx->mbox_ctr, fix, 4, hipMemcpyHostToDevice, ctx->stream));
+            if (!upload_state(ctx, tokens, n, n_past) || !enqueue_forward(ctx, n, false, n_past + n)) return -2;
+            HIP_TRY(-2, hipMemcpyAsync(ctx->logits_host, ctx->logits, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (!poll_stream(ctx)) return -2;
+            if (!xpipe_check(ctx)) return -2;
+        }
+    }
     ctx->row_cur = ctx->logits_host;
     if (logits_out) std::memcpy(logits_out, ctx->logits_host, bytes);
     return 0;
@@ -1874,7 +1953,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
-    const bool use_graph = ctx->opt.no_graph == 0;
+    bool use_graph = ctx->opt.no_graph == 0;
     if ((ctx->opt.dbg & 128) && !ctx->tstamp) {      // profiling builds: stage stamps of the pipelined launches (tools/tail_timeline.py)
         HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
         HIP_TRY(-2, hipMemset(ctx->tstamp, 0, (size_t)4 << 20));
@@ -1889,6 +1968,11 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
             pl_bucket[b] = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;
             if (!ensure_graph(ctx, 1, b, pl_bucket[b])) return -2;
         }
+    if (use_graph) {   // captured five-launch steps are not replayed beside ANOTHER context's persistent launch (plain_graph_begin): such a run takes eager steps
+        bool any_plain = false;
+        for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++) any_plain = any_plain || pl_bucket[b] == 0;
+        if (any_plain && !plain_graph_begin(ctx)) use_graph = false;
+    }
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -2062,7 +2146,7 @@ static int generate_greedy_batch_once(biogpt_hip_ctx *ctx, const int32_t *prompt
         HIP_TRY(false, hipGetLastError());
         return true;
     };
-    const bool use_graph = ctx->opt.no_graph == 0;
+    const bool use_graph = ctx->opt.no_graph == 0 && (pl != 0 || plain_graph_begin(ctx));      // (a captured five-launch step is not replayed beside another context's persistent launch)
     if (use_graph) {
         for (int b = graph_bucket(max_len + 1); b <= graph_bucket(std::max(1, max_len + n_predict - 1)); b++) {
             if (ctx->graph_batch[6 * pl + b]) continue;
@@ -2146,7 +2230,8 @@ int biogpt_hip_generate_greedy_batch(biogpt_hip_ctx *ctx, const int32_t *prompts
 int biogpt_hip_debug_stamps(biogpt_hip_ctx *ctx, size_t offset, size_t count, unsigned long long *out) {
     clear_error();
     if (!ctx || !out) BG_FAIL(-1, "null argument");
-    if (!ctx->tstamp || (offset + count) * 8 > ((size_t)4 << 20)) BG_FAIL(-1, "no stamps (profiling build with BIOGPT_HIP_DBG=128 only)");
+    const size_t cap = ((size_t)4 << 20) / 8;                 // stamps in the buffer; checked without a sum that could wrap
+    if (!ctx->tstamp || offset > cap || count > cap - offset) BG_FAIL(-1, "no stamps (profiling build with BIOGPT_HIP_DBG=128 only)");
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
     HIP_TRY(-2, hipStreamSynchronize(ctx->stream));

@@ -237,6 +237,7 @@ struct MatvecParams {
     // producer-quantized activations (single-token fast chain): 32 int8 per block + scale + block sum
     const int8_t *aq_q; const float *aq_d; const uint32_t *aq_s;   // PRO_Q8IN input
     int8_t *oq_q; float *oq_d; uint32_t *oq_s;                     // EPI_GELU_Q8 output
+    uint32_t *lineage;   // EPI_LOGITS, single-token eval graphs: the call's lineage words (SEQ_* below); null: off
     DevState *st_adv;    // EPI_LOGITS, fused decode step: block 0 moves the device-side position / id count on by `adv`
     int32_t adv;         //   after the step (the sampler runs in the next step's first kernel); null / 0: off
     double inv_k;        // 1.0 / K
@@ -244,6 +245,15 @@ struct MatvecParams {
     unsigned long long *tstamp;  // profiling: [2][grid][8] shader-clock stamps when dbg & 32
     int32_t dbg;         // profiling ablations (bench only; 0 in production): 1 skip x loads, 2 skip LN stats, 4 skip chain, 8 skip weights, 16 skip epilogue table
 };
+
+// Lineage of a replayed single-token eval (the five-launch layer captured as a graph; biogpt_hip_eval): the graph's FIRST node writes the call's sequence number, the
+// LAST layer's last kernel forwards it when it starts, the lm_head kernel forwards that, the row's copy to pinned host memory carries it out.  A kernel that ran before its
+// predecessor forwards the previous call's number: the host sees a row that is not this call's and repeats the call on eager launches (profiles/two_contexts_r4.txt: a
+// replayed graph returned the row of the call before, bit for bit, beside another context's draining persistent kernel).
+enum : int { SEQ_FETCHED = 0, SEQ_LAST_LAYER = 1, SEQ_LM_HEAD = 2 };
+__device__ __forceinline__ void seq_forward(uint32_t *seq, int to) {
+    if (seq != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) seq[to] = seq[to - 1];
+}
 
 template <int WT> struct TypeInfo;
 template <> struct TypeInfo<W_F32>  { static constexpr bool quant = false; static constexpr int qbytes = 16; static constexpr int elems = 4; static constexpr bool q81 = false; };
@@ -447,6 +457,7 @@ template <int WT, int PRO, int EPI, int NC, int KCH, bool SEQ = true>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
     using TI = TypeInfo<WT>;
     BG_STAMP(0);
+    if (EPI == EPI_LOGITS) seq_forward(p.lineage, SEQ_LM_HEAD);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.W.K, M = p.W.M;
     const int nblk_pad = K / QK + 4;

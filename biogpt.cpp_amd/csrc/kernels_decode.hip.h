@@ -599,6 +599,7 @@ struct DecFc2Params {
     unsigned long long *tstamp;
     unsigned long long *wall;
     int32_t wall_slot;
+    uint32_t *seq;             // last layer only: the eval's lineage words (kernels.hip.h, SEQ_*); null: off
 };
 
 constexpr int DEC_PS2 = 132;   // 128 block terms + 4
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(NW * 64) void dec_fc2_kernel(const DecFc2Params p) 
     const int row = blockIdx.x * NW + wave;
     DEC_STAMP(0);
     DEC_WALL(0);
+    seq_forward(p.seq, SEQ_LAST_LAYER);
     Unit<WT> wq[2];
     uint32_t ax[2][8];
     float axd[2];
@@ -740,7 +742,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *logits, int V, 
 
 // biogpt_hip_eval's logits row: written by the device straight into pinned host memory as the last node of the replayed
 // graph (a device-to-host copy command behind the graph costs 60-120 us of extra latency per token on this runtime)
-__global__ __launch_bounds__(256) void logits_to_host_kernel(const float *src, float *dst_pinned, int n) {
+__global__ __launch_bounds__(256) void logits_to_host_kernel(const float *src, float *dst_pinned, int n, const uint32_t *seq, int stamp_at) {
+    if (seq != nullptr && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(dst_pinned)[stamp_at] = seq[SEQ_LM_HEAD];   // the row's lineage (kernels.hip.h)
     const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) *reinterpret_cast<float4 *>(dst_pinned + i) = *reinterpret_cast<const float4 *>(src + i);
     else for (int j = i; j < n; j++) dst_pinned[j] = src[j];
@@ -749,9 +752,10 @@ __global__ __launch_bounds__(256) void logits_to_host_kernel(const float *src, f
 // Single-token evals through the C API: the host drops {n_past, causal, token} into a ring of pinned slots and replays the
 // captured step; this first node of the graph pulls the next slot into the device state (one PCIe read instead of a copy
 // command + its blit kernel in front of every token).  ctr counts the replays; the host mirrors it.
-__global__ void fetch_state_kernel(const int32_t *mbox, uint32_t *ctr, DevState *st) {
+__global__ void fetch_state_kernel(const int32_t *mbox, uint32_t *ctr, DevState *st, uint32_t *seq) {
     const uint32_t n = *ctr;
     const int32_t *slot = mbox + (size_t)(n & 63u) * 8;
+    if (seq) seq[SEQ_FETCHED] = (uint32_t)slot[3];       // the call's sequence number: forwarded by the last layer and the lm_head, returned beside the row
     st->n_past = slot[0];
     st->n_gen = 0;
     st->causal = slot[1];

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void matvec_fast_kernel(const MatvecParams p) 
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "fast path is for the block-quantized types");
     static_assert(NC == 1 || PRO == PRO_Q8IN, "multi-column fast path takes pre-quantized activations");
+    if (EPI == EPI_LOGITS) seq_forward(p.lineage, SEQ_LM_HEAD);
     constexpr int BPR = K / QK;                      // blocks per row
     constexpr int LPR = BPR < 64 ? BPR : 64;         // lanes per row
     constexpr int NIT = BPR / LPR;                   // blocks per lane per row

@@ -26,6 +26,7 @@ template <int WT>
 __global__ __launch_bounds__(512) void lm_stream_kernel(const MatvecParams p) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
+    seq_forward(p.lineage, SEQ_LM_HEAD);
     constexpr int NW = 8, NB = 3, LE = 16, LL = 8;       // block units per lane of an early / a LayerNorm wave: 4 LE + 4 LL = 96 row pairs
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
     unsigned char *const s_sc = lm_smem + (size_t)NW * 32 * DEC_PS * 4;

@@ -103,6 +103,7 @@ struct XpParams {
     // pinned mailbox slot (mbox_seq0 + tk) % 64 = {n_past, causal, token, seq} that the NEXT biogpt_eval() call fills -- workgroup 0 of XCD 0 waits for it,
     // at most idle_ticks of the 100 MHz clock -- and every lm_head workgroup reports its share of the host logits row with a word in done_host
     int32_t dual;              // contexts of 257 .. 512 keys (every launch form): 1 = dec_xpipe_kernel's two-workgroups-per-head variant (needs gran_l), 0 = kernels_xlong.hip.h
+    int32_t as_res;            // measurement only (BIOGPT_HIP_XPIPE_AS_RES=1, read with the context's options): ordinary launches go through the RES instantiations with resident = 0
     int32_t resident;
     int32_t res_tok0, res_n_past0;   // token 0 of a resident launch and its position
     int32_t res_dbg;                 // measurement only (BIOGPT_HIP_RES_DBG): 1 completion word without waiting for the row stores, 2 no sleep in the mailbox poll, 4 no row store
@@ -544,6 +545,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "18-30 weight units per lane must fit the register file (Q8_0: 9 registers per unit: split layers)");
     static_assert(ROLE == 0 || ROLE == 1 || (ROLE == 2 && SPLIT), "0 attention head, 1 q/k/v rows, 2 (split layers) the MLP half");
+    static_assert(SPLIT || TI::q81, "the producers publish Q8_0 block sums only for Q4_1 / Q5_1 (want_sum = q81): the symmetric formats need the signed units of the split form (unit_dot_settled)");
     constexpr bool ATTN = ROLE == 0;
     constexpr bool EXPAND = SPLIT;      // units are settled (nibbles unpacked, scales converted) while they wait; Q8_0: the scale only
     constexpr bool FIRST = !SPLIT || ROLE != 2, SECOND = !SPLIT || ROLE == 2;      // which stages this workgroup runs

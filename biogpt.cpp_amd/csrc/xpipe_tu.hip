@@ -38,9 +38,8 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XpParams &x
     // workgroup's key range of the next layer (beyond) fit the 256-register budget
     if (xp.resident != 0 && t_cap > 256 && !(t_cap <= 512 && xp.dual != 0 && xp.gran_l != nullptr)) return (hipError_t)bg_xpipe_launch_long(WT, t_cap, sm, st, &xp, sizeof(xp), true);
     if (xp.resident != 0) return (hipError_t)bg_xpipe_launch_resident(WT, t_cap, sm, st, &xp, sizeof(xp));      // its own translation unit (xpipe_res_tu.hip)
-    // measurement only (BIOGPT_HIP_XPIPE_AS_RES=1): ordinary launches through the RES instantiations with resident = 0 -- what the resident form's exits cost the chain itself
-    const char *const as_res_env = getenv("BIOGPT_HIP_XPIPE_AS_RES");      // (looked up per launch: the tests switch it inside one process)
-    const bool as_res = as_res_env && as_res_env[0] == '1';
+    // measurement only (BIOGPT_HIP_XPIPE_AS_RES=1, an engine option like every other): ordinary launches through the RES instantiations with resident = 0 -- what the resident form's exits cost the chain itself
+    const bool as_res = xp.as_res != 0;
     if (as_res && t_cap <= 256) return (hipError_t)bg_xpipe_launch_resident(WT, t_cap, sm, st, &xp, sizeof(xp));
     if (t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 8, 8, 64, true>), dim3(256), dim3(512), sm, st, xp);
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xpipe_kernel<WT, 4, 8, 128, true>), dim3(256), dim3(512), sm, st, xp);

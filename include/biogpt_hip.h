@@ -306,6 +306,12 @@ int biogpt_hip_quantize_rows_device(int device, int32_t type, const float *src, 
  * loader happy, F6). */
 int biogpt_hip_write_synthetic(const char *fname, const biogpt_hip_hparams *hp, uint64_t seed);
 
+/* Single-token evals of a context that does not hold the device's pipeline slot are replayed as a captured five-launch step.  The row of such a replay carries the
+ * sequence number its first node fetched (forwarded by the last layer's last kernel and by the lm_head as they start); biogpt_hip_eval / biogpt_hip_eval_inplace /
+ * biogpt_hip_read_logits compare it with the call's and, if it is another call's, repeat the call on eager launches.  out2 = {evals replayed that way, rows repeated}.
+ * The contract behind it: the row biogpt_eval returns is the row of THIS eval (biogpt.cpp:840-844). */
+int biogpt_hip_lineage_stats(biogpt_hip_ctx *ctx, int64_t *out2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,6 +360,106 @@ def test_two_contexts_interleave_single_token_evals_on_one_device(pkg, files, mo
     r.close()
 
 
+def _load_env(pkg, path, monkeypatch, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    g = pkg.BiogptModel.load(path)
+    for k in env:
+        monkeypatch.delenv(k)
+    return g
+
+
+def test_a_stale_row_of_a_replayed_eval_is_detected_and_repaired(pkg, oracle, files, monkeypatch):
+    """The contract of biogpt.cpp:840-844: the row an eval returns is the row of THIS eval.  A single-token eval off the pipeline is a replayed graph of the five-launch
+    layer whose first node pulls {position, token, call number} from a pinned mailbox; the call number travels with the data (last layer's last kernel -> lm_head -> the
+    row's copy to the host: kernels.hip.h SEQ_*) and the host compares it.  BIOGPT_HIP_FAULT_STALE=4 makes every fourth replay start from the PREVIOUS mailbox slot -- it
+    evaluates the previous call's token again and returns that call's row, the symptom of profiles/two_contexts_r4.txt.  Every row must still be this call's (== eager
+    launches of the same kernels, and the oracle), through biogpt_hip_eval, biogpt_hip_eval_topk and biogpt_hip_eval_device + biogpt_hip_read_logits."""
+    f = _load_env(pkg, files["q4_0"], monkeypatch, BIOGPT_HIP_XPIPE=0, BIOGPT_HIP_RESIDENT=0, BIOGPT_HIP_FAULT_STALE=4)
+    r = _load_env(pkg, files["q4_0"], monkeypatch, BIOGPT_HIP_XPIPE=0, BIOGPT_HIP_RESIDENT=0, BIOGPT_HIP_NO_GRAPH=1)
+    o = oracle.OracleModel(files["q4_0"], n_threads=16)
+    prompt = [2, 900, 17, 4211, 8, 31, 77]
+    f.eval_device(prompt, 0); r.eval_device(prompt, 0); lo = o.eval(prompt, 0)
+    tok, n_past = int(lo.argmax()), len(prompt)
+    for k in range(18):
+        want = r.eval([tok], n_past)
+        if k % 3 == 0:
+            got = f.eval([tok], n_past)
+        elif k % 3 == 1:
+            f.eval_device([tok], n_past)
+            got = f.read_logits()
+        else:
+            vals, ids = f.eval_topk([tok], n_past, 5)
+            order = np.lexsort((np.arange(want.size), -want))[:5]
+            assert list(ids) == [int(v) for v in order] and (vals == want[order]).all(), ("top-k", k)
+            got = want
+        assert (got == want).all(), "call %d (position %d): the row is not this call's (max diff %g)" % (k, n_past, np.abs(got - want).max())
+        lo = o.eval([tok], n_past)
+        assert np.abs(want - lo).max() <= 1e-3 and int(want.argmax()) == int(lo.argmax())
+        tok = int(want.argmax()); n_past += 1
+    st = f.lineage_stats()
+    assert st["graph_evals"] == 18 and st["stale_rows"] == 4, st      # replays 4, 8, 12, 16 (an eval, a device row, a top-k, an eval) were sent to the previous slot; each one found and repeated
+    assert r.lineage_stats()["graph_evals"] == 0
+    f.close(); r.close()
+
+
+def test_two_contexts_with_the_graph_forced_beside_a_resident_launch(pkg, files, monkeypatch):
+    """The arrangement of profiles/two_contexts_r4.txt with the workaround switched OFF (BIOGPT_HIP_GRAPH_CONTENDED=1: the second context replays its captured five-launch
+    step although the first one holds the pipeline slot with a resident launch).  Round 3 / 4 got the previous call's row back there, silently; now a row that is not the
+    call's is found by its lineage and the call repeated: every row equals a third context's (eager launches, alone on the device).  How many rows had to be repeated on
+    this box is printed (0 = the runtime behaved; profiles/stale_row_r5.txt)."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    u = _load_env(pkg, files["q4_0"], monkeypatch, BIOGPT_HIP_GRAPH_CONTENDED=1)
+    rng = np.random.default_rng(3)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 245)]
+    g.eval_device(prompt, 0); u.eval_device(prompt, 0)
+    toks, rows_g, rows_u = [77], [], []
+    for n_past in range(246, 276):
+        a = g.eval([toks[-1]], n_past)
+        rows_g.append(a); rows_u.append(u.eval([toks[-1]], n_past))
+        toks.append(int(a.argmax()))
+    st = u.lineage_stats()
+    print("second context: %d replayed evals, %d rows repeated" % (st["graph_evals"], st["stale_rows"]))
+    assert st["graph_evals"] > 0      # the graph path was taken (the point of the switch)
+    g.close(); u.close()
+    r = _load_env(pkg, files["q4_0"], monkeypatch, BIOGPT_HIP_RESIDENT=0, BIOGPT_HIP_XPIPE=0, BIOGPT_HIP_NO_GRAPH=1)
+    r.eval_device(prompt, 0)
+    for i, n_past in enumerate(range(246, 276)):
+        t = r.eval([toks[i]], n_past)
+        assert (rows_g[i] == t).all(), ("first context", n_past)
+        assert (rows_u[i] == t).all(), ("second context", n_past)
+    r.close()
+
+
+def test_generate_beside_another_contexts_resident_launch(pkg, oracle, files, monkeypatch):
+    """generate_greedy / generate_greedy_batch of a context that cannot take the pipeline slot replayed captured five-launch steps beside the holder's live
+    resident launch -- a stale row there is a wrong arg-max fed forward.  They now take eager steps in that state (plain_graph_begin, decided under the slot's mutex):
+    the ids equal the oracle's and a lone context's."""
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    u = pkg.BiogptModel.load(files["q4_0"])
+    prompt = [2, 900, 17, 4211, 8]
+    lg = g.eval(prompt, 0)
+    n_past = len(prompt)
+    ids_u = None
+    for k in range(6):      # the first context's resident launch is live (it waits up to 1 ms for its caller) while the second one generates
+        lg = g.eval([int(lg.argmax())], n_past); n_past += 1
+        if k == 2:
+            ids_u, _ = u.generate_greedy(prompt, 40, n_batch=8)
+            ids_b, _ = u.generate_greedy_batch([prompt, prompt[:3]], 12, n_batch=8)
+    g.close(); u.close()
+    lone = _load_env(pkg, files["q4_0"], monkeypatch, BIOGPT_HIP_RESIDENT=0, BIOGPT_HIP_XPIPE=0)
+    ids_l, _ = lone.generate_greedy(prompt, 40, n_batch=8)
+    lone.close()
+    assert [int(t) for t in ids_u] == [int(t) for t in ids_l]
+    ref, _ = oracle.OracleModel(files["q4_0"], n_threads=16).generate_greedy(prompt, 12)
+    assert [int(t) for t in ids_u[:12]] == [int(t) for t in ref]
+    assert [int(t) for t in ids_b[0][:12]] == [int(t) for t in ref]
+
+
 @pytest.mark.parametrize("name", ["q4_0", "q5_1", "q8_0"])
 def test_resident_instantiations_as_ordinary_multi_token_launches(pkg, oracle, files, monkeypatch, name):
     """BIOGPT_HIP_XPIPE_AS_RES=1 (measurement switch, xpipe_tu.hip) sends ORDINARY pipelined launches -- the device-resident greedy loop's multi-token launches --
