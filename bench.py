@@ -173,6 +173,62 @@ def pmc_mfma_busy(model_path, pass_seconds):
                    "(pass time x 2.4 GHz x 1024 SIMDs); attention runs on the VALU (exact double sums, DESIGN 4.5) and counts as zero"}
 
 
+def bench_capi(args):
+    """`--replicas capi`: the single-process form of SURVEY 8(e) -- biogpt_hip_replicas_load (weights read once, one ncclBroadcast over a communicator from
+    ncclCommInitAll) and biogpt_hip_replicas_generate_greedy (a host thread and a stream per device, prompt g on device g mod N).  Same workload, same JSON line
+    (value = all devices' tokens / the wall time of the whole call, max over devices by construction)."""
+    import numpy as np
+    import _pkg
+    pkg = _pkg.load()
+    pkg.lib()
+    n = args.gpus
+    path = ensure_model(pkg, args.workdir, args.ftype, args.n_layer)
+    t0 = time.time()
+    reps = pkg.Replicas(path, list(range(n)))
+    t_load = time.time() - t0
+    hp = pkg.HParams(**pkg.BIOGPT_BASE)
+    n_predict = min(args.n_predict, hp.n_positions - 4)
+    def step(k):
+        prompts = [make_prompt(hp.n_vocab, k * n + g) for g in range(n)]
+        ids, secs = reps.generate_greedy(prompts, n_predict, n_batch=8)
+        return ids, secs
+    for w in range(args.warmup):
+        step(1000 + w)
+    t0 = time.perf_counter()
+    tokens = 0
+    for k in range(args.steps):
+        ids, _ = step(args.warmup + k)
+        tokens += sum(len(v) for v in ids)
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": "decode tokens/sec BioGPT %s n_ctx=%d" % (args.ftype.upper(), hp.n_positions), "value": round(tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8" if args.ftype.startswith("q") else args.ftype, "data": "synthetic",
+        "config": {"workload": "greedy %d-token continuation of a 4-token prompt per GPU (main.cpp loop, -b 8, --top_k 1), BioGPT-base %s, F32 KV cache, n_ctx=%d; "
+                               "1 step = 1 continuation per device" % (n_predict, args.ftype.upper(), hp.n_positions),
+                   "n_layer": args.n_layer, "n_predict": n_predict, "n_prompt": 4, "parallelism": "replicas x%d, ONE process (biogpt_hip_replicas_*)" % n,
+                   "weights": "synthetic N(0,0.02^2), seed 0x42494F47, written + quantized by the build's own tools"},
+        "load_s": round(t_load, 2),
+        "replicas": {"form": "one process, ncclCommInitAll, a host thread and a stream per device (csrc/replicas.cpp)", "ranks_seen": int(reps.count),
+                     "broadcast_ms": round(reps.broadcast_seconds * 1e3, 3), "arena_bytes": int(pkg.arena_bytes_for(hp_for(pkg, args)))},
+    }
+    reps.close()
+    try:        # RCCL writes its version banner to the C library's stdout buffer: out with it BEFORE the JSON line, which must be the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def hp_for(pkg, args):
+    hp = pkg.HParams(**pkg.BIOGPT_BASE)
+    hp.n_layer = args.n_layer
+    hp.ftype = pkg.FTYPES[args.ftype]
+    return hp
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +241,9 @@ def main():
     ap.add_argument("--workload", default="decode", choices=["decode", "prefill"],
                     help="decode = headline (configs[1]); prefill = configs[2]: 512-token prompt in chunks of n_batch=8")
     ap.add_argument("--n-prompt", type=int, default=512)
+    ap.add_argument("--replicas", default="ranks", choices=["ranks", "capi"],
+                    help="N > 1: ranks = one process per GPU under torch.distributed (RCCL), the driver's form; capi = ONE process driving biogpt_hip_replicas_* "
+                         "(ncclCommInitAll, a host thread and a stream per device) -- the other form of SURVEY 8(e), for comparison on the same lease")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded cpu_baseline sample")
@@ -192,6 +251,8 @@ def main():
 
     # `python bench.py --gpus N` with N > 1 and no launcher (no WORLD_SIZE in the environment): become the launcher.  BIOGPT_BENCH_SELF_LAUNCH=1 takes
     # this branch for N = 1 too (tests on the one-GPU box); =print shows the command and stops.
+    if args.replicas == "capi":
+        return bench_capi(args)
     forced = os.environ.get("BIOGPT_BENCH_SELF_LAUNCH", "")
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or forced in ("1", "print")):
         cmd = self_launch_command(args.gpus, sys.argv[1:])
@@ -231,6 +292,7 @@ def main():
 
     # ---- model: rank 0 loads the file; the packed arena is broadcast (RCCL over xGMI) ----------------
     t_load0 = time.time()
+    bcast_s, bcast_bytes = None, None
     if world == 1 and not force_dist:
         path = ensure_model(pkg, args.workdir, args.ftype, args.n_layer)
         model = pkg.BiogptModel.load(path, device=local_rank)
@@ -258,6 +320,7 @@ def main():
             model = pkg.BiogptModel.attach(hp, local_rank, arena_t.data_ptr(), nbytes)
         if rank == 0:
             log("bench: broadcast %.1f MiB arena in %.1f ms" % (nbytes / 2 ** 20, tb * 1e3))
+        bcast_s, bcast_bytes = tb, nbytes
     hp = model.hparams
     t_load = time.time() - t_load0
 
@@ -297,7 +360,9 @@ def main():
     model.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    report = None
     if dist is not None:
+        report = replicas.replica_report(elapsed, args.steps * (n_prompt if prefill else n_predict), torch.cuda.get_device_name(torch.cuda.current_device()), bcast_s, bcast_bytes)
         elapsed = replicas.max_over_ranks(elapsed)
 
     total_tokens = world * args.steps * (n_prompt if prefill else n_predict)
@@ -337,6 +402,8 @@ def main():
         },
         "load_s": round(t_load, 2),
     }
+    if report is not None:
+        out["replicas"] = dict(report, form="one process per GPU (torch.distributed, backend nccl = RCCL), one broadcast of the packed weight arena from rank 0")
 
     if prefill:
         chunk_calls = bool(os.environ.get("BIOGPT_BENCH_CHUNK_CALLS"))
@@ -412,6 +479,19 @@ def main():
                            "a launch moves %.1f MB, which 8 TB/s would move in %.2f us, against a measured ~1.3-1.6 us launch boundary" % (reps, nbytes / 1e6, nbytes / 8e6)),
                 "other_kernels": per,
             }
+            if quant:
+                # north_star's threshold (">= 70 % of the HBM roofline on the Q4_0 single-token decode mat-vec at d_model = 1024") on the MODEL'S OWN bytes: every block-
+                # quantized matrix of the arena (24 x {q/k/v, out_proj, fc1, fc2} + lm_head) x a resident Q8 activation of its shape in ONE launch, rows spread over the
+                # chip, two copies of the weights in turn so that the Infinity Cache cannot serve them (csrc/kernels_sweep.hip.h; SURVEY 7 "hard parts")
+                try:
+                    sw_s, sw_b, sw_chk = model.bench_sweep(reps=40)
+                    out["matvec_sweep"] = {"what": "matvec_sweep_kernel<%s>: all %d block-quantized matrices of the model (the W of SURVEY 8(d)) as independent mat-vecs in one launch; int8 block "
+                                                   "dots, block terms added in block order (the reference's arithmetic); launches alternate between two copies of the weights (2 x %.0f MB > the "
+                                                   "256 MB Infinity Cache)" % (args.ftype.upper(), 4 * hp.n_layer + 1, sw_b / 1e6),
+                                           "bytes": sw_b, "us": round(sw_s * 1e6, 2), "GBps": round(sw_b / sw_s / 1e9, 1), "frac": round(sw_b / sw_s / 1e9 / HBM_PEAK_GBS, 4),
+                                           "max_abs_diff_vs_host_recompute": sw_chk, "method": "HIP events around 40 back-to-back launches (launch gaps included)"}
+                except Exception as e:
+                    out["matvec_sweep"] = {"error": str(e)[:200]}
             if args.ftype == "q4_0":
                 # NOT a roofline answer for this model (no BASELINE config has such a matrix): the mat-vec kernel body on a
                 # 524288 x 1024 synthetic Q4_0 stream (302 MB > L2 + Infinity Cache), to show what the loop sustains per byte

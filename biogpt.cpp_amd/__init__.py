@@ -85,6 +85,7 @@ SYMBOLS = [
     ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_chunk_launches", C.c_int64, [_P]),
     ("biogpt_hip_lineage_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("biogpt_hip_bench_sweep", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
@@ -442,6 +443,13 @@ class BiogptModel:
         """Re-read the BIOGPT_HIP_* switches (they are cached at load time) and drop the captured graphs."""
         if lib().biogpt_hip_refresh_options(self._h) != 0:
             raise BiogptError(_err())
+
+    def bench_sweep(self, reps=20, which=0):
+        """(seconds per launch, algorithmic bytes per launch, max |device - host| over sampled rows) of the all-matrices mat-vec launch (biogpt_hip_bench_sweep)."""
+        secs, nbytes, chk = C.c_double(0.0), C.c_double(0.0), C.c_double(-1.0)
+        if lib().biogpt_hip_bench_sweep(self._h, int(which), int(reps), C.byref(secs), C.byref(nbytes), C.byref(chk)) != 0:
+            raise BiogptError(_err())
+        return secs.value, nbytes.value, chk.value
 
     def bench_decode(self, n_past, reps=50):
         secs = C.c_double(0.0)

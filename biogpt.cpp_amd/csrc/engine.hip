@@ -32,6 +32,7 @@
 #include "kernels_decode.hip.h"
 #include "kernels_fdecode.hip.h"
 #include "kernels_lmhead.hip.h"
+#include "kernels_sweep.hip.h"
 #include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
 #include "kernels_xcols.hip.h"   // (likewise: xcols_tu.hip)
 #include "kernels_quant.hip.h"

@@ -72,6 +72,35 @@ def sum_over_ranks(value):
     return float(t.item())
 
 
+def gather_floats(value):
+    """One float per rank, on every rank (per-rank rates in the bench line)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(o.item()) for o in out]
+
+
+def gather_strings(text):
+    """One short string per rank, on every rank (device names in the bench line)."""
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, str(text))
+    return [str(o) for o in out]
+
+
+def replica_report(elapsed_s, tokens_this_rank, device_name, broadcast_s, arena_bytes):
+    """What makes the first N > 1 bench record self-explanatory: how many ranks the communicator saw, which device each bound, each rank's own rate,
+    the broadcast's time and size.  Every rank calls it (two all-gathers); the dict is the same on all of them."""
+    import torch.distributed as dist
+    rates = gather_floats(tokens_this_rank / max(elapsed_s, 1e-12))
+    return {"ranks_seen": int(dist.get_world_size()), "backend": str(dist.get_backend()), "devices": gather_strings(device_name),
+            "per_rank_tokens_per_s": [round(r, 2) for r in rates],
+            "broadcast_ms": None if broadcast_s is None else round(broadcast_s * 1e3, 3), "arena_bytes": None if arena_bytes is None else int(arena_bytes)}
+
+
 def gather_ids(ids, max_len):
     """All ranks' generated ids on every rank: returns a [world, max_len] int32 array (padded with -1)."""
     import torch

@@ -306,6 +306,13 @@ int biogpt_hip_quantize_rows_device(int device, int32_t type, const float *src, 
  * loader happy, F6). */
 int biogpt_hip_write_synthetic(const char *fname, const biogpt_hip_hparams *hp, uint64_t seed);
 
+/* Measurement: the decode mat-vec over EVERY block-quantized matrix of the loaded model (24 x {q/k/v, out_proj, fc1, fc2} + lm_head = the W of SURVEY 8(d)) in one
+ * launch, rows spread over the chip, each against a resident Q8 activation vector of its shape; launches alternate between two copies of the weights so that the
+ * 256 MB Infinity Cache cannot serve them.  seconds_out per launch, bytes_out = SURVEY 8(d)'s algorithmic bytes per launch, check_out = max |device - host| over
+ * sampled rows (0 = bit-identical to the reference's arithmetic; -1 = format not checked).  The figure north_star's ">= 70 % of the HBM roofline on the Q4_0
+ * single-token decode mat-vec at d_model = 1024" asks for; replaces nothing of biogpt.cpp (its loop body is biogpt.cpp:705-803). */
+int biogpt_hip_bench_sweep(biogpt_hip_ctx *ctx, int which /* 0: every matrix, two copies; 1: lm_head alone, 14 copies in turn */, int reps, double *seconds_out, double *bytes_out, double *check_out);
+
 /* Single-token evals of a context that does not hold the device's pipeline slot are replayed as a captured five-launch step.  The row of such a replay carries the
  * sequence number its first node fetched (forwarded by the last layer's last kernel and by the lm_head as they start); biogpt_hip_eval / biogpt_hip_eval_inplace /
  * biogpt_hip_read_logits compare it with the call's and, if it is another call's, repeat the call on eager launches.  out2 = {evals replayed that way, rows repeated}.

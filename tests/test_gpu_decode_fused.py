@@ -235,12 +235,30 @@ def test_bench_rccl_replica_path_on_one_gpu(oracle, tmp_path, launcher):
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert "replicas x1" in out["config"]["parallelism"]
     assert "broadcast" in r.stderr                      # the arena went through the collective
+    rep = out["replicas"]                               # what makes an N > 1 record self-explanatory: ranks the communicator saw, device and rate per rank, the broadcast
+    assert rep["ranks_seen"] == 1 and rep["backend"] == "nccl" and len(rep["devices"]) == 1 and rep["devices"][0]
+    assert len(rep["per_rank_tokens_per_s"]) == 1 and rep["per_rank_tokens_per_s"][0] >= out["value"] * 0.99
+    assert rep["broadcast_ms"] > 0 and rep["arena_bytes"] > 0
     if launcher == "self":
         assert "starting 1 rank(s)" in r.stderr and "torch.distributed.run" in r.stderr
         assert "rank 0 / 1 bound cuda:0" in r.stderr and "communicator size 1" in r.stderr and "backend nccl" in r.stderr
     rec = json.load(open(dump + ".rank0"))
     ref, _ = oracle.OracleModel(rec["model"], n_threads=16).generate_greedy(rec["prompt"], 40, n_batch=8)
     assert rec["ids"] == [int(v) for v in ref]
+
+
+def test_bench_replicas_capi_on_one_gpu(tmp_path):
+    """`bench.py --replicas capi`: the SINGLE-process form of SURVEY 8(e) (biogpt_hip_replicas_*: ncclCommInitAll, one broadcast, a host thread per device) behind the
+    same JSON line, so that both forms can be compared on one lease.  One device here: the communicator has one rank."""
+    env = dict(os.environ, BIOGPT_BENCH_DIR=str(tmp_path / "work"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--replicas", "capi", "--steps", "2", "--warmup", "1", "--n-layer", "4", "--n-predict", "40"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and "ONE process" in out["config"]["parallelism"]
+    assert out["replicas"]["ranks_seen"] == 1 and out["replicas"]["broadcast_ms"] >= 0 and out["replicas"]["arena_bytes"] > 0
 
 
 def test_c_abi_replicas_single_process(pkg, oracle, files):
@@ -634,6 +652,21 @@ def test_hand_off_region_placement_does_not_change_results(pkg, files, monkeypat
     iu, _ = u.generate_greedy(toks[:5], 40, n_batch=8)
     assert list(ig) == list(iu) and u.xpipe_state() == 1
     g.close(); u.close()
+
+
+def test_matvec_sweep_over_the_models_own_matrices(pkg, base24_f32, tmp_path):
+    """biogpt_hip_bench_sweep: the decode mat-vec on every block-quantized matrix of BioGPT-base (Q4_0: 196 MB) in one launch -- the measurement behind north_star's
+    ">= 70 % of the HBM roofline" -- with its rows recomputed on the host from the arena's bytes (unit_dot_quant's expressions, block order): bit-identical."""
+    path = str(tmp_path / "q4_0.bin")
+    pkg.quantize_file(base24_f32, path, "q4_0")
+    g = pkg.BiogptModel.load(path)
+    secs, nbytes, chk = g.bench_sweep(reps=10)
+    assert chk == 0.0, chk
+    assert abs(nbytes - 195.96e6) < 0.5e6, nbytes        # 24 x (3072 + 1024 + 4096 + 1024 rows of 1024 or 4096) + 42384 x 1024 at 18 / 32 bytes + vectors
+    assert nbytes / secs > 2.0e12, "the sweep moved %.0f GB/s" % (nbytes / secs / 1e9)      # (75 % of 8 TB/s measured; the bound only catches a broken launch)
+    s1, b1, c1 = g.bench_sweep(reps=10, which=1)
+    assert c1 == 0.0 and abs(b1 - 24.6e6) < 0.3e6
+    g.close()
 
 
 def test_lm_head_bench_with_cold_weights(pkg, files):

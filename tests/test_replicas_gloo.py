@@ -29,7 +29,8 @@ def _worker(rank, world, port, q):
     allids = replicas.gather_ids(ids, 8)
     tmax = replicas.max_over_ranks(1.0 + rank)
     tot = replicas.sum_over_ranks(len(units) * 200)
-    q.put((rank, hp, int(arena.to(torch.int64).sum()), units, allids.tolist(), tmax, tot))
+    rep = replicas.replica_report(0.5 * (rank + 1), 400, "fake-device-%d" % rank, 0.0125 if rank == 0 else None, 1000)
+    q.put((rank, hp, int(arena.to(torch.int64).sum()), units, allids.tolist(), tmax, tot, rep))
     dist.destroy_process_group()
 
 
@@ -44,12 +45,16 @@ def test_two_rank_replica_plumbing():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, hp0, s0, u0, ids0, t0, tot0), (r1, hp1, s1, u1, ids1, t1, tot1) = res
+    (r0, hp0, s0, u0, ids0, t0, tot0, rep0), (r1, hp1, s1, u1, ids1, t1, tot1, rep1) = res
     assert hp0 == hp1 == [42384, 24, 16, 1024, 4096, 1024, 2, 40000]
     assert s0 == s1 and s0 > 0                       # identical arena bytes on both ranks
     assert u0 == [0, 2, 4, 6] and u1 == [1, 3, 5, 7]   # disjoint, complete cover of the 8 prompts
     assert ids0 == ids1 and ids0[0][:4] == [0, 2, 4, 6] and ids0[1][:4] == [101, 103, 105, 107]
     assert t0 == t1 == 2.0 and tot0 == tot1 == 1600.0
+    # the fields that make the first N > 1 bench record self-explanatory (bench.py puts rank 0's dict into its JSON line as "replicas")
+    assert rep0["ranks_seen"] == 2 and rep0["backend"] == "gloo" and rep0["devices"] == ["fake-device-0", "fake-device-1"] == rep1["devices"]
+    assert rep0["per_rank_tokens_per_s"] == [800.0, 400.0] == rep1["per_rank_tokens_per_s"]
+    assert rep0["broadcast_ms"] == 12.5 and rep0["arena_bytes"] == 1000 and rep1["broadcast_ms"] is None
 
 
 def test_bench_self_launch_command_line(tmp_path):
