@@ -28,7 +28,6 @@
 #include "host_common.h"
 #include "kernels.hip.h"
 #include "kernels_fast.hip.h"
-#include "kernels_mfma.hip.h"
 #include "kernels_decode.hip.h"
 #include "kernels_fdecode.hip.h"
 #include "kernels_lmhead.hip.h"
@@ -172,13 +171,12 @@ int env_int(const char *name, int dflt) {
 // Tuning / debugging switches.  Read from the environment ONCE, when a context is created (and again only on
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
-    int mv_waves, max_wgs, tree_reduce, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
+    int mv_waves, max_wgs, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
         split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
         max_wgs = get("BIOGPT_HIP_MAX_WGS", 1024);
-        tree_reduce = get("BIOGPT_HIP_TREE_REDUCE", 0);
         lm_steps = get("BIOGPT_HIP_LM_STEPS", 8);
         fast_steps = get("BIOGPT_HIP_FAST_STEPS", 1);
         no_fast = get("BIOGPT_HIP_NO_FAST", 0);
@@ -389,13 +387,10 @@ hipError_t launch_mv_kch(const bgk::MatvecParams &p, const MvShape &s, hipStream
     const int need = (PRO == bgk::PRO_LN || NC > 1) ? njj : (njj + s.nwaves - 1) / s.nwaves;  // chunks a wave holds per column
     const size_t sm = bgk::matvec_smem_bytes(WT, p.W.K, NC, s.upr, s.rpw, s.nwaves);
     const int gy = (p.N + NC - 1) / NC;
-    const bool seq = opt().tree_reduce == 0;  // default: the reference's block order (bit parity)
     if (need <= 4) {
-        if (seq) hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, true>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
-        else hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4, false>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 4>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
     } else if (need <= 16) {
-        if (seq) hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 16, true>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
-        else hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 16, false>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
+        hipLaunchKernelGGL((bgk::matvec_kernel<WT, PRO, EPI, NC, 16>), dim3(s.grid, gy), dim3(s.nwaves * 64), sm, st, p);
     } else {
         return hipErrorInvalidValue;  // K > 4096*nwaves: not a BioGPT shape
     }
@@ -490,29 +485,21 @@ hipError_t launch_chain_nc(ChainOp op, const bgk::MatvecParams &p, hipStream_t s
     return hipErrorInvalidValue;
 }
 // many columns (prompt passes, batched sequences): the same chain on the int8 matrix cores, reading the row-tiled
-// weight image (kernels_mfma.hip.h)
-template <int WT, int EPI, int K>
-hipError_t launch_mfma(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    const size_t sm = bgk::matmul_mfma_smem_bytes(K, bgk::TypeInfo<WT>::q81, EPI == bgk::EPI_GELU_Q8);
-    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>);
-    if (sm > 64 * 1024 && !t_ctx->lds_attr_done.count(fn)) {   // > 64 KB of dynamic LDS needs the opt-in attribute, per device
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) return e;
-        t_ctx->lds_attr_done.insert(fn);
-    }
-    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(bgk::mfma_threads(K)), sm, st, p, img);
-    return hipGetLastError();
-}
+// weight image (kernels_mfma.hip.h; the 25 kernels live in their own translation unit, mfma_tu.hip)
+extern "C" int bg_mfma_launch(int wt, int op, const void *params, size_t params_bytes, const void *img, size_t img_bytes, hipStream_t st);
+extern "C" int bg_mfma_retile(int wt, const void *src, size_t src_bytes, uint8_t *dq, uint8_t *ds, hipStream_t st);
 template <int WT>
 hipError_t launch_chain_mfma(ChainOp op, const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
+    int site = -1;
     switch (op) {
-        case CHAIN_QKV_Q8: return launch_mfma<WT, bgk::EPI_QKV, 1024>(p, img, st);
-        case CHAIN_OPROJ: return launch_mfma<WT, bgk::EPI_RESID, 1024>(p, img, st);
-        case CHAIN_FC1_Q8: return launch_mfma<WT, bgk::EPI_GELU_Q8, 1024>(p, img, st);
-        case CHAIN_FC2: return launch_mfma<WT, bgk::EPI_RESID, 4096>(p, img, st);
-        case CHAIN_LMHEAD_Q8: return launch_mfma<WT, bgk::EPI_LOGITS, 1024>(p, img, st);
+        case CHAIN_QKV_Q8: site = 0; break;
+        case CHAIN_OPROJ: site = 1; break;
+        case CHAIN_FC1_Q8: site = 2; break;
+        case CHAIN_FC2: site = 3; break;
+        case CHAIN_LMHEAD_Q8: site = 4; break;
         default: return hipErrorInvalidValue;
     }
+    return (hipError_t)bg_mfma_launch(WT, site, &p, sizeof(p), &img, sizeof(img), st);
 }
 template <int WT>
 hipError_t launch_chain_typed(ChainOp op, const bgk::MatvecParams &p, hipStream_t st, const bgk::DevMatrix *img) {
@@ -622,11 +609,6 @@ bgk::DevMatrix tile_matrix(const biogpt_hip_ctx *c, const MatSlot &m) {
     d.type = m.type; d.M = (int32_t)m.M; d.K = (int32_t)m.K;
     return d;
 }
-template <int WT>
-void retile_one(biogpt_hip_ctx *c, const MatSlot &m) {
-    const int64_t n = m.M * (m.K / QK);
-    hipLaunchKernelGGL((bgk::retile_kernel<WT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_matrix(c, m), c->tile_img + m.xq, c->tile_img + m.xs);
-}
 bool ensure_tile_images(biogpt_hip_ctx *c) {
     if (c->tile_img || c->tile_img_failed) return true;
     size_t off = 0;
@@ -646,18 +628,15 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
         if (c->opt.verbose) fprintf(stderr, "biogpt_hip: no memory for the %zu-byte row-tiled weight image; many-column passes stay on the 8-column kernels\n", off);
         return true;
     }
+    bool retile_ok = true;
     auto one = [&](const MatSlot &m) {
-        switch (m.type) {
-            case T_Q4_0: retile_one<bgk::W_Q4_0>(c, m); break;
-            case T_Q4_1: retile_one<bgk::W_Q4_1>(c, m); break;
-            case T_Q5_0: retile_one<bgk::W_Q5_0>(c, m); break;
-            case T_Q5_1: retile_one<bgk::W_Q5_1>(c, m); break;
-            case T_Q8_0: retile_one<bgk::W_Q8_0>(c, m); break;
-            default: break;
-        }
+        if (!is_quantized(m.type)) return;
+        const bgk::DevMatrix src = dev_matrix(c, m);
+        if (bg_mfma_retile(m.type, &src, sizeof(src), c->tile_img + m.xq, c->tile_img + m.xs, c->stream) != (int)hipSuccess) retile_ok = false;
     };
     for (const auto &L : c->plan.layers) { one(L.qkv); one(L.o); one(L.fc1); one(L.fc2); }
     one(c->plan.lm_head);
+    if (!retile_ok) BG_FAIL(false, "building the row-tiled weight image failed");
     HIP_TRY(false, hipGetLastError());
     return true;
 }

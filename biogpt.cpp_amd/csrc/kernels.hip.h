@@ -453,7 +453,7 @@ __host__ __device__ inline size_t matvec_smem_bytes(int wtype, int K, int NC, in
 #define BG_STAMP(k) do {} while (0)
 #endif
 
-template <int WT, int PRO, int EPI, int NC, int KCH, bool SEQ = true>
+template <int WT, int PRO, int EPI, int NC, int KCH>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
     using TI = TypeInfo<WT>;
     BG_STAMP(0);
@@ -672,21 +672,12 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p) {
         if (TI::quant) {
             // sumf = 0; for b: sumf += c_b   (ggml_vec_dot_q*_q8_* scalar order)
             float sumf = 0.0f;
-            if (SEQ) {
-                for (int b = 0; b < p.upr; b += 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(part + b);
-                    sumf = __fadd_rn(sumf, t.x);
-                    if (b + 1 < p.upr) sumf = __fadd_rn(sumf, t.y);
-                    if (b + 2 < p.upr) sumf = __fadd_rn(sumf, t.z);
-                    if (b + 3 < p.upr) sumf = __fadd_rn(sumf, t.w);
-                }
-            } else {  // 4 interleaved partial sums (tolerance mode, not the parity path)
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int b = 0; b < p.upr; b += 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(part + b);
-                    a0 += t.x; if (b + 1 < p.upr) a1 += t.y; if (b + 2 < p.upr) a2 += t.z; if (b + 3 < p.upr) a3 += t.w;
-                }
-                sumf = (a0 + a1) + (a2 + a3);
+            for (int b = 0; b < p.upr; b += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(part + b);
+                sumf = __fadd_rn(sumf, t.x);
+                if (b + 1 < p.upr) sumf = __fadd_rn(sumf, t.y);
+                if (b + 2 < p.upr) sumf = __fadd_rn(sumf, t.z);
+                if (b + 3 < p.upr) sumf = __fadd_rn(sumf, t.w);
             }
             v = sumf;
         } else {

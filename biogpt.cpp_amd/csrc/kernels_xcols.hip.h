@@ -79,34 +79,13 @@ __device__ __forceinline__ void xc_sweep(const xp_u64 *g, bool active, uint32_t 
     }
 }
 
-// XC_NT_WEIGHTS: the weight units with the streaming hint (each line is used once per launch by this XCD; the hand-off granules should keep their place in the L2)
-#ifndef XC_NT_WEIGHTS
-#define XC_NT_WEIGHTS 0
-#endif
 template <int WT>
 __device__ __forceinline__ void xc_load_unit(Unit<WT> &u, const DevMatrix &W, int64_t idx) {
-#if XC_NT_WEIGHTS
-    using TI = TypeInfo<WT>;
-    const xp_v4u t = __builtin_nontemporal_load(reinterpret_cast<const xp_v4u *>(W.qs + idx * TI::qbytes));
-    u.q0 = make_uint4(t.x, t.y, t.z, t.w);
-    if (TI::q81) u.sc = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(W.sc) + idx);
-    else u.sc = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(W.sc) + idx);
-    if (WT == W_Q5_0 || WT == W_Q5_1) u.qh = __builtin_nontemporal_load(W.qh + idx);
-#else
     load_unit<WT>(u, W, idx);
-#endif
 }
-// XC_PW: how many waves of a workgroup poll (all sweeps are theirs): 4 = waves 0 .. 3 (each LayerNorm worker takes its own 4 elements in), 1 = wave 0 alone (16 .. 20
-// granules per lane, the values go through LDS to the LayerNorm workers).  With 1 and XC_FREE_WAVES = 7 only wave 0 -- an eighth of the workgroup's bytes -- keeps the
-// burst discipline, waves 1 .. 7 stream freely: tools/microbench21.hip measures what a hand-off costs beside streaming waves (0.46 - 0.57 us one way against 0.24 idle)
-#ifndef XC_PW
-#define XC_PW 4
-#endif
-// XC_FREE_WAVES: waves 4 .. 7 never poll (every sweep is waves 0 .. 3's), so nothing of theirs waits behind their loads: they re-request a stage's units for the
-// next layer right behind the use -- a continuous stream over the whole layer -- and only waves 0 .. 3 keep the burst discipline described in xc_run
-#ifndef XC_FREE_WAVES
-#define XC_FREE_WAVES 0
-#endif
+// (Measured and gone, round 4 -- table in HISTORY.md, "prompt chunk as one persistent launch": one polling wave per workgroup with the others streaming freely (0.73 against
+// 0.50 ms per 8-token eval), waves 4 .. 7 re-requesting their units right behind the use (20 % slower), the streaming hint on the weight units (no change).  Waves 0 .. 3
+// poll, every wave keeps the burst discipline described in xc_run.)
 template <int WT, int LPK, int KCAP, int ROLE>
 __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, const int col, const int slot, const uint32_t epoch) {
     using TI = TypeInfo<WT>;
@@ -128,13 +107,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     // late requests at all (161 - 252 VGPRs, no spills either) is 7 % slower (0.540 against 0.505 ms per 8-token eval): bigger bursts in front of the long poll.
     constexpr bool UNCOND = WT == W_Q8_0 || KCAP > 256;      // (512-key variant: 128 K / V registers must not stay alive through the layer)
     constexpr bool LATE_W2 = ATTN && (KCAP > 128 || (WT == W_Q8_0 && KCAP > 64));
-    // bits of XC_FREE_WAVES: 1 the q / k / v workgroups (every unit), 2 the attention workgroups' fc1 / fc2 units, 4 their out_proj units and K / V rows
-    // (the 256-key attention workgroups cannot keep fc1 / fc2 units across the attention: every wave in the burst scheme)
-    constexpr int PW = XC_PW;      // polling waves
-    static_assert(PW == 1 || PW == 4, "polling waves");
-    constexpr bool FREE = (XC_FREE_WAVES & 1) != 0 && !ATTN;
-    constexpr bool FREE_F = (XC_FREE_WAVES & 2) != 0 && ATTN && !LATE_W2;
-    constexpr bool FREE_O = (XC_FREE_WAVES & 4) != 0 && ATTN;
+    constexpr int PW = 4;      // polling waves: waves 0 .. 3 (each LayerNorm worker takes its own 4 elements in)
     float *const s_x = reinterpret_cast<float *>(smem + XP_S_X);
     float *const s_x1 = reinterpret_cast<float *>(smem + XP_S_X1);
     uint32_t *const s_xq = reinterpret_cast<uint32_t *>(smem + XP_S_XQ);
@@ -244,7 +217,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         request_small(0, tid);
         if constexpr (!ATTN) {
             request_qkv(0, tid);      // (waves 0 .. 3: the other units in layer 0's burst)
-            if (FREE && tid >= 64 * PW) { request_wo(0, tid); request_w1(0, tid); request_w2(0, tid); }
         } else {
             request_wo(0, tid);
             if constexpr (!LATE_W2) { request_w1(0, tid); request_w2(0, tid); }
@@ -292,16 +264,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         auto layer_input = [&]() __attribute__((always_inline)) {
         if (L == 0) {
             if (worker) xv = reinterpret_cast<const float4 *>(s_x)[tid];      // the embedding: computed in front of the loop (this thread's own LDS write)
-        } else if constexpr (PW == 1) {
-            if (wave == 0) {      // granule lane + 64 k holds element 4 (g & 255) + (g >> 8) (xp_col_slot)
-                uint32_t v[16];
-                xc_sweep<16, 64>(G - XP_G_LAYER + XP_G_X + lane, true, epoch, v, p);
-#pragma unroll
-                for (int k = 0; k < 16; k++) s_x[4 * ((lane + 64 * k) & 255) + ((lane + 64 * k) >> 8)] = __uint_as_float(v[k]);
-            }
-            __syncthreads();
-            if (worker) xv = reinterpret_cast<const float4 *>(s_x)[tid];
-            return;
         } else if (wave < 4) {
             uint32_t v[4];
             xc_sweep<4, 256>(G - XP_G_LAYER + XP_G_X + tid, true, epoch, v, p);
@@ -324,7 +286,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * QS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < QS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wqkv[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if (FREE && !QKV_LATE && wave >= PW && more) request_qkv(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -344,7 +305,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             }
             XC_WALL(1);
             // the burst: this layer's other units in the order of their use, then the next layer's q / k / v units and small vectors -- the attention takes microseconds
-            if (!FREE || wave < PW) {
+            {
                 request_wo(L, tid); request_w1(L, tid); request_w2(L, tid);
                 if (more && !QKV_LATE) request_qkv(L + 1, tid);
             }
@@ -451,7 +412,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                 }
                 s_pv[tid] = a0 + a1;
             }
-            if (FREE_O && wave >= PW && more) request_kv(L + 1, tid);
             __syncthreads();
             XC_WALL(15);
             if (tid < DK) {
@@ -471,16 +431,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(2);
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if constexpr (LATE_W2) { request_w1(L, tid); request_w2(L, tid); }
-        if constexpr (PW == 1) {
-            if (wave == 0) {      // 256 + 32 + 32 granules, five per lane
-                uint32_t v[5];
-                xc_sweep<5, 64>(G + XP_G_ATT + lane, true, epoch, v, p);
-#pragma unroll
-                for (int k = 0; k < 4; k++) s_xq[lane + 64 * k] = v[k];
-                if (lane < 32) s_xd[lane] = __uint_as_float(v[4]);
-                else s_xs[lane - 32] = v[4];
-            }
-        } else
         if (wave < 4) {      // 256 + 32 + 32 granules: two per lane in wave 0, one elsewhere
             uint32_t v[1], w[1] = {0u};
             if (wave == 0) {
@@ -510,7 +460,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * OS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < OS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(wo[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if ((FREE || FREE_O) && wave >= PW && more) request_wo(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -523,20 +472,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         XC_WALL(3);
         // ================= stage D: LayerNorm -> Q8 -> fc1 -> GELU -> Q8 (biogpt.cpp:777-787) =================
         float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
-        if constexpr (PW == 1) {
-            if (wave == 0) {
-                uint32_t v[16];
-                xc_sweep<16, 64>(G + XP_G_X1 + lane, true, epoch, v, p);
-#pragma unroll
-                for (int k = 0; k < 16; k++) s_x1[4 * ((lane + 64 * k) & 255) + ((lane + 64 * k) >> 8)] = __uint_as_float(v[k]);
-            }
-            __syncthreads();
-            if (worker) {
-                x1v = reinterpret_cast<const float4 *>(s_x1)[tid];
-                XC_WALL(9);
-                lnw = reinterpret_cast<const float4 *>(s_ln + 2048)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 3072)[tid];
-            }
-        } else
         if (wave < 4) {
             uint32_t v[4];
             xc_sweep<4, 256>(G + XP_G_X1 + tid, true, epoch, v, p);
@@ -556,7 +491,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float *const part = s_part + wave * 2 * FS * DEC_PS;
 #pragma unroll
             for (int s = 0; s < FS; s++) part[(s * 2 + rsub) * DEC_PS + sub] = unit_dot_quant<WT>(w1[s], ax, axd, __uint_as_float(axs), (int)axs);
-            if ((FREE || FREE_F) && wave >= PW && more) request_w1(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -585,16 +519,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         }
         XC_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
-        if constexpr (PW == 1) {
-            if (wave == 0) {   // 1024 + 128 + 128 granules in ONE poll loop, twenty per lane
-                uint32_t v[20];
-                xc_sweep<20, 64>(G + XP_G_H + lane, true, epoch, v, p);
-#pragma unroll
-                for (int k = 0; k < 16; k++) s_hq[lane + 64 * k] = v[k];
-                s_hd[lane] = __uint_as_float(v[16]); s_hd[lane + 64] = __uint_as_float(v[17]);
-                s_hs[lane] = v[18]; s_hs[lane + 64] = v[19];
-            }
-        } else
         if (wave < 4) {   // 1024 + 128 + 128 granules in ONE poll loop, five per lane: every pass has all of a lane's loads in flight together
             uint32_t v[5];
             const xp_u64 *g = G + XP_G_H + tid;
@@ -619,7 +543,6 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int r = 0; r < F2R; r++) part[r * DEC_PS2 + u] = unit_dot_quant<WT>(w2[r][it], ax, axd, __uint_as_float(axs), (int)axs);
             }
-            if ((FREE || FREE_F) && wave >= PW && more) request_w2(L + 1, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -648,9 +571,9 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
         if constexpr (ATTN) {      // the burst of the attention workgroups: the next layer's units in the order of their use, the head's old keys / values, the small vectors
             if (more || UNCOND) {
                 const int Ln = more ? L + 1 : L;
-                if (!FREE_O || wave < PW) request_wo(Ln, tid);
-                if constexpr (!LATE_W2) { if (!FREE_F || wave < PW) { request_w1(Ln, tid); request_w2(Ln, tid); } }
-                if (!FREE_O || wave < PW) request_kv(Ln, tid);
+                request_wo(Ln, tid);
+                if constexpr (!LATE_W2) { request_w1(Ln, tid); request_w2(Ln, tid); }
+                request_kv(Ln, tid);
                 if (more) request_small(L + 1, tid);
             }
         }

@@ -34,9 +34,6 @@ namespace bgk {
 
 // (granules of one layer in the long-context buffer, XpParams::gran_l: XL_G_SC / XL_G_PV / XL_G_LAYER in kernels_xpipe.hip.h)
 
-#ifndef XL_COMBINE_HOME
-#define XL_COMBINE_HOME 1
-#endif
 #ifdef BIOGPT_HIP_PROFILE_HOOKS
 // wall clock of workgroups 0 and 16 of the layer's own XCD ([n_layer][32] slots; workgroup 0 is also the first helper of head 2 xcd)
 #define XL_WALL(k) do { if (p.wall && tid == 0 && (slot & 15) == 0 && own_first) p.wall[L * 32 + (k)] = wall_clock64(); } while (0)
@@ -67,11 +64,11 @@ __device__ __forceinline__ void xl_live(uint32_t *s_dead) {
 template <bool RES, int N, int S = 1, bool CROSS = false>
 __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t *s_dead) {
     if constexpr (!RES) {
-        if constexpr (CROSS && XP_CROSS_PIPE != 0) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
+        if constexpr (CROSS) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
         else xp_sweep<N, S>(g, active, epoch, v, p);
         return;
     }
-    if constexpr (CROSS && XP_CROSS_PIPE != 0) {
+    if constexpr (CROSS) {
         xp_u64 cur[N];
 #pragma unroll
         for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
@@ -102,7 +99,6 @@ __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t 
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); xl_die(s_dead); }
         if ((spins & 255u) == 255u && xl_err(p)) xl_die(s_dead);
-        xp_poll_pause();
     }
 }
 
@@ -177,14 +173,14 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
     };
 
     // ---- the partial sums of one head added in range order (attn_split_combine_kernel's association), Q8, published for out_proj.  Round 3: by the head's first
-    //      helper on XCD head / 2 (partials in-XCD, the result across: two hops).  Round 4 (XL_COMBINE_HOME): by workgroup `head` of the layer's OWN XCD -- the one
+    //      helper on XCD head / 2 (partials in-XCD, the result across: two hops).  Round 4: by workgroup `head` of the layer's OWN XCD -- the one
     //      that computed the head's q / k / v rows and waits for the attention output anyway: the partials cross XCDs (one hop, 2048 granules per head), the result
     //      stays inside the XCD (plain stores): T = 1024 14.25 -> ~13.2 us per layer (profiles/xlong_timeline_r4.txt) ----
-    auto combine = [&](const int L, const uint32_t epoch, const int T, const int head, const bool home) __attribute__((always_inline)) {
+    auto combine = [&](const int L, const uint32_t epoch, const int T, const int head) __attribute__((always_inline)) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
-        const bool own_first = home || (slot & 15) == 0;      // (profiling hooks: the workgroup whose stamps are kept)
+        const bool own_first = true;      // (profiling hooks: the workgroup whose stamps are kept)
         {
             __syncthreads();                      // s_pv: the slice sums of the helper duty have been read
             const int nr = (T + KR - 1) / KR;     // active ranges
@@ -210,7 +206,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (__all(ok)) break;
                     if (spins >= XP_SPIN_MAX) { if ((tid & 63) == 0) xp_fail(p, 7u); if (RES) xl_die(s_dead); break; }
                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                    xp_poll_pause();
                 }
                 s_pv[part * DK + d] = a0 ? __hiloint2double((int)v[1], (int)v[0]) : 0.0;
                 s_pv[(part + 8) * DK + d] = a1 ? __hiloint2double((int)v[3], (int)v[2]) : 0.0;
@@ -231,13 +226,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 const uint32_t packed = xp_pack4(q8);
                 xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
                 const int blk = head * 2 + (tid >> 5);
-                if (home) {
-                    if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
-                    if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, epoch, s8); }
-                } else {
-                    if ((tid & 3) == 0) xp_put(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
-                    if ((tid & 31) == 0) { xp_put(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put(G + XP_G_ATT + 288 + blk, epoch, s8); }
-                }
+                if ((tid & 3) == 0) xp_put_local(G + XP_G_ATT + head * 16 + (tid >> 2), epoch, packed);
+                if ((tid & 31) == 0) { xp_put_local(G + XP_G_ATT + 256 + blk, epoch, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_ATT + 288 + blk, epoch, s8); }
             }
             XL_WALL(22);
             __syncthreads();                      // s_pv is rewritten by the next helper duty
@@ -309,7 +299,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (__all(ok)) break;
                     if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 6u); if (RES) xl_die(s_dead); break; }
                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                    xp_poll_pause();
                 }
 #pragma unroll
                 for (int k = 0; k < NSC; k++) sc[k] = (tid + NT * k < T) ? __uint_as_float(v[k]) : -INFINITY;
@@ -368,13 +357,11 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 for (int s2 = 0; s2 < NW; s2 += 2) { t0 += s_pv[s2 * DK + tid]; t1 += s_pv[(s2 + 1) * DK + tid]; }
                 const double part = t0 + t1;
                 xp_u64 *const gp = GL + XL_G_PV + (hx_head * 16 + hx_r) * 128 + tid;
-                // XL_COMBINE_HOME: the partials go straight to the layer's own XCD (write-through), where the head's workgroup adds them (stage C's prologue)
-                if (XL_COMBINE_HOME) { xp_put(gp, epoch, (uint32_t)__double2loint(part)); xp_put(gp + 64, epoch, (uint32_t)__double2hiint(part)); }
-                else { xp_put_local(gp, epoch, (uint32_t)__double2loint(part)); xp_put_local(gp + 64, epoch, (uint32_t)__double2hiint(part)); }
+                // the partials go straight to the layer's own XCD (write-through), where the head's workgroup adds them (stage C's prologue)
+                xp_put(gp, epoch, (uint32_t)__double2loint(part)); xp_put(gp + 64, epoch, (uint32_t)__double2hiint(part));
             }
             XL_WALL(20);
         }
-        if (!XL_COMBINE_HOME && hx_j0 < T && hx_r == 0) combine(L, epoch, T, hx_head, false);      // (round 3: the head's first helper, then a cross-XCD hop)
         // this workgroup's K / V rows for its next helper duty (the next layer of this token, or layer 0 of the next token) -- issued AFTER the combiner's
         // polls, and on the layer's own XCD after stage C has published its rows: 32 KB of cache-missing loads occupy the compute unit's memory
         // pipeline for ~1.5 us, and whatever is issued behind them -- a poll (a wave's loads return in order), even a hand-off store -- waits
@@ -513,7 +500,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                     if (__all(ok)) break;
                                     if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) xl_die(s_dead); break; }
                                     if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                                    xp_poll_pause();
                                 }
                                 if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
                                 if (a1) {
@@ -672,11 +658,11 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
             if constexpr (FIRST) {
                 {
-                    if constexpr (XL_COMBINE_HOME != 0 && ROLE == 0) combine(L, epoch, n_past + 1, slot, true);      // this workgroup's head: partials of its 16 key ranges -> attention output, in-XCD
+                    if constexpr (ROLE == 0) combine(L, epoch, n_past + 1, slot);      // this workgroup's head: partials of its 16 key ranges -> attention output, in-XCD
                     // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
                     if (wave < 5) {
                         uint32_t v[1];
-                        xl_sweep<RES, 1, 1, XL_COMBINE_HOME == 0>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, s_dead);      // (the block sums travel only with Q8_1 activations)
+                        xl_sweep<RES, 1, 1, false>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, s_dead);      // (the block sums travel only with Q8_1 activations)
                         if (tid < 256) s_xq[tid] = v[0];
                         else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
                         else s_xs[tid - 288] = v[0];
@@ -781,7 +767,6 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             if (__all(ok)) break;
                             if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) xl_die(s_dead); break; }
                             if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && (RES ? xl_err(p) : __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) xl_die(s_dead); break; }
-                            xp_poll_pause();
                         }
 #pragma unroll
                         for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];

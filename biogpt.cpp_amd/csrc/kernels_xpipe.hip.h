@@ -152,49 +152,12 @@ __device__ __forceinline__ void xp_fail(const XpParams &p, uint32_t code) {
     __hip_atomic_store(p.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// experiment switches of the poll loops (round 4 A/B runs, profiles/xpipe_ab_r4.txt): XP_CROSS_PIPE 1 = the sweeps of the two cross-XCD hand-offs keep TWO passes
-// in flight (the next pass is requested before the previous one is looked at); XP_POLL_SLEEP = s_sleep argument between passes (0: none); XP_EXP_LDS 0 = the softmax's exp table read from global memory
-#ifndef XP_CROSS_PIPE
-#define XP_CROSS_PIPE 1
-#endif
-// XP_H16: the fc1 activations (the largest hand-off of a layer: 1152 granules polled by all 32 workgroups) travel as 16-byte granules {3 words, tag}: 512 per layer,
-// ONE aligned 16-byte plain store per producing lane, ONE 16-byte agent-scope load per polling lane and pass.  A 16-byte access of one lane to a naturally aligned
-// address is one request of one cache line at the XCD's L2 and was never observed torn on gfx950 (tools/microbench19.hip: 10^9 granule reads against a writer;
-// MI355X_MICROARCH.md says the same of 16-byte sc1 halves) -- an observation, not an architectural guarantee: measured at +0.4 % (4010 -> 4025 tok/s,
-// profiles/xpipe_ab_r4.txt), it stays OFF -- the 8-byte granules are single-copy atomic by the memory model, and 0.4 % does not buy a silent-corruption mode.
-#ifndef XP_H16
-#define XP_H16 0
-#endif
-// XP_SPLIT_Q (192- / 256-key variants, where the head's workgroup has no room for all 192 q / k / v rows beside its K / V registers): the head's workgroup computes its
-// own 64 q rows (4 units per lane) and starts on the scores of the old keys while workgroup 16 + head computes and hands over only the token's k / v rows -- the hand-over
-// (0.45 us in-XCD) overlaps with the scores instead of standing in front of them.  Round 3: workgroup 16 + head computed all 192 rows and the attention waited for them.
-// Measured per token inside multi-token launches (tools/bucket_ab.py): 133 .. 188 keys 262.1 -> 254.2 us; in the 256-key variant, whose two polling waves have keys of their
-// own beyond 192 keys, 265.8 -> 268.0: there it stays off.
-#ifndef XP_SPLIT_Q
-#define XP_SPLIT_Q 1
-#endif
-// XP_SOFTMAX_WAVE: the softmax of the <= 256-key variants with ONE exchange through LDS (the scores) instead of two (the waves' maxima, then their sums): see the
-// attention stage.  Measured per token inside multi-token launches (tools/bucket_ab.py): profiles/xpipe_ab_r4.txt.
-#ifndef XP_SOFTMAX_WAVE
-#define XP_SOFTMAX_WAVE 1
-#endif
-#ifndef XP_SUM_INT      // (the two-exchange softmax with integer sums of the numerators: measured, no gain)
-#define XP_SUM_INT 0
-#endif
-#ifndef XP_LOCAL_PIPE
-#define XP_LOCAL_PIPE 0
-#endif
-#ifndef XP_EXP_LDS
-#define XP_EXP_LDS 1
-#endif
-#ifndef XP_POLL_SLEEP
-#define XP_POLL_SLEEP 0
-#endif
-__device__ __forceinline__ void xp_poll_pause() {
-#if XP_POLL_SLEEP > 0
-    __builtin_amdgcn_s_sleep(XP_POLL_SLEEP);
-#endif
-}
+// (The compile-time arms of rounds 3 - 4 that were measured and lost -- 16-byte fc1 granules, integer softmax sums, an in-XCD two-pass sweep, s_sleep between poll
+// passes, the resident form's pieces compiled out one by one, sticky / early dead-wave words, scalarised uniform values, a pinned parameter block -- are gone from this
+// file; what each one measured is in profiles/xpipe_ab_r4.txt and profiles/res_instantiation_ab_r4c.txt, the source of the arms in the repository's history before round 5.
+// What they left behind as the one form of the code: the two cross-XCD sweeps keep TWO poll passes in flight; the head's workgroup of the <= 192-key variants computes its
+// own 64 q rows while workgroup 16 + head hands over only the token's k / v rows; the <= 64-key softmax exchanges the scores once through LDS; the softmax's exp slice sits
+// in LDS beside the GELU slices; the XCD of the last-but-one unit takes no lm_head rows.)
 template <int N, int S = 1>
 __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p);
 template <int N, int S>
@@ -203,18 +166,15 @@ __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active,
 // Which 256 rows (four 64-row blocks) of the output projection does workgroup (xcd, slot) take inside the pipelined launch ?  -1: none.  Not XCD 0's attention
 // workgroups (the next token's layer 0), not the last unit's XCD, and (XP_LM_LATE_XCD) not the XCD of the unit before it; the other XCDs in order, then
 // workgroups 16 .. 31 of XCD 0.  The host checks that the ranks cover the blocks (xpipe_lm_capacity).
-#ifndef XP_LM_LATE_XCD
-#define XP_LM_LATE_XCD 1
-#endif
 __host__ __device__ inline int xp_lm_rank(int xcd, int slot, int n_units) {
-    const int last_xcd = (n_units - 1) & 7, late_xcd = XP_LM_LATE_XCD ? ((n_units - 2) & 7) : last_xcd;
+    const int last_xcd = (n_units - 1) & 7, late_xcd = (n_units - 2) & 7;
     int n_full = 0, before = 0;
     for (int x = 1; x < 8; x++) {
         if (x == last_xcd || x == late_xcd) continue;
         if (x < xcd) before++;
         n_full++;
     }
-    if (xcd == 0) return (XP_LM_LATE_XCD && slot >= 16) ? 32 * n_full + (slot - 16) : -1;
+    if (xcd == 0) return (slot >= 16) ? 32 * n_full + (slot - 16) : -1;
     if (xcd == last_xcd || xcd == late_xcd) return -1;
     return 32 * before + slot;
 }
@@ -237,70 +197,25 @@ __device__ __forceinline__ void xp_quit(const XpParams &p) {
     if (__hip_atomic_compare_exchange_strong(p.ctl + 1, &expected, XP_QUIT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         __hip_atomic_store(p.err_host, XP_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// A value every lane of the wave holds alike although the compiler cannot know it (read from one LDS word): as a scalar (XP_UNI 1).  The publishing tag of the
-// resident instantiations is set from such values.  Measured at the end of round 4 (profiles/res_instantiation_ab_r4c.txt): no gain (256.5 against 255.5 us per
-// token through the RES instantiations) -- the tag's tests are not what the resident form costs; 0 = off in the product.
-// XP_RES_AB (measurement builds only, tools/exp_res_ab_r4c.sh): pieces of the resident form compiled out of the RES instantiations, to find what they cost the
-// chain when such a kernel runs an ORDINARY launch (BIOGPT_HIP_XPIPE_AS_RES=1): 1 plain sweeps, 2 no resident-mode code, 4 no "dead wave" flags in LDS, 8 the ordinary
-// lm_head epilogue.  0 in the product.
-#ifndef XP_RES_AB
-#define XP_RES_AB 0
-#endif
-#define XP_RES_CADENCE ((XP_RES_AB & 16) ? 1023u : 255u)      // poll passes between two looks at the error word in the resident sweeps
-// XP_RES_EXPECT 1: the exits of the resident sweeps marked unlikely (block placement: the drain paths out of the polling loops' line) -- A/B arm, see profiles/res_instantiation_ab_r4c.txt
-#ifndef XP_RES_EXPECT
-#define XP_RES_EXPECT 0
-#endif
-#if XP_RES_EXPECT
-#define XP_COLD(c) __builtin_expect(!!(c), 0)
-#else
-#define XP_COLD(c) (c)
-#endif
-#define XP_RESIDENT(p) (!(XP_RES_AB & 2) && (p).resident != 0)
-// XP_DEAD_STICKY 1: the "dead wave" words of the resident form (a wave whose layer input / k, v rows never came tells the workgroup's other waves, which append K / V rows
-// or publish) are raised ONCE and stay up for the rest of the launch (a draining launch never recovers: its quit / error word stays) -- no store per layer and wave, one
-// word to look at instead of four / two.  0: the round-3 form (a word per wave, rewritten every layer).
-// XP_DEAD_EARLY 1: the dead-wave words are read right behind LayerNorm's barriers (with the activation's other LDS reads) instead of at the K / V append, where the
-// read and its wait stand between the rows and their stores.  A/B arm (profiles/res_instantiation_ab_r4c.txt).
-#ifndef XP_DEAD_EARLY
-#define XP_DEAD_EARLY 0
-#endif
-#ifndef XP_DEAD_STICKY
-#define XP_DEAD_STICKY 0
-#endif
-#ifndef XP_UNI
-#define XP_UNI 0
-#endif
-__device__ __forceinline__ uint32_t xp_uni(uint32_t v) {
-#if XP_UNI
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-#else
-    return v;
-#endif
-}
+constexpr uint32_t XP_RES_CADENCE = 255u;      // poll passes between two looks at the error word in the resident sweeps
 // Sweep with a publishing tag: etag is the tag this wave publishes with (the token's epoch), or 0 once the wave has seen the error / quit word -- from
 // then on it polls nothing and publishes only tag 0, which no poller accepts: a draining launch can never hand valid-looking garbage downstream (the
 // host may be waiting for exactly that token's completion words).
 template <bool RES, int N, int S = 1, bool CROSS = false>
 __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p, uint32_t &etag) {
-    if constexpr (!RES || (XP_RES_AB & 1) != 0) {       // ordinary launches: the plain sweep (declared below), etag stays the epoch
-        if constexpr (CROSS && XP_CROSS_PIPE != 0) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
+    if constexpr (!RES) {       // ordinary launches: the plain sweep (declared below), etag stays the epoch
+        if constexpr (CROSS) xp_sweep_pipelined<N, S>(g, active, epoch, v, p);
         else xp_sweep<N, S>(g, active, epoch, v, p);
         return;
     }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
-    etag = xp_uni(etag);
-    if (!(XP_RES_AB & 32) && XP_COLD(etag == 0u)) return;
-    if constexpr (CROSS && XP_CROSS_PIPE != 0) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
+    etag = (etag);
+    if (etag == 0u) return;
+    if constexpr (CROSS) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];
 #pragma unroll
         for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
-#if XP_CROSS_PIPE >= 2
-        xp_u64 mid[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) mid[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
-#endif
         for (uint32_t spins = 0;; spins++) {
             xp_u64 nxt[N];
 #pragma unroll
@@ -313,15 +228,10 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
                 for (int k = 0; k < N; k++) v[k] = active ? (uint32_t)cur[k] : 0u;
                 return;
             }
-            if (XP_COLD(spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
-            if (XP_COLD((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
-#if XP_CROSS_PIPE >= 2
-#pragma unroll
-            for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
-#else
+            if ((spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
+            if (((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
 #pragma unroll
             for (int k = 0; k < N; k++) cur[k] = nxt[k];
-#endif
         }
     }
     for (uint32_t spins = 0;; spins++) {
@@ -335,9 +245,9 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
             }
         }
         if (__all(ok)) return;
-        if (XP_COLD(spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); if (!(XP_RES_AB & 64)) etag = 0u; return; }
-        if (XP_COLD((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (!(XP_RES_AB & 64)) etag = 0u; return; }
-        xp_poll_pause();
+        if ((spins >= XP_SPIN_MAX)) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); etag = 0u; return; }
+        if (((spins & XP_RES_CADENCE) == XP_RES_CADENCE) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { etag = 0u; return; }
+        
     }
 }
 // two passes in flight: a pass is a round trip to the memory side (0.3 - 0.4 us across XCDs); looked at one after the other, a granule that lands just behind a
@@ -347,11 +257,6 @@ __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active,
     xp_u64 cur[N];
 #pragma unroll
     for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
-#if XP_CROSS_PIPE >= 2      // (three passes in flight: measured at the end of round 4, profiles/res_instantiation_ab_r4c.txt)
-    xp_u64 mid[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) mid[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
-#endif
     for (uint32_t spins = 0;; spins++) {
         xp_u64 nxt[N];
 #pragma unroll
@@ -362,13 +267,8 @@ __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active,
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
-#if XP_CROSS_PIPE >= 2
-#pragma unroll
-        for (int k = 0; k < N; k++) { cur[k] = mid[k]; mid[k] = nxt[k]; }
-#else
 #pragma unroll
         for (int k = 0; k < N; k++) cur[k] = nxt[k];
-#endif
     }
 }
 // every ACTIVE lane polls its N granules (stride S) until all their tags carry this launch's counter; wave-uniform exit
@@ -387,7 +287,7 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
         if (__all(ok)) return;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) xp_fail(p, 1u); return; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return;
-        xp_poll_pause();
+        
     }
 }
 
@@ -698,7 +598,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                             if (__all(ok)) break;
                             if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 4u); if (RES) etag = 0u; break; }
                             if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
-                            xp_poll_pause();
+                            
                         }
                         if (a0) { bv = __uint_as_float(v[0]); bi = (int)v[1]; }
                         if (a1) {
@@ -717,8 +617,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (bi < 0 || bi >= p.n_vocab) bi = 0;
                     return bi;
                 };
-                if (RES && XP_RESIDENT(p) && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
-                if (RES && XP_RESIDENT(p) && tk > 0) {
+                if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                if (RES && p.resident != 0 && tk > 0) {
                     // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox -- or, speculating, the device's own
                     // arg-max of the previous one, which that post must then confirm.  Workgroup 0 decides and hands the token to the XCD's other workgroups
                     // as a granule; a wait for the host lasts at most idle_ticks, then the launch ends cleanly (xp_quit)
@@ -818,7 +718,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         tokens[0] = tok;
                     }
                 } else {
-                    tok = (RES && XP_RESIDENT(p)) ? p.res_tok0 : state_tokens(p.st)[0];
+                    tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
                 }
                 if (slot == 0) XP_TAIL(tk, 5);
                 if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
@@ -845,7 +745,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
             // read behind LayerNorm's barriers
-            if (RES && !(XP_RES_AB & 4) && wave < 4 && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_dead[0] = 1u; } else s_dead[wave] = (etag == 0u) ? 1u : 0u; }
+            if (RES && wave < 4 && lane == 0) { s_dead[wave] = (etag == 0u) ? 1u : 0u; }
             return xv;
         };
         if constexpr (FIRST) {
@@ -861,7 +761,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         if (!attn_wg && !MERGE) {
             // ================= stage A (workgroups 16-31): LayerNorm -> Q8 -> the 192 q / k / v rows of head `head` =================
-            constexpr int Q0 = (XP_SPLIT_Q != 0 && KCAP <= 192) ? QS / 3 : 0;      // XP_SPLIT_Q: the q rows (units 0 .. QS / 3 - 1) are the head's own workgroup's
+            constexpr int Q0 = (KCAP <= 192) ? QS / 3 : 0;      // XP_SPLIT_Q: the q rows (units 0 .. QS / 3 - 1) are the head's own workgroup's
             Unit<WT> wqkv[QS];
 #pragma unroll
             for (int s = Q0; s < QS; s++) {
@@ -878,7 +778,6 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
             }
             ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
-            const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
             XP_WALL(6);
             uint32_t ax[8];
             const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -897,7 +796,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int which = jj >> 6, d = jj & 63;
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                     float *cache = (which == 1) ? Y.kcache : Y.vcache;
                     cache[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
@@ -948,7 +847,6 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                 }
                 ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
-                const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
                 XP_WALL(6);
                 if (L == 0 && slot == 0) XP_TAIL(tk, 7);
                 uint32_t ax[8];
@@ -968,7 +866,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = jj >> 6, d = jj & 63;
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -993,7 +891,6 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     lnw = reinterpret_cast<const float4 *>(s_ln)[tid]; lnb = reinterpret_cast<const float4 *>(s_ln + 1024)[tid];
                 }
                 ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);
-                const uint32_t deadw = (RES && !(XP_RES_AB & 4) && XP_DEAD_EARLY != 0) ? (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) : 0u;      // XP_DEAD_EARLY: requested here, behind LayerNorm's barriers, used at the K / V append
                 XP_WALL(6);
                 uint32_t ax[8];
                 const uint4 a = *reinterpret_cast<const uint4 *>(s_xq + sub * 8), b = *reinterpret_cast<const uint4 *>(s_xq + sub * 8 + 4);
@@ -1013,7 +910,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
-                    if (which != 0 && (!RES || (XP_RES_AB & 4) != 0 || (etag != 0u && xp_uni(XP_DEAD_EARLY ? deadw : XP_DEAD_STICKY ? s_dead[0] : (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3])) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
+                    if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
                         float *cache = (which == 1) ? Y.kcache : Y.vcache;
                         cache[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
@@ -1024,9 +921,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int jo = (1 - HI) * 96 + (tid < 96 ? tid : 0);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + (jo >> 6) * 1024 + head * 64 + (jo & 63), tid < 96, epoch, v, p, etag);
                     if (tid < 96) s_cur[jo] = __uint_as_float(v[0]);
-                    if (RES && !(XP_RES_AB & 4) && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_kvdead[0] = 1u; } else s_kvdead[wave] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && lane == 0) { s_kvdead[wave] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
-            } else if constexpr (XP_SPLIT_Q != 0 && KCAP <= 192) {
+            } else if constexpr (KCAP <= 192) {
                 // ---- the head's 64 q rows in here (XP_SPLIT_Q): LayerNorm -> Q8 -> 4 units per lane -> s_cur[0 .. 63]; k / v of this token come from workgroup 16 + head ----
                 constexpr int Q0 = QS / 3;
                 Unit<WT> wq[Q0];
@@ -1075,9 +972,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             }
             __syncthreads();
-            if constexpr (RES && DUAL) { if (xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u; }
+            if constexpr (RES && DUAL) { if ((s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u; }
             XP_WALL(7);
-            constexpr bool LATE_KV = !MERGE && XP_SPLIT_Q != 0 && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
+            constexpr bool LATE_KV = !MERGE && KCAP <= 192;      // the token's own k / v rows arrive while the old keys' scores are computed
             auto key_score = [&](const float4 (&kk)[NF4]) __attribute__((always_inline)) -> float {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -1099,7 +996,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     const int which = wave - (NW - 3);
                     xp_sweep_q<RES, 1>(G + XP_G_QKV + which * 1024 + head * 64 + lane, true, epoch, v, p, etag);
                     s_cur[which * 64 + lane] = __uint_as_float(v[0]);
-                    if (RES && !(XP_RES_AB & 4) && lane == 0) { if (XP_DEAD_STICKY) { if (etag == 0u) s_kvdead[0] = 1u; } else s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
+                    if (RES && lane == 0) { s_kvdead[which - 1] = (etag == 0u) ? 1u : 0u; }      // a draining launch: every wave of the workgroup must stop publishing (read behind the barrier below)
                 }
             }
             float sc = -INFINITY;
@@ -1112,7 +1009,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 if (jg < T && !(LATE_KV && jg == n_past)) sc = key_score(kr);
             }
             static_assert(NW == 8, "key j = wave + 8 k sits in lane (wave + 8 k) & 63 of slot k >> 3");
-            constexpr bool SMW = XP_SOFTMAX_WAVE != 0 && KCAP <= 64;      // (measured: -1.5 us per token with 64 keys, +-0 with 128, +1 / +9 us with 192 / 256 -- 2-4 look-ups per lane and 16-32 v_readlane per wave)
+            constexpr bool SMW = KCAP <= 64;      // (measured: -1.5 us per token with 64 keys, +-0 with 128, +1 / +9 us with 192 / 256 -- 2-4 look-ups per lane and 16-32 v_readlane per wave)
             constexpr int KC = (KCAP + 63) / 64;
             [[maybe_unused]] float ev[KC];
             float inv;
@@ -1127,7 +1024,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int c = 0; c < KC; c++) scl[c] = s_S[lane + 64 * c];
                 if constexpr (LATE_KV) {
-                    if (RES && !(XP_RES_AB & 4) && xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u;
+                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
                     float4 kn[NF4];                 // the token's own key: every group of LPK lanes of every wave forms its score (the association of the old keys' scores)
 #pragma unroll
                     for (int m = 0; m < NF4; m++) kn[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1148,9 +1045,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                         // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
                         const uint32_t ix = f2h(__fsub_rn(scl[c], mx)), neg = ix - 0x8000u;
                         uint16_t e16;
-                        if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
-                        else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
-                        else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
+                        if (neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
+                        else if (p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
+                        else if (p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
                         else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
                         val = h2f(e16);
                     }
@@ -1164,7 +1061,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             } else {
                 if constexpr (LATE_KV) {
                     __syncthreads();      // the token's k / v rows are in s_cur
-                    if (RES && !(XP_RES_AB & 4) && xp_uni(XP_DEAD_STICKY ? s_kvdead[0] : (s_kvdead[0] | s_kvdead[1])) != 0u) etag = 0u;
+                    if (RES && (s_kvdead[0] | s_kvdead[1]) != 0u) etag = 0u;
                     if (kidx == n_past) {      // the LPK lanes of the new key
 #pragma unroll
                         for (int m = 0; m < NF4; m++) kr[m] = *reinterpret_cast<const float4 *>(s_cur + 64 + 4 * (LPK * m + ksub));
@@ -1194,40 +1091,28 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     uint32_t dead = 0u;
 #pragma unroll
                     for (int w = 0; w < NW; w++) dead |= reinterpret_cast<const uint32_t *>(s_redf)[NW + w];
-                    if (xp_uni(dead) != 0u) etag = 0u;
+                    if ((dead) != 0u) etag = 0u;
                 }
                 XP_WALL(13);
                 double sum = 0.0;
-                [[maybe_unused]] uint32_t ulo = 0u, uhi = 0u;
                 if (valid) {
                     // ggml_soft_max: fp16 exp table; its non-zero negative slice sits in LDS (XP_EXP_LDS; sc - mx <= 0: the code is 0x0000 or a negative one)
                     const uint32_t ix = f2h(__fsub_rn(sc, mx)), neg = ix - 0x8000u;
                     uint16_t e16;
-                    if (XP_EXP_LDS != 0 && neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
-                    else if (XP_EXP_LDS != 0 && p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
-                    else if (XP_EXP_LDS != 0 && p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
+                    if (neg < (uint32_t)p.exp_n) e16 = s_gelu[neg];
+                    else if (p.exp_n > 0 && ix == 0u) e16 = 0x3C00;
+                    else if (p.exp_n > 0 && neg < 0x7C00u) e16 = 0;
                     else e16 = p.exp_tab[ix];                                   // -inf, NaN, a positive argument (or no slice)
                     const float val = h2f(e16);
                     if (ksub == 0) s_S[kidx] = val;
                     sum = (double)val;
-                    if constexpr (XP_SUM_INT != 0) { const uint32_t u = (uint32_t)__fmul_rn(val, 16777216.0f); ulo = u & 0xFFFFu; uhi = u >> 16; }
                 }
-                if constexpr (XP_SUM_INT != 0) {      // integer sums of the numerators' low / high 16 bits instead of the double butterfly (measured: +2.4 / -0.8 / +1.8 us per token at 128 / 192 / 256 keys: off)
-                    ulo = xp_wave_sum_u32(ulo); uhi = xp_wave_sum_u32(uhi);
-                    if (lane == 0) reinterpret_cast<uint2 *>(s_redd)[wave] = make_uint2(ulo, uhi);
-                    __syncthreads();
-                    uint32_t tl = 0u, th = 0u;
+                sum = wave_sum_f64(sum);
+                if (lane == 0) s_redd[wave] = sum;
+                __syncthreads();
+                sum = 0.0;
 #pragma unroll
-                    for (int w = 0; w < NW; w++) { const uint2 t = reinterpret_cast<const uint2 *>(s_redd)[w]; tl += t.x; th += t.y; }
-                    sum = ((double)th * 65536.0 + (double)tl) * 0x1p-24;
-                } else {
-                    sum = wave_sum_f64(sum);
-                    if (lane == 0) s_redd[wave] = sum;
-                    __syncthreads();
-                    sum = 0.0;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) sum += s_redd[w];
-                }
+                for (int w = 0; w < NW; w++) sum += s_redd[w];
                 inv = inv_sum_f32(sum);
             }
             XP_WALL(14);
@@ -1286,7 +1171,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         // ================= stage C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         if (wave < 5) {
             uint32_t v[1];
-            xp_sweep_q<RES, 1, 1, XP_LOCAL_PIPE != 0>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, etag);      // (the block sums travel only with Q8_1 activations)
+            xp_sweep_q<RES, 1, 1, false>(G + XP_G_ATT + tid, TI::q81 || tid < 288, epoch, v, p, etag);      // (the block sums travel only with Q8_1 activations)
             if (tid < 256) s_xq[tid] = v[0];
             else if (tid < 288) s_xd[tid - 256] = __uint_as_float(v[0]);
             else s_xs[tid - 288] = v[0];
@@ -1359,48 +1244,11 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             q8_block32(s_g[tid], TI::q81, q8, d8, s8, TI::q81);
             const uint32_t packed = xp_pack4(q8);
             const int blk = slot * 4 + (tid >> 5);
-#if XP_H16
-            // the block's eight words sit in lanes 0, 4, .. 28 of its 32 lanes (two 16-lane rows); four granules per block, each assembled inside ONE row:
-            //   lane 0: {w0, w1, w2}   lane 12: {w3, d, s}   lane 16: {w4, w5, w6}   lane 28: {w7, 0, 0}      (granule 4 blk + 0 .. 3)
-            const uint32_t up4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)packed, 0x104, 0xf, 0xf, true);      // row_shl:4 -- the word of lane + 4
-            const uint32_t up8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)packed, 0x108, 0xf, 0xf, true);      // row_shl:8
-            const int l32 = tid & 31;
-            if (l32 == 0 || l32 == 12 || l32 == 16 || l32 == 28) {
-                const bool first = (l32 & 15) == 0;
-                xp_v4u gq;
-                gq.x = packed;
-                gq.y = first ? up4 : (l32 == 12 ? __float_as_uint(d8) : 0u);
-                gq.z = first ? up8 : (l32 == 12 ? s8 : 0u);
-                gq.w = etag;
-                const int gi = blk * 4 + (l32 == 0 ? 0 : l32 == 12 ? 1 : l32 == 16 ? 2 : 3);
-                *reinterpret_cast<xp_v4u *>(reinterpret_cast<unsigned char *>(G + XP_G_H) + (size_t)gi * 16) = gq;      // plain store: the line stays in the XCD's L2
-            }
-#else
             if ((tid & 3) == 0) xp_put_local(G + XP_G_H + slot * 32 + (tid >> 2), etag, packed);
             if ((tid & 31) == 0) { xp_put_local(G + XP_G_H + 1024 + blk, etag, __float_as_uint(d8)); if (TI::q81) xp_put_local(G + XP_G_H + 1152 + blk, etag, s8); }
-#endif
         }
         XP_WALL(4);
         // ================= stage E: fc2 + bias + residual (biogpt.cpp:790-795) =================
-#if XP_H16
-        {   // 512 granules of 16 bytes, one per thread: {3 words, tag}
-            static_assert(NT == 512, "one 16-byte granule per thread");
-            const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(G + XP_G_H), 0, 512 * 16, 0x00027000);
-            xp_v4u gq = {0u, 0u, 0u, 0u};
-            for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
-                gq = __builtin_amdgcn_raw_buffer_load_b128(hrs, tid * 16, 0, XP_CPOL_SC1);      // agent scope: the L1 is not consulted, the XCD's L2 answers
-                if (__all(gq.w == epoch)) break;
-                if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) etag = 0u; break; }
-                if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
-                xp_poll_pause();
-            }
-            const int blk = tid >> 2, part = tid & 3;
-            if (part == 0) { s_hq[blk * 8 + 0] = gq.x; s_hq[blk * 8 + 1] = gq.y; s_hq[blk * 8 + 2] = gq.z; }
-            else if (part == 1) { s_hq[blk * 8 + 3] = gq.x; s_hd[blk] = __uint_as_float(gq.y); s_hs[blk] = gq.z; }
-            else if (part == 2) { s_hq[blk * 8 + 4] = gq.x; s_hq[blk * 8 + 5] = gq.y; s_hq[blk * 8 + 6] = gq.z; }
-            else s_hq[blk * 8 + 7] = gq.x;
-        }
-#else
         {   // 1024 + 128 + 128 granules in ONE poll loop: every pass has all of a lane's loads in flight together
             constexpr int NQ = 1024 / NT;
             uint32_t v[NQ + 1];
@@ -1408,25 +1256,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             for (int k = 0; k <= NQ; k++) v[k] = 0u;
             const xp_u64 *g = G + XP_G_H + tid;
             const bool tail = tid < (TI::q81 ? 256 : 128);      // scales, and with Q8_1 activations the block sums
-#if XP_LOCAL_PIPE
-            xp_u64 cur[NQ + 1];
-#pragma unroll
-            for (int k = 0; k < NQ; k++) cur[k] = __hip_atomic_load(g + k * NT, XP_RLX);
-            cur[NQ] = tail ? __hip_atomic_load(g + 1024, XP_RLX) : ((xp_u64)epoch << 32);
-#endif
             for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
                 bool ok = true;
-#if XP_LOCAL_PIPE
-                xp_u64 nxt[NQ + 1];
-#pragma unroll
-                for (int k = 0; k < NQ; k++) nxt[k] = __hip_atomic_load(g + k * NT, XP_RLX);
-                nxt[NQ] = tail ? __hip_atomic_load(g + 1024, XP_RLX) : ((xp_u64)epoch << 32);
-#pragma unroll
-                for (int k = 0; k <= NQ; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
-                if (!tail) v[NQ] = 0u;
-#pragma unroll
-                for (int k = 0; k <= NQ; k++) cur[k] = nxt[k];
-#else
 #pragma unroll
                 for (int k = 0; k < NQ; k++) {
                     const xp_u64 a = __hip_atomic_load(g + k * NT, XP_RLX);
@@ -1438,18 +1269,16 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     v[NQ] = (uint32_t)a;
                     ok &= (uint32_t)(a >> 32) == epoch;
                 }
-#endif
                 if (__all(ok)) break;
                 if (spins >= XP_SPIN_MAX) { if (lane == 0) xp_fail(p, 1u); if (RES) etag = 0u; break; }
                 if ((spins & (RES ? 255u : 1023u)) == (RES ? 255u : 1023u) && __any(__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u)) { if (RES) etag = 0u; break; }
-                xp_poll_pause();
+                
             }
 #pragma unroll
             for (int k = 0; k < NQ; k++) s_hq[tid + k * NT] = v[k];
             if (tid < 128) s_hd[tid] = __uint_as_float(v[NQ]);
             else if (tid < 256) s_hs[tid - 128] = v[NQ];
         }
-#endif
         __syncthreads();
         XP_WALL(12);
         {
@@ -1511,7 +1340,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         constexpr int LMS = 128 / NW;                                         // 2-row steps per wave: 256 rows per workgroup
         const int row0 = lm_rank * 256;
         // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
-        const bool alt = RES && XP_RESIDENT(p) && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
+        const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
         float *const lg_dev = alt ? p.logits_alt : p.logits;
         float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
         Unit<WT> wl[LMS];
@@ -1525,7 +1354,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         for (int s = 0; s < LMS; s++) xp_settle<WT, EXPAND>(wl[s]);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
         if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
-        if (RES && XP_RESIDENT(p) && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
+        if (RES && p.resident != 0 && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
             uint32_t go[1];
             xp_sweep_q<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, etag);
         }
@@ -1555,7 +1384,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
             if (row < p.n_vocab) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
-                if constexpr (RES && !(XP_RES_AB & 8)) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
+                if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
                 else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
                 best_val = v; best_idx = row;
             }
@@ -1568,7 +1397,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         constexpr int LPB = 64 / NW;                                          // finisher lanes per 64-row block in one wave
         if (lane < 2 * LMS && (lane & (LPB - 1)) == 0) { s_redf[(lane / LPB) * NW + wave] = best_val; s_redi[(lane / LPB) * NW + wave] = best_idx; }
         bool row_ok = true;
-        if constexpr (RES && !(XP_RES_AB & 8)) row_ok = __syncthreads_and(etag != 0u);
+        if constexpr (RES) row_ok = __syncthreads_and(etag != 0u);
         else __syncthreads();
         // the host's copy of the row (biogpt_eval's output): wave 1 writes the workgroup's 256 logits as ONE kilobyte of 16-byte write-through stores
         // (four-byte stores from the finisher lanes were one PCIe write each: 42 k per token); a resident launch follows them with the workgroup's
@@ -1583,7 +1412,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             } else {
                 for (int j = r; j < p.n_vocab; j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
             }
-            if (XP_RESIDENT(p)) {
+            if (p.resident != 0) {
                 if (lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (the same maxima tid < 4 records below)
                     float bm = s_redf[lane * NW];
 #pragma unroll
@@ -1636,38 +1465,8 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     }
 }
 
-// XP_PIN_PARAMS 1 (measurement builds): the parameter block of the resident instantiations, every word of it read ONCE at the kernel's entry and passed through
-// an empty asm statement.  A kernel argument is an invariant scalar load and the register allocator rematerialises such loads instead of spilling them: the
-// ordinary instantiations keep all 21 s_loads in the entry block, the resident ones (more live words: mailbox, completion words, alternate buffers) have 99 of
-// them inside the token loop and 57 inside the LAYER loop.  A value that comes out of an asm statement cannot be rematerialised (it goes to a vector register's
-// lane instead, as in the ordinary instantiations): with it the loops hold 0 .. 3 such loads -- and the launch is no faster (64-key bucket 244.5 against 245.7 us
-// per token, 192- / 256-key buckets 8 / 5 us slower: profiles/res_instantiation_ab_r4c.txt).  The rematerialised loads are not what the resident form costs; off.
-#ifndef XP_PIN_PARAMS
-#define XP_PIN_PARAMS 0
-#endif
-template <typename T>
-__device__ __forceinline__ void xp_pin(T &v) {
-    if constexpr (sizeof(T) == 4 && !__is_pointer(T) && !__is_integral(T)) { uint32_t u = __float_as_uint(v); asm volatile("" : "+s"(u)); v = __uint_as_float(u); }
-    else asm volatile("" : "+s"(v));
-}
-__device__ __forceinline__ void xp_pin(DevMatrix &m) { xp_pin(m.qs); xp_pin(m.sc); xp_pin(m.qh); xp_pin(m.type); xp_pin(m.M); xp_pin(m.K); }
-__device__ __forceinline__ void xp_pin_params(XpParams &q) {
-    xp_pin(q.layers); xp_pin(q.n_layer); xp_pin(q.gran); xp_pin(q.gran_l); xp_pin(q.ctl); xp_pin(q.err_host); xp_pin(q.st); xp_pin(q.tok_emb); xp_pin(q.pos_emb);
-    xp_pin(q.embed_scale); xp_pin(q.tok_src); xp_pin(q.pmax_val); xp_pin(q.pmax_idx); xp_pin(q.nparts); xp_pin(q.n_positions); xp_pin(q.n_vocab); xp_pin(q.eps);
-    xp_pin(q.q_scale); xp_pin(q.P); xp_pin(q.t_cap); xp_pin(q.exp_tab); xp_pin(q.gelu_tab); xp_pin(q.gelu_p); xp_pin(q.gelu_n); xp_pin(q.gelu_z); xp_pin(q.exp_n);
-    xp_pin(q.x_final); xp_pin(q.lm); xp_pin(q.lm_blocks); xp_pin(q.adv); xp_pin(q.n_tok); xp_pin(q.samp); xp_pin(q.Wlm); xp_pin(q.lm_ln_w); xp_pin(q.lm_ln_b);
-    xp_pin(q.logits); xp_pin(q.logits_host); xp_pin(q.pmax_out_val); xp_pin(q.pmax_out_idx); xp_pin(q.dual); xp_pin(q.resident); xp_pin(q.res_tok0);
-    xp_pin(q.res_n_past0); xp_pin(q.res_dbg); xp_pin(q.mbox); xp_pin(q.mbox_seq0); xp_pin(q.idle_ticks); xp_pin(q.done_host); xp_pin(q.res_spec0); xp_pin(q.spec_rec);
-    xp_pin(q.logits_alt); xp_pin(q.logits_host_alt); xp_pin(q.pmax_alt_val); xp_pin(q.pmax_alt_idx); xp_pin(q.wall);
-}
-
 template <int WT, int LPK, int NW, int KCAP, bool SPLIT, bool RES = false>
-__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p_in) {
-    XpParams p_pinned;
-    const XpParams &p = [&]() -> const XpParams & {
-        if constexpr (RES && XP_PIN_PARAMS != 0) { p_pinned = p_in; xp_pin_params(p_pinned); return p_pinned; }
-        else return p_in;
-    }();
+__global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant && (WT != W_Q8_0 || SPLIT), "Q8_0 (9 registers per weight unit) runs with split layers");
     static_assert(LPK == 2 || LPK == 4 || LPK == 8 || LPK == 16, "lanes per key");
@@ -1711,10 +1510,9 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p_in)
     }
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane(s_redi[0]), slot = __builtin_amdgcn_readfirstlane(s_redi[1]);
-    if (RES && XP_DEAD_STICKY != 0 && threadIdx.x < 16) reinterpret_cast<uint32_t *>(smem + XP_S_REDD + 64)[threadIdx.x] = 0u;      // s_kvdead / s_dead (xp_run): raised once, never lowered
     __syncthreads();
     if ((unsigned)slot >= 32u) { if (threadIdx.x == 0) xp_fail(p, 2u); return; }
-    const int n_past0 = (RES && XP_RESIDENT(p)) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
+    const int n_past0 = (RES && p.resident != 0) ? p.res_n_past0 : p.st->n_past, n_gen0 = p.st->n_gen;
     const int t_cap = p.t_cap;
 
     // ggml_gelu's fp16 table (biogpt.cpp:784): 70 KB of it cover every argument for which GELU is neither the identity (x >= 3.38
@@ -1725,7 +1523,7 @@ __global__ __launch_bounds__(NW * 64) void dec_xpipe_kernel(const XpParams p_in)
         for (int i = threadIdx.x; i < np8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
         for (int i = threadIdx.x; i < nn8; i += NT) reinterpret_cast<uint4 *>(s_gelu + p.gelu_p)[i] = src[0x8000 / 8 + i];
     }
-    if (XP_EXP_LDS != 0 && SPLIT && !(xcd & 1) && (slot < 16 || KCAP > 256) && p.exp_n > 0) {      // the attention workgroups (512-key variant: all 32 of the XCD): the exp table's slice where the MLP halves keep GELU's
+    if (SPLIT && !(xcd & 1) && (slot < 16 || KCAP > 256) && p.exp_n > 0) {      // the attention workgroups (512-key variant: all 32 of the XCD): the exp table's slice where the MLP halves keep GELU's
         const uint4 *src = reinterpret_cast<const uint4 *>(p.exp_tab + 0x8000);
         for (int i = threadIdx.x; i < p.exp_n / 8; i += NT) reinterpret_cast<uint4 *>(s_gelu)[i] = src[i];
     }
