@@ -22,6 +22,9 @@ elif len(sys.argv) > 2 and sys.argv[2] == "chunk":     # the column-per-XCD chun
     print("chunk launches", g.chunk_launches(), flush=True)
 elif len(sys.argv) > 2 and sys.argv[2] == "dual":      # the two-workgroups-per-head launch at 400 keys: graph replays at n_past = 399
     print("T=400", round(g.bench_decode(399, 40) * 1e6, 2), "us per token", flush=True)
+elif len(sys.argv) > 2 and sys.argv[2] == "sweep":     # matvec_sweep_kernel: every block-quantized matrix of the model in one launch (kernels_sweep.hip.h)
+    s, b, c = g.bench_sweep(40)
+    print("sweep", round(s * 1e6, 2), "us", b, "bytes", round(b / s / 1e9, 1), "GB/s, check", c, flush=True)
 elif len(sys.argv) > 2 and sys.argv[2] == "xpipe":     # only the XCD-pipelined single-token launch at 104 keys (bench.py's roofline.traffic pass)
     if g.xpipe_state() == 1:
         s, b = g.bench_matvec(11, 0, 24)
