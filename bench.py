@@ -170,7 +170,7 @@ def pmc_mfma_busy(model_path, pass_seconds):
         raise RuntimeError("no MFMA dispatch in the pass")
     return {"busy_cycles_per_pass": busy, "frac_of_simd_cycles": round(busy / (pass_seconds * 2.4e9 * 1024), 4),
             "how": "one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass (kernel-trace only beside it) over tools/pmc_target.py <model> prefill; busy cycles of every MFMA kernel of one pass / "
-                   "(pass time x 2.4 GHz x 1024 SIMDs); attention runs on the VALU (exact double sums, DESIGN 4.5) and counts as zero"}
+                   "(pass time x 2.4 GHz x 1024 SIMDs); attention runs on the VALU (exact double sums, DESIGN 4.4) and counts as zero"}
 
 
 def bench_capi(args):
@@ -446,7 +446,7 @@ def main():
                              "60-72 tokens per launch)" % (args.ftype.upper(), hp.n_layer))
                     method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel as a single-token launch (hipGraph, as biogpt_eval's step is replayed), real arena weights; "
                               "algorithmic bytes = the four matrices of every layer and the output projection at file density + K / V rows of 104 keys + the new K / V rows + x in / out + the logits row; "
-                              "rocprofv3 agreement: profiles/rocprofv3_kernel_stats_r4.csv is taken with BIOGPT_HIP_XPIPE_MULTI=0 BIOGPT_HIP_RESIDENT=0 (every call one token); "
+                              "rocprofv3 agreement: profiles/rocprofv3_kernel_stats_r5.csv is taken with BIOGPT_HIP_XPIPE_MULTI=0 BIOGPT_HIP_RESIDENT=0 (every call one token); "
                               "the launch is LATENCY-bound by design: a layer is %.1f us of dependent stages (profiles/xpipe_timeline_r4.txt) on 1/8 of the chip while the "
                               "other XCDs prefetch -- 8 TB/s would move a layer's 7.1 MB in 0.9 us" % (sx * 1e6 / hp.n_layer))
             else:
@@ -458,7 +458,7 @@ def main():
             per["lm_head"] = {"GBps": round(nbytes_lm / secs_lm / 1e9, 1), "us": round(secs_lm * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lm / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "HIP events around 50 back-to-back launches on the ONE copy of the matrix the model owns: between launches its 24.6 MB stay in the 256 MB Infinity Cache, so "
                                       "this is a fabric-side rate, not an HBM rate (a pure read of the same bytes takes 2.4 us); rocprofv3's average over the calls of a whole bench run is higher "
-                                      "(profiles/rocprofv3_kernel_stats_r4.csv: the first calls after other work are cold)"}
+                                      "(profiles/rocprofv3_kernel_stats_r5.csv: the first calls after other work are cold)"}
             try:        # the same kernel with the weights NOT cache-resident: a different one of 14 copies of the matrix per launch (344 MB) -- the figure an "HBM roofline" means
                 secs_lc, _ = model.bench_matvec(12, layer=0, reps=56)
                 per["lm_head_cold"] = {"GBps": round(nbytes_lm / secs_lc / 1e9, 1), "us": round(secs_lc * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lc / 1e9 / HBM_PEAK_GBS, 4),
@@ -470,7 +470,7 @@ def main():
                 "bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 # HBM bytes from PMC counters need their own rocprofv3 --pmc passes: two child processes after the timed work (pmc_traffic below; null when
-                # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r4.txt)
+                # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r4.txt, pmc_attn_tile_r5.txt)
                 "traffic": None,
                 "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
                 "method": (method if quant and method else
@@ -566,7 +566,7 @@ def main():
                                              "chunk_launches_per_32_evals": int(per_loop),
                                              "tokens_per_s_512_token_prompt": round(512 / t512, 1), "ms_per_eval_257_512_keys": round((t512 - t256) / 32 * 1e3, 3),
                                              "note": "biogpt_hip_eval per 8-token chunk from Python (ctypes), rows copied to the host; 0 .. 256 keys: the column-per-XCD launch "
-                                                     "(every XCD streams all weights: 16.7 us per layer against 9.8 us of pure weight stream and ~ 11 us of dependent chain, DESIGN 4.1f; profiles/xcols_timeline_r4.txt), "
+                                                     "(every XCD streams all weights: 16.7 us per layer against 9.8 us of pure weight stream and ~ 11 us of dependent chain, HISTORY.md round 4; profiles/xcols_timeline_r4.txt), "
                                                      "257 .. 512 keys: the launch chain (round 3: 0.86 ms per eval at every context)"}
             except Exception as e:
                 out["prompt_chunk_evals"] = {"error": str(e)[:300]}

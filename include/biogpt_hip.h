@@ -143,7 +143,7 @@ int biogpt_hip_eval(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens
 /* biogpt_eval (biogpt.cpp:812-847) without the final copy: *row_out points at the context's pinned host buffer that the launch
  * itself wrote the n_vocab logits of the last token into (valid until the next call on this context).  A loop of single-token calls
  * (main.cpp:91-151) -- through this entry or biogpt_hip_eval -- is served by ONE pipelined launch that stays on the device between
- * the calls and takes each next token from a pinned mailbox (DESIGN.md 4.1d); it leaves the device after BIOGPT_HIP_RESIDENT_US
+ * the calls and takes each next token from a pinned mailbox (DESIGN.md 4.1); it leaves the device after BIOGPT_HIP_RESIDENT_US
  * (default 1000) microseconds without a call, or as soon as the context is asked to do anything else. */
 int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n_tokens, int32_t n_past,
                             const float **row_out);
