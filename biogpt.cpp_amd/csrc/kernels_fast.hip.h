@@ -846,6 +846,8 @@ __host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
 #else
 #define ATTN_STAMP(k) do { } while (0)
 #endif
+typedef float at_f4 __attribute__((ext_vector_type(4)));
+typedef float at_f2 __attribute__((ext_vector_type(2)));
 template <int G>
 __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
     constexpr int DK = 64, NW = 8;
@@ -890,37 +892,41 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
         for (int j0 = 0; j0 < Tmax; j0 += 512) {
             if (j0 + 64 * wave >= Tmax) break;                                   // this wave's 64 keys are past every query's context
             const int jb = j0 + 4 * kg;
-            const float4 *krow[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) krow[c] = kbase + (size_t)min(jb + c, t_cap - 1) * (DK / 4);
+            // the 4 key rows of this thread are consecutive: ONE address, the row in the load's immediate offset (rows past the context are clamped into the head's
+            // P >= 4 allocated rows; what is computed from them is never stored)
+            const at_f4 *krow0 = reinterpret_cast<const at_f4 *>(kbase) + (size_t)min(jb, p.P - 4) * (DK / 4);
             double acc[4][4];
 #pragma unroll
             for (int qi = 0; qi < 4; qi++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) acc[qi][c] = 0.0;
-#pragma unroll 2
+#pragma unroll 1
             for (int m = 0; m < DK / 4; m++) {
-                float4 kv[4], qv[4];
+                at_f4 kv[4], qv[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) kv[c] = krow[c][m];
+                for (int c = 0; c < 4; c++) kv[c] = krow0[c * (DK / 4) + m];
 #pragma unroll
-                for (int qi = 0; qi < 4; qi++) qv[qi] = qbase[qi * (DK / 4) + m];
+                for (int qi = 0; qi < 4; qi++) qv[qi] = reinterpret_cast<const at_f4 *>(qbase)[qi * (DK / 4) + m];
+                // two dims of ONE (query, key) per packed multiply: the operands are the register pairs the 16-byte loads left behind (pairing two queries of one
+                // dim -- what the vectoriser picks by itself -- costs a v_mov per product pair to build the operand); the sums stay in dim order per accumulator
 #pragma unroll
-                for (int qi = 0; qi < 4; qi++)
+                for (int hf = 0; hf < 2; hf++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].x, qv[qi].x);
+                    for (int qi = 0; qi < 4; qi += 2) {
+                        at_f2 pr2[2][4];
 #pragma unroll
-                for (int qi = 0; qi < 4; qi++)
+                        for (int q2 = 0; q2 < 2; q2++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].y, qv[qi].y);
+                            for (int c = 0; c < 4; c++) pr2[q2][c] = (hf == 0 ? kv[c].lo : kv[c].hi) * (hf == 0 ? qv[qi + q2].lo : qv[qi + q2].hi);
 #pragma unroll
-                for (int qi = 0; qi < 4; qi++)
+                        for (int q2 = 0; q2 < 2; q2++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].z, qv[qi].z);
+                            for (int c = 0; c < 4; c++) acc[qi + q2][c] += (double)pr2[q2][c].x;
 #pragma unroll
-                for (int qi = 0; qi < 4; qi++)
+                        for (int q2 = 0; q2 < 2; q2++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[qi][c] += (double)__fmul_rn(kv[c].w, qv[qi].w);
+                            for (int c = 0; c < 4; c++) acc[qi + q2][c] += (double)pr2[q2][c].y;
+                    }
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -983,25 +989,40 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
     {
         const int qg = lane >> 4, dg = lane & 15;
         const float4 *vbase = reinterpret_cast<const float4 *>(p.vcache + (size_t)h * p.P * DK) + dg;
-        for (int j = wave; j < Tmax; j += 4 * NW) {      // 4 keys of this slice per trip: all loads first
-            float4 v[4], pr[4];
+        // 4 keys of this slice per trip, all loads first.  Whole trips carry no guards (every key < Tmax <= t_cap: nothing to clamp, no probability to zero): the
+        // guarded form spent 33 of its 200 VALU instructions per trip on clamps, 64-bit row addresses and exec masks
+        auto mac4 = [&](const at_f4 &v, const at_f4 &pr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int qi = 0; qi < 4; qi++) {
+                const at_f2 pp = {pr[qi], pr[qi]};
+                const at_f2 a = v.lo * pp, b = v.hi * pp;
+                acc[qi][0] += (double)a.x; acc[qi][1] += (double)a.y; acc[qi][2] += (double)b.x; acc[qi][3] += (double)b.y;
+            }
+        };
+        const at_f4 *vrow = reinterpret_cast<const at_f4 *>(vbase);
+        const float *Sq = S + 4 * qg;
+        int j = wave;
+        for (; j + 3 * NW < Tmax; j += 4 * NW) {
+            at_f4 v[4], pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[u] = vrow[(size_t)(j + NW * u) * (DK / 4)];
+                pr[u] = *reinterpret_cast<const at_f4 *>(Sq + (size_t)(j + NW * u) * G);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) mac4(v[u], pr[u]);
+        }
+        if (j < Tmax) {                                   // the last, partial trip
+            at_f4 v[4], pr[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int jj = j + NW * u;
-                v[u] = vbase[(size_t)min(jj, t_cap - 1) * (DK / 4)];
-                pr[u] = (jj < Tmax) ? *reinterpret_cast<const float4 *>(S + (size_t)jj * G + 4 * qg) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = vrow[(size_t)min(jj, t_cap - 1) * (DK / 4)];
+                pr[u] = *reinterpret_cast<const at_f4 *>(Sq + (size_t)min(jj, t_cap - 1) * G);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (j + NW * u < Tmax) {                  // a hidden key has p = 0 and adds +-0: the accumulator is unchanged
-                    const float pq[4] = {pr[u].x, pr[u].y, pr[u].z, pr[u].w};
-#pragma unroll
-                    for (int qi = 0; qi < 4; qi++) {
-                        acc[qi][0] += (double)__fmul_rn(v[u].x, pq[qi]); acc[qi][1] += (double)__fmul_rn(v[u].y, pq[qi]);
-                        acc[qi][2] += (double)__fmul_rn(v[u].z, pq[qi]); acc[qi][3] += (double)__fmul_rn(v[u].w, pq[qi]);
-                    }
-                }
-            }
+            for (int u = 0; u < 4; u++)
+                if (j + NW * u < Tmax) mac4(v[u], pr[u]);   // (a key past Tmax is not touched: its V row may never have been written)
         }
     }
     ATTN_STAMP(3);
