@@ -16,7 +16,8 @@ find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_sta
 cd $R
 timeout 200 python tools/api_loop_modes.py 2>&1 | grep -v loading > $OUT/api_loop_modes_r5.txt
 timeout 300 python tools/long_context_sweep.py 63 103 255 256 300 511 512 700 1023 2>&1 | grep -v loading > $OUT/long_context_sweep_r5.txt
-timeout 100 tools/microbench22 > $OUT/microbench22_mfma_stamps_r5.txt 2>&1
-timeout 100 tools/microbench23 512 > $OUT/microbench23_attn_stamps_r5.txt 2>&1
+# (built here, against the headers as they are: a binary left over from an earlier revision of the kernel reads stamps the kernel no longer writes)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMFMA_STAMPS -Ibiogpt.cpp_amd/csrc -Iinclude -o /tmp/microbench22 tools/microbench22.hip && timeout 100 /tmp/microbench22 > $OUT/microbench22_mfma_stamps_r5.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DATTN_STAMPS -Ibiogpt.cpp_amd/csrc -Iinclude -o /tmp/microbench23 tools/microbench23.hip && timeout 100 /tmp/microbench23 512 > $OUT/microbench23_attn_stamps_r5.txt 2>&1
 timeout 300 python tools/soak_two_contexts_r5.py 600 300 2>&1 | grep -v "loading\|hand-off" > $OUT/soak_two_contexts_r5.txt
 ls -la $OUT

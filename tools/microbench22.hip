@@ -1,5 +1,5 @@
 // matmul_mfma_kernel (csrc/kernels_mfma.hip.h) alone, on synthetic operands, with per-wave shader-clock stamps: where does a workgroup's time go?
-//   stamps of a computing wave: 0 entry, 1 past barrier 0 (phase 0 landed), 2 loop done, (3 unused);  staging wave: 0 entry, 1 DMAs of phase 0 issued, 2 landed, 3 exit
+//   stamps of a computing wave: 0 entry, 1 its phase-0 DMAs issued, 2 loop done, (3 unused);  staging wave: 0 entry, 1 DMAs of phase 0 issued, 2 landed, 3 exit
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMFMA_STAMPS -Ibiogpt.cpp_amd/csrc -Iinclude -o tools/microbench22 tools/microbench22.hip && tools/microbench22
 #include "kernels_mfma.hip.h"
 #include <cstdio>
@@ -50,7 +50,7 @@ void run(const char *name, int M, int N, size_t sm_override = 0) {
     double c01 = 0, c12 = 0, s01 = 0, s12 = 0, s03 = 0; size_t nw = 0, nwg = grid.x * grid.y;
     std::vector<double> start, wend;
     for (size_t w = 0; w < nwg; w++) {
-        for (int v = 0; v < 4; v++) { const u64 *q = &t[(w * 5 + v) * 8]; wend.push_back((double)q[5]); c01 += (double)(q[3] - q[0]); c12 += (double)(q[2] - q[3]); s01 += (double)(q[1] - q[0]); nw++; }
+        for (int v = 0; v < 4; v++) { const u64 *q = &t[(w * 5 + v) * 8]; wend.push_back((double)q[5]); c01 += (double)(q[1] - q[0]); c12 += (double)(q[2] - q[1]); s01 += (double)(q[1] - q[0]); nw++; }
         if (K > 1024) { const u64 *q = &t[(w * 5 + 4) * 8]; s12 += (double)(q[2] - q[1]); s03 += (double)(q[3] - q[0]); }
         start.push_back((double)t[(w * 5) * 8 + 4]);
     }
@@ -73,12 +73,15 @@ void run(const char *name, int M, int N, size_t sm_override = 0) {
         avgconc /= std::max(1, ncu);
     }
     std::sort(start.begin(), start.end()); std::sort(wend.begin(), wend.end());
-    printf("%-10s M %5d K %5d N %4d  %4zu workgroups  %7.2f us per launch | computing waves: entry->barrier0 %7.0f cyc, loop %7.0f cyc | phase-0 DMAs issued at +%6.0f; staging wave: landed +%6.0f, exit %7.0f | wall (10 ns ticks): entries median +%.0f last +%.0f, loop ends first +%.0f median +%.0f last +%.0f | %d compute units seen, workgroups at a time on one: max %d, mean of the per-unit maxima %.2f\n",
+    printf("%-10s M %5d K %5d N %4d  %4zu workgroups  %7.2f us per launch | computing waves: entry -> phase-0 DMAs issued %7.0f cyc, from there to the loop's end %7.0f cyc | (the same, all waves) +%6.0f; staging wave: landed +%6.0f, exit %7.0f | wall (10 ns ticks): entries median +%.0f last +%.0f, loop ends first +%.0f median +%.0f last +%.0f | %d compute units seen, workgroups at a time on one: max %d, mean of the per-unit maxima %.2f\n",
            name, M, K, N, nwg, ms * 1000.0 / reps, c01 / nw, c12 / nw, s01 / nw, s12 / nwg, s03 / nwg, start[nwg / 2] - start[0], start[nwg - 1] - start[0], wend[0] - start[0], wend[wend.size() / 2] - start[0], wend.back() - start[0], ncu, maxconc, avgconc);
     hipFree(iq); hipFree(is); hipFree(aq); hipFree(ad); hipFree(as); hipFree(bias); hipFree(resid); hipFree(out); hipFree(kc); hipFree(vc); hipFree(qo); hipFree(oq); hipFree(od); hipFree(os); hipFree(gelu); hipFree(st); hipFree(ts);
 }
 int main() {
-    if (getenv("MB_GAPS")) { run<EPI_RESID, 1024>("out_proj", 1024, 512); return 0; }
+    if (getenv("MB_GAPS")) {      // per compute unit: workgroup entries (+) and loop ends (-) in 10 ns ticks (the first six units)
+        if (atoi(getenv("MB_GAPS")) == 2) run<EPI_GELU_Q8, 1024>("fc1", 4096, 512); else run<EPI_RESID, 1024>("out_proj", 1024, 512);
+        return 0;
+    }
     for (int N : {512, 64}) {
         run<EPI_RESID, 1024>("out_proj", 1024, N);
         run<EPI_RESID, 4096>("fc2", 1024, N);
