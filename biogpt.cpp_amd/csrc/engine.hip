@@ -13,6 +13,9 @@
 //   state     DevState + token ring (kernels read n_past / ids from HBM so the captured decode graph
 //             advances itself)
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -172,7 +175,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, proc_lock, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -218,6 +221,7 @@ struct EngineOptions {
         attn_tile = get("BIOGPT_HIP_ATTN_TILE", 1);
         graph_contended = get("BIOGPT_HIP_GRAPH_CONTENDED", 0);   // test switch: replay the five-launch eval graph even while ANOTHER context holds the pipeline slot (the arrangement of profiles/two_contexts_r4.txt)
         fault_stale = get("BIOGPT_HIP_FAULT_STALE", 0);           // test switch: every k-th replayed eval starts from the PREVIOUS mailbox slot (the stale-row symptom, injected)
+        proc_lock = get("BIOGPT_HIP_PROC_LOCK", 1);               // one process per device drives the pipelined launches (engine_xpipe.inc, xpipe_process_lock)
         xpipe_as_res = get("BIOGPT_HIP_XPIPE_AS_RES", 0);          // measurement only: ordinary pipelined launches through the RES instantiations (tests/test_gpu_resident.py)
         eval_graph_split = get("BIOGPT_HIP_EVAL_GRAPH_SPLIT", 0);   // 0: per entry point (eval_topk: one graph, eval: two segments)
     }
@@ -297,6 +301,7 @@ struct biogpt_hip_ctx {
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
+    bool xp_proc_ref = false;              // this context counts in the process's hold on the device's lock file (guarded by g_xp_mu)
     bool xp_in_call = false;               // guarded by g_xp_mu: an API call of this context has taken the device's pipeline slot and has not returned yet
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
     int xp_exp_n = 0;      // the exp table's non-zero negative slice the attention workgroups keep in LDS

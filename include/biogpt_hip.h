@@ -121,7 +121,8 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx);
 /* The single-token decode step of BioGPT-base-shaped block-quantized models (Q4_0 .. Q8_0) with at most 256 keys runs as ONE
  * persistent launch pipelined over the 8 XCDs (csrc/kernels_xpipe.hip.h).  1: this context uses it; 0: switched off
  * (BIOGPT_HIP_XPIPE=0) or another context of the device holds the path; -1: not available (model shape / weight type /
- * device) or abandoned after a disturbed launch (the call was repeated on the five-launch layer). */
+ * device; another PROCESS holds the device's lock file) or abandoned after a disturbed launch (the
+ * call was repeated on the five-launch layer). */
 int biogpt_hip_xpipe_state(const biogpt_hip_ctx *ctx);
 
 int biogpt_hip_get_hparams(const biogpt_hip_ctx *ctx, biogpt_hip_hparams *out);

@@ -487,3 +487,62 @@ def test_resident_instantiations_as_ordinary_multi_token_launches(pkg, oracle, f
         assert tok == int(ids_res[k]), "%s: token %d: oracle %d, RES instantiation %d" % (name, k, tok, int(ids_res[k]))
         lo = o.eval([tok], n_past)
         n_past += 1
+
+
+_SECOND_PROCESS = r"""
+import sys, os, json, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import _pkg
+pkg = _pkg.load()
+m = pkg.BiogptModel.load(sys.argv[2], verbosity=0)
+state = m.xpipe_state()
+prompt = [2, 900, 17, 4211, 8]
+t0 = time.time()
+lg = m.eval(prompt, 0)
+ids, n_past = [], len(prompt)
+for k in range(24):
+    tok = int(lg.argmax()); ids.append(tok)
+    lg = m.eval([tok], n_past); n_past += 1
+print(json.dumps({"state": state, "state_after": m.xpipe_state(), "ids": ids, "row": [float(v) for v in lg[:64]], "seconds": time.time() - t0}))
+"""
+
+
+def test_a_second_process_on_the_device_stays_off_the_pipeline(pkg, files, tmp_path):
+    """Two PROCESSES on one device: persistent launches of both would each hold part of the compute units and wait for the rest.  The process
+    that prepares a pipelined context first holds an advisory lock on the device's lock file (engine_xpipe.inc, xpipe_process_lock); a second process finds it taken,
+    reports xpipe_state -1 and serves the reference's loop (main.cpp:91-151) on the five-launch layer -- same ids, same rows, no hand-off time-outs -- while the first
+    keeps its resident launch going.  When the first process's contexts are gone, a new process gets the pipeline."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "second.py"
+    script.write_text(_SECOND_PROCESS)
+
+    def second():
+        env = dict(os.environ); env.pop("BIOGPT_HIP_PROC_LOCK", None)
+        r = subprocess.run([sys.executable, str(script), root, files["q4_0"]], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "hand-off" not in r.stderr and "timed out" not in r.stderr, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    g = pkg.BiogptModel.load(files["q4_0"])
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    prompt = [2, 900, 17, 4211, 8]
+    lg = g.eval(prompt, 0)
+    ids, n_past = [], len(prompt)
+    for k in range(12):
+        tok = int(lg.argmax()); ids.append(tok)
+        lg = g.eval([tok], n_past); n_past += 1
+    other = second()                      # runs while this process's resident launch may still be on the device
+    assert other["state"] == -1 and other["state_after"] == -1
+    for k in range(12, 24):
+        tok = int(lg.argmax()); ids.append(tok)
+        lg = g.eval([tok], n_past); n_past += 1
+    assert g.xpipe_state() == 1
+    assert other["ids"] == ids
+    assert np.array_equal(np.asarray(other["row"], dtype=np.float32), lg[:64])
+    assert other["seconds"] < 20.0
+    g.close()
+    again = second()                      # the lock went with the last pipelined context of this process
+    assert again["state"] == 1 and again["ids"] == ids
