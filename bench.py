@@ -671,6 +671,13 @@ def main():
         except Exception as e:
             out["cpu_baseline_error"] = str(e)
 
+    # the PMC passes below are child processes on this device: the pipelined launches belong to ONE process per device (engine_xpipe.inc, xpipe_process_lock), and
+    # everything that is timed is done -- this process lets go of its context (and with it of the device's lock file) first
+    if world == 1 and not args.no_pmc:
+        try:
+            model.close()
+        except Exception:
+            pass
     # ---- roofline.traffic: HBM-side bytes per launch of the dominant kernel from the PMC counters, each counter in its OWN rocprofv3 pass over a small child
     #      process (tools/pmc_target.py: 24 single-token launches of the pipelined kernel at 104 keys), after everything that is timed
     if world == 1 and args.ftype.startswith("q") and not prefill and not args.no_pmc and "roofline" in out and "dec_xpipe" in out["roofline"].get("kernel", ""):
