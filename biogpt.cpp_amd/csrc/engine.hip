@@ -2228,7 +2228,7 @@ int biogpt_hip_read_kv(biogpt_hip_ctx *ctx, int which, size_t offset, size_t cou
     if (!ctx || !out) BG_FAIL(-1, "null argument");
     const size_t L = (size_t)ctx->hp.n_layer, P = (size_t)ctx->hp.n_positions, D = (size_t)ctx->hp.d_model, H = (size_t)ctx->hp.n_head;
     const size_t dk = D / H, total = L * P * D;
-    if (offset + count > total) BG_FAIL(-1, "KV range out of bounds");
+    if (offset > total || count > total - offset) BG_FAIL(-1, "KV range out of bounds");      // (no sum that could wrap)
     if (count == 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
     if (!resident_stop(ctx)) return -2;
