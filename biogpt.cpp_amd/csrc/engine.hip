@@ -302,6 +302,7 @@ struct biogpt_hip_ctx {
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
     uint32_t *xp_err_host = nullptr;
     bool xp_proc_ref = false;              // this context counts in the process's hold on the device's lock file (guarded by g_xp_mu)
+    bool xp_foreign = false;               // another process holds the device's lock file: no pipelined launches AND no replay of captured five-launch steps here
     bool xp_in_call = false;               // guarded by g_xp_mu: an API call of this context has taken the device's pipeline slot and has not returned yet
     bool xp_tripped = false;               // set by xpipe_check when the pipeline failed in the call that just synchronised: the API entry repeats the call once
     int xp_exp_n = 0;      // the exp table's non-zero negative slice the attention workgroups keep in LDS
@@ -342,6 +343,9 @@ struct biogpt_hip_ctx {
 };
 
 static bool resident_stop(biogpt_hip_ctx *c);   // ends a resident single-token launch (defined with the eval entry points)
+// An entry point that enqueues work of its own (generate_*, eval_all, eval_prompt, the bench calls) makes the row of an EARLIER replayed single-token eval history: its lineage
+// watch must not fire on a later biogpt_hip_read_logits (it would re-evaluate the old token at the old position over this call's K / V rows).  ADVICE r5.
+static inline void disarm_lineage(biogpt_hip_ctx *c) { c->dev_stamp_expect = 0; c->stamp_expect = 0; }
 
 namespace {
 
@@ -641,8 +645,14 @@ bool ensure_tile_images(biogpt_hip_ctx *c) {
     };
     for (const auto &L : c->plan.layers) { one(L.qkv); one(L.o); one(L.fc1); one(L.fc2); }
     one(c->plan.lm_head);
-    if (!retile_ok) BG_FAIL(false, "building the row-tiled weight image failed");
-    HIP_TRY(false, hipGetLastError());
+    if (!retile_ok || hipGetLastError() != hipSuccess) {
+        // a partially built image must never be used (the next call would find tile_img non-null and run the matrix-core chain on it): drop it, the passes stay on the VALU chain
+        (void)hipStreamSynchronize(c->stream); (void)hipGetLastError();
+        (void)hipFree(c->tile_img);
+        c->tile_img = nullptr; c->tile_img_failed = true;
+        if (c->opt.verbose) fprintf(stderr, "biogpt_hip: building the row-tiled weight image failed; many-column passes stay on the 8-column kernels\n");
+        return true;
+    }
     return true;
 }
 
@@ -1001,7 +1011,9 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                 // a pass of many query columns: register-tiled kernel, 16 queries per workgroup share every K / V row they load
                 // (BIOGPT_HIP_ATTN_TILE=0: the first grouped kernel, 8 queries per workgroup, kept as the A/B arm of the equivalence test)
                 a.t_cap = std::min(P, t_max);
-                if (opt().attn_tile) {
+                // (the tile kernel addresses a thread's four consecutive key rows from ONE base clamped to P - 4: that is only their own rows when 4 | P and P >= 4;
+                //  any other table size takes the grouped kernel, which clamps row by row)
+                if (opt().attn_tile && (P & 3) == 0 && P >= 4) {
                     const size_t smb = bgk::attn_tile_smem_bytes<16>(a.t_cap);
                     const void *fn = reinterpret_cast<const void *>(bgk::attn_tile_kernel<16>);
                     if (smb > 64 * 1024 && !c->lds_attr_done.count(fn)) {
@@ -1872,7 +1884,7 @@ int biogpt_hip_eval_all(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t n, i
     if (!logits_out) BG_FAIL(-1, "null logits buffer");
     if (!check_eval_args(ctx, tokens, n, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
+    if (!resident_stop(ctx)) return -2; disarm_lineage(ctx);
     if ((size_t)n > ctx->logits_all_rows) {
         if (ctx->logits_all) (void)hipFree(ctx->logits_all);
         ctx->logits_all = nullptr;
@@ -1915,7 +1927,7 @@ static int eval_prompt_once(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     if (n_batch < 1) BG_FAIL(-1, "n_batch must be >= 1");
     if (!check_eval_args(ctx, tokens, n_tokens, n_past)) return -1;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
+    if (!resident_stop(ctx)) return -2; disarm_lineage(ctx);
     if (!enqueue_prompt(ctx, tokens, n_tokens, n_past, n_batch)) return -2;
     if (logits_out) {
         HIP_TRY(-2, hipMemcpyAsync(logits_out, ctx->logits, (size_t)ctx->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1937,7 +1949,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     n_predict = std::min(n_predict, ctx->hp.n_positions - n_prompt);  // main.cpp:82
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
+    if (!resident_stop(ctx)) return -2; disarm_lineage(ctx);
     bool use_graph = ctx->opt.no_graph == 0;
     if ((ctx->opt.dbg & 128) && !ctx->tstamp) {      // profiling builds: stage stamps of the pipelined launches (tools/tail_timeline.py)
         HIP_TRY(-2, hipMalloc(&ctx->tstamp, (size_t)4 << 20));
@@ -2081,7 +2093,7 @@ static int generate_greedy_batch_once(biogpt_hip_ctx *ctx, const int32_t *prompt
     n_predict = std::min(n_predict, P - max_len);  // main.cpp:82, for the longest prompt
     if (n_predict <= 0) return 0;
     HIP_TRY(-2, hipSetDevice(ctx->device));
-    if (!resident_stop(ctx)) return -2;
+    if (!resident_stop(ctx)) return -2; disarm_lineage(ctx);
     const size_t seq_stride = (size_t)hp.n_layer * P * D;
     if (n_seqs > ctx->batch_cap) {  // per-sequence F32 KV caches + state (192 MiB per BioGPT-base sequence)
         for (void *p : {(void *)ctx->bk, (void *)ctx->bv, (void *)ctx->seq, (void *)ctx->seq_gen}) if (p) (void)hipFree(p);

@@ -893,7 +893,8 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
             if (j0 + 64 * wave >= Tmax) break;                                   // this wave's 64 keys are past every query's context
             const int jb = j0 + 4 * kg;
             // the 4 key rows of this thread are consecutive: ONE address, the row in the load's immediate offset (rows past the context are clamped into the head's
-            // P >= 4 allocated rows; what is computed from them is never stored)
+            // allocated rows; what is computed from them is never stored).  Needs 4 | P and P >= 4 -- jb is a multiple of 4, so a clamped base never holds a key that
+            // IS stored; the host only launches this kernel for such tables (engine.hip), any other size takes attn_group_kernel
             const at_f4 *krow0 = reinterpret_cast<const at_f4 *>(kbase) + (size_t)min(jb, p.P - 4) * (DK / 4);
             double acc[4][4];
 #pragma unroll

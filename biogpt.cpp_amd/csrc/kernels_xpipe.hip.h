@@ -210,7 +210,6 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
     }      // ordinary launches: the plain sweep (declared below), etag stays the epoch
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = 0u;
-    etag = (etag);
     if (etag == 0u) return;
     if constexpr (CROSS) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];

@@ -151,6 +151,8 @@ SHAPES = [
     (1000, 1, 5, 33, 96, 320),      # d_ff < d_model, dk = 64, position table shorter than one 64-key tile
     (50, 1, 2, 200, 64, 128),       # dk = 64 with tables that are not multiples of 64 keys: every decode
     (50, 1, 2, 300, 64, 128),       #   attention variant (<=256, <=512, <=1024 keys) meets a ragged last tile
+    (50, 1, 2, 90, 64, 128),        # dk = 64, a table that is not a multiple of 4 rows and a pass of >= 80 columns: the register-tiled pass attention
+    (50, 1, 2, 201, 64, 128),       #   (one clamped base for 4 key rows) must not be taken; keys 88, 89 / 200 are scored against their own rows
     (50, 1, 2, 600, 64, 128),
     (50, 1, 2, 1000, 64, 128),
     (50, 1, 2, 1500, 64, 128),      # beyond 1024 keys: generic attention
