@@ -1014,13 +1014,17 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
                 // (the tile kernel addresses a thread's four consecutive key rows from ONE base clamped to P - 4: that is only their own rows when 4 | P and P >= 4;
                 //  any other table size takes the grouped kernel, which clamps row by row)
                 if (opt().attn_tile && (P & 3) == 0 && P >= 4) {
+                    // up to 640 keys the K / V rows of the two MAC loops travel through a ring in LDS, two steps ahead (global_load_lds); beyond, the ring has no room
+                    // beside the scores in a 2-workgroups-per-compute-unit footprint: loads at the top of each step
+                    const bool dma = bgk::attn_tile_dma_ok(a.t_cap) && opt().attn_tile != 2;      // (BIOGPT_HIP_ATTN_TILE=2: the A/B arm without the ring)
                     const size_t smb = bgk::attn_tile_smem_bytes<16>(a.t_cap);
-                    const void *fn = reinterpret_cast<const void *>(bgk::attn_tile_kernel<16>);
+                    const void *fn = dma ? reinterpret_cast<const void *>(bgk::attn_tile_kernel<16, true>) : reinterpret_cast<const void *>(bgk::attn_tile_kernel<16, false>);
                     if (smb > 64 * 1024 && !c->lds_attr_done.count(fn)) {
                         HIP_TRY(false, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgk::attn_tile_smem_bytes<16>(P)));
                         c->lds_attr_done.insert(fn);
                     }
-                    hipLaunchKernelGGL((bgk::attn_tile_kernel<16>), dim3(H, (N + 15) / 16), dim3(512), smb, st, a);
+                    if (dma) hipLaunchKernelGGL((bgk::attn_tile_kernel<16, true>), dim3(H, (N + 15) / 16), dim3(512), smb, st, a);
+                    else hipLaunchKernelGGL((bgk::attn_tile_kernel<16, false>), dim3(H, (N + 15) / 16), dim3(512), smb, st, a);
                 } else {
                     hipLaunchKernelGGL((bgk::attn_group_kernel<8>), dim3(H, (N + 7) / 8), dim3(512), bgk::attn_group_smem_bytes(a.t_cap), st, a);
                 }

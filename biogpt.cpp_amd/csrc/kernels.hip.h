@@ -96,6 +96,8 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
 constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i inside each 16
 constexpr int DPP_WAVE_SHR1 = 0x138;       // lane i <- lane i-1 across the whole wave (GFX9)
+constexpr int DPP_ROW_ROR4 = 0x124;        // lane i <- lane (i + 4) mod 16 inside each row of 16 (rotation: every lane gets a value)
+constexpr int DPP_ROW_ROR8 = 0x128;
 
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));

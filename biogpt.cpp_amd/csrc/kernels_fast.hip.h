@@ -826,11 +826,22 @@ __global__ __launch_bounds__(512) void attn_group_kernel(const AttnParams p) {
 //           rows) + one LDS float4 of 4 probabilities for 16 products; the 4 key slices are added at the end
 // 16 queries share every K / V row they load (8 before); 256 threads, ~40 KB of LDS -> 4 workgroups per compute unit.
 // Visibility per query as everywhere (visible_keys: the end of its own reference chunk, F1).
+// DMA form (contexts up to 640 keys): behind the scores a ring of 3 x 1 KB per wave (24 KB) that the K / V rows of the two MAC loops travel through (global_load_lds)
+constexpr int ATTN_TILE_RING = 3;
+__host__ __device__ inline bool attn_tile_dma_ok(int t_cap) { return (size_t)t_cap * 16 * 4 + (size_t)ATTN_TILE_RING * 8 * 1024 <= (size_t)8 * 16 * 64 * 8; }
 template <int G>
 __host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
     const size_t sc = (size_t)t_cap * G * 4, po = (size_t)8 * G * 64 * 8;
-    return (sc > po ? sc : po) + (size_t)G * 64 * 4 + 32 * G * 4 + 32 * G * 8 + G * 4 + 64;
+    return (sc > po ? sc : po) + (size_t)G * 64 * 4 + 36 * G * 4 + 8 * G * 8 + 64;
 }
+// One 1 KB DMA: 64 lanes x 16 bytes from the lanes' own global addresses to LDS bytes lds .. lds + 1023, lane-linear (global_load_lds_dwordx4; M0 = the LDS address, saved and
+// restored around it: the compiler owns M0).  Inline assembly so that hipcc does not count it: a load it counts is drained by a vmcnt(0) in front of the next ds_read of ANY
+// address (it sees LDS written by VMEM), which would wait for the prefetch just issued.  The waits below (at_wait_dma) are ours.
+__device__ __forceinline__ void at_dma16(const void *gsrc, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+}
+template <int N> __device__ __forceinline__ void at_wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // 512 threads = 8 waves: the critical path of the pass is its longest tile (512 keys), whose per-thread work this halves
 // against a 256-thread version; two workgroups per compute unit = 4 waves per SIMD, hence the 128-register bound.
@@ -848,9 +859,9 @@ __host__ __device__ inline size_t attn_tile_smem_bytes(int t_cap) {
 #endif
 typedef float at_f4 __attribute__((ext_vector_type(4)));
 typedef float at_f2 __attribute__((ext_vector_type(2)));
-template <int G>
+template <int G, bool DMA = false>
 __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
-    constexpr int DK = 64, NW = 8;
+    constexpr int DK = 64, NW = 8, RING = ATTN_TILE_RING;
     static_assert(G == 16, "thread maps assume 16 queries: 4 query groups x 128 key groups, 16 queries x 32 key slots, 8 x (4 x 16) for PV");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t_cap = p.t_cap;
@@ -858,12 +869,17 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
     float *const S = reinterpret_cast<float *>(smem_raw);                       // [key][G]: scores, then e, then probabilities
     double *const pvp = reinterpret_cast<double *>(smem_raw);                   // [8 slices][G][DK] partial outputs (after the PV loop)
     float *const Qs = reinterpret_cast<float *>(smem_raw + main_bytes);         // [G][DK]
-    float *const s_mx = Qs + G * DK;                                            // [32 slots][G]
-    double *const s_sum = reinterpret_cast<double *>(s_mx + 32 * G);            // [32 slots][G]
-    float *const s_inv = reinterpret_cast<float *>(s_sum + 32 * G);             // [G]
+    constexpr int MXP = 36;                                                     // floats per query row of s_mx (32 + 4: the 16 queries' 16-byte reads spread over the banks)
+    float *const s_mx = Qs + G * DK;                                            // [G][MXP]: per query the maxima of the 32 (wave, lane row) key groups of the scores phase
+    double *const s_sum = reinterpret_cast<double *>(s_mx + G * MXP);           // [8 waves][G]
     const int h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, D = p.D;
+    // DMA: this wave's ring behind the scores: slot r at ring + r * 1024 (generic pointer for the reads, LDS byte address in an SGPR for the DMAs)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const size_t ring_off = (((size_t)t_cap * G * 4 + 1023) & ~(size_t)1023) + (size_t)wv * (RING * 1024);
+    const unsigned char *const ring = smem_raw + ring_off;
+    const unsigned ring_lds = DMA ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem_raw + (int)ring_off) : 0u;
     // dispatch order: the long-context half of the tiles first (largest first), then the short half in ASCENDING order -- the
     // second round of workgroups then lands a short tile next to each long one (44.9 -> 41.2 us against plain longest-first)
     const int ny = (int)gridDim.y, yb = (int)blockIdx.y, nhalf = (ny + 1) / 2;
@@ -878,6 +894,7 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
         const int q = tid >> 4, d4 = tid & 15;
         reinterpret_cast<float4 *>(Qs)[tid] = *reinterpret_cast<const float4 *>(p.q + (size_t)min(i0 + q, N - 1) * D + (size_t)h * DK + 4 * d4);
     }
+    for (int i = tid; i < G * MXP; i += 512) s_mx[i] = -INFINITY;
     const int Tmax = visible_keys(p.st, min(i0 + G - 1, N - 1), N);              // visibility grows with the column index
     __syncthreads();
 
@@ -896,6 +913,13 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
             // allocated rows; what is computed from them is never stored).  Needs 4 | P and P >= 4 -- jb is a multiple of 4, so a clamped base never holds a key that
             // IS stored; the host only launches this kernel for such tables (engine.hip), any other size takes attn_group_kernel
             const at_f4 *krow0 = reinterpret_cast<const at_f4 *>(kbase) + (size_t)min(jb, p.P - 4) * (DK / 4);
+            // DMA: lane = key (j0 + 64 wave + lane), one 16-byte piece (4 dims) of its row per step, two steps ahead of the arithmetic: the loop above (loads at the top of
+            // a step, waited for at once) left a wave standing for an L2 round trip per step with one other wave per SIMD to cover it.  Step m's piece of key k of the
+            // wave lies at ring slot m mod 3, byte 16 k; the 4 query groups' lanes of a key group read the same 4 pieces.  The ring always runs two requests ahead (the
+            // last two steps re-request steps 0 and 1: a constant vmcnt(2)).
+            const unsigned char *const kdma = reinterpret_cast<const unsigned char *>(kbase) + (size_t)min(j0 + 64 * wv + lane, p.P - 1) * (DK * 4);
+            if (DMA) { at_dma16(kdma, ring_lds); at_dma16(kdma + 16, ring_lds + 1024); }
+            int rs = 0;                                                          // slot of step m
             double acc[4][4];
 #pragma unroll
             for (int qi = 0; qi < 4; qi++)
@@ -904,8 +928,18 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
 #pragma unroll 1
             for (int m = 0; m < DK / 4; m++) {
                 at_f4 kv[4], qv[4];
+                if (DMA) {
+                    const int rn = rs == 0 ? 2 : rs - 1;                         // (m + 2) mod 3
+                    at_dma16(kdma + 16 * ((m + 2) & 15), ring_lds + rn * 1024);
+                    at_wait_dma<2>();
+                    const at_f4 *const kb = reinterpret_cast<const at_f4 *>(ring + rs * 1024) + 4 * (lane >> 2);
 #pragma unroll
-                for (int c = 0; c < 4; c++) kv[c] = krow0[c * (DK / 4) + m];
+                    for (int c = 0; c < 4; c++) kv[c] = kb[c];
+                    rs = rs == 2 ? 0 : rs + 1;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) kv[c] = krow0[c * (DK / 4) + m];
+                }
 #pragma unroll
                 for (int qi = 0; qi < 4; qi++) qv[qi] = reinterpret_cast<const at_f4 *>(qbase)[qi * (DK / 4) + m];
                 // two dims of ONE (query, key) per packed multiply: the operands are the register pairs the 16-byte loads left behind (pairing two queries of one
@@ -929,56 +963,84 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
                             for (int c = 0; c < 4; c++) acc[qi + q2][c] += (double)pr2[q2][c].y;
                     }
             }
+            if (DMA) at_wait_dma<0>();                                           // (the two re-requests: the ring is quiet before it is used again)
+            // the softmax's first pass, taken while the scores are in registers: per query the maximum of this thread's keys, then of the four key groups of its lane row
+            // (lanes 4 apart: same query group) -> one value per (wave, row, query) in s_mx (preset to -inf: a wave without keys writes nothing)
+            float mq[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int j = jb + c;
-                if (j < t_cap)
-                    *reinterpret_cast<float4 *>(S + (size_t)j * G + 4 * qg) =
-                        make_float4(j < Tq[0] ? (float)acc[0][c] : -INFINITY, j < Tq[1] ? (float)acc[1][c] : -INFINITY,
-                                    j < Tq[2] ? (float)acc[2][c] : -INFINITY, j < Tq[3] ? (float)acc[3][c] : -INFINITY);
+                if (j < t_cap) {
+                    const float4 sc = make_float4(j < Tq[0] ? (float)acc[0][c] : -INFINITY, j < Tq[1] ? (float)acc[1][c] : -INFINITY,
+                                                  j < Tq[2] ? (float)acc[2][c] : -INFINITY, j < Tq[3] ? (float)acc[3][c] : -INFINITY);
+                    *reinterpret_cast<float4 *>(S + (size_t)j * G + 4 * qg) = sc;
+                    mq[0] = fmaxf(mq[0], sc.x); mq[1] = fmaxf(mq[1], sc.y); mq[2] = fmaxf(mq[2], sc.z); mq[3] = fmaxf(mq[3], sc.w);
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; qi++) {
+                mq[qi] = fmaxf(mq[qi], dpp_f<DPP_ROW_ROR4>(mq[qi]));
+                mq[qi] = fmaxf(mq[qi], dpp_f<DPP_ROW_ROR8>(mq[qi]));
+            }
+            if ((lane & 12) == 0) {
+                const int grp = wave * 4 + (lane >> 4);
+#pragma unroll
+                for (int qi = 0; qi < 4; qi++) {
+                    float *const slot = s_mx + (4 * qg + qi) * MXP + grp;
+                    *slot = (j0 == 0) ? mq[qi] : fmaxf(mq[qi], *slot);       // (contexts beyond 512 keys: the same lane comes back to its slot)
+                }
             }
         }
     }
+    __builtin_amdgcn_s_setprio(3);                           // the short, latency-bound phases go first when they compete with another workgroup's MAC loops for issue slots
     __syncthreads();
     ATTN_STAMP(1);
 
     // ---- softmax (ggml_soft_max: fp16-table exp, double row sum, p = fl(e * (float)(1/sum))) ----
+    // thread = (query, one of 32 key slots).  The maximum comes from the scores phase; 8 table lookups are in flight per thread; the row sum is a sum of fp16 values below
+    // 2^11 in double -- exact in any order -- so the slots are added lane to lane and wave to wave, and every thread takes the reciprocal itself (three barriers, were five).
     {
         const int q = tid & 15, slot = tid >> 4;           // 32 key slots
         const int Tw = (i0 + q < N) ? visible_keys(p.st, i0 + q, N) : 0;
-        float mx = -INFINITY;
-        for (int j = slot; j < Tw; j += 32) mx = fmaxf(mx, S[(size_t)j * G + q]);
-        s_mx[slot * G + q] = mx;
-        __syncthreads();
+        float mx;
+        {
+            const at_f4 *mrow = reinterpret_cast<const at_f4 *>(s_mx + q * MXP);
+            at_f4 m4 = mrow[0];
 #pragma unroll
-        for (int s2 = 0; s2 < 32; s2++) mx = fmaxf(mx, s_mx[s2 * G + q]);
+            for (int s2 = 1; s2 < 8; s2++) { const at_f4 t = mrow[s2]; m4.x = fmaxf(m4.x, t.x); m4.y = fmaxf(m4.y, t.y); m4.z = fmaxf(m4.z, t.z); m4.w = fmaxf(m4.w, t.w); }
+            mx = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
+        }
         double sum = 0.0;
-        for (int j = slot; j < Tw; j += 128) {           // 4 table lookups in flight per thread
-            float e[4];
+        for (int j = slot; j < Tw; j += 256) {
+            float e[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const int jj = j + 32 * u;
                 e[u] = (jj < Tw) ? h2f(p.exp_tab[f2h(__fsub_rn(S[(size_t)jj * G + q], mx))]) : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const int jj = j + 32 * u;
                 if (jj < Tw) { S[(size_t)jj * G + q] = e[u]; sum += (double)e[u]; }
             }
         }
-        s_sum[slot * G + q] = sum;
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);          // the wave's four slots of this query
+        if (lane < 16) s_sum[wave * G + q] = sum;
         __syncthreads();
-        if (slot == 0) {
-            double t = 0.0;
+        double t = 0.0;
 #pragma unroll
-            for (int s2 = 0; s2 < 32; s2++) t += s_sum[s2 * G + q];
-            s_inv[q] = (Tw > 0) ? inv_sum_f32(t) : 0.0f;
+        for (int w = 0; w < NW; w++) t += s_sum[w * G + q];
+        const float inv = (Tw > 0) ? inv_sum_f32(t) : 0.0f;
+        for (int j = slot; j < Tmax; j += 256) {
+            float pr[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int jj = j + 32 * u; pr[u] = (jj < Tw) ? S[(size_t)jj * G + q] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int jj = j + 32 * u; if (jj < Tmax) S[(size_t)jj * G + q] = __fmul_rn(pr[u], inv); }
         }
-        __syncthreads();
-        const float inv = s_inv[q];
-        for (int j = slot; j < Tmax; j += 32) S[(size_t)j * G + q] = (j < Tw) ? __fmul_rn(S[(size_t)j * G + q], inv) : 0.0f;
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     ATTN_STAMP(2);
 
     // ---- PV: wave = key slice (j mod 8), lane = (4 queries, 4 dims) ----
@@ -1003,6 +1065,42 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
         const at_f4 *vrow = reinterpret_cast<const at_f4 *>(vbase);
         const float *Sq = S + 4 * qg;
         int j = wave;
+        if (DMA) {
+            // a trip's four V rows (keys j, j + 8, j + 16, j + 24 of this wave's slice: 4 x 256 bytes) are ONE 1 KB DMA -- lane = (row u = lane / 16, piece lane % 16) --
+            // requested two trips ahead; lane (qg, dg) reads piece dg of the four rows (the four query groups' lanes the same bytes).  Rows past the context are clamped
+            // (never used); the ring always runs two requests ahead.
+            const unsigned char *const vb = reinterpret_cast<const unsigned char *>(p.vcache + (size_t)h * p.P * DK) + (lane & 15) * 16;
+            const int ju = wv + NW * (lane >> 4);                               // this lane's row in trip 0
+            auto vreq = [&](int trip, int slot) __attribute__((always_inline)) { at_dma16(vb + (size_t)min(ju + 4 * NW * trip, t_cap - 1) * (DK * 4), ring_lds + slot * 1024); };
+            vreq(0, 0); vreq(1, 1);
+            int rs = 0, trip = 0;
+            const at_f4 *const rb = reinterpret_cast<const at_f4 *>(ring) + (lane & 15);
+            for (; j + 3 * NW < Tmax; j += 4 * NW, trip++) {
+                at_f4 v[4], pr[4];
+                vreq(trip + 2, rs == 0 ? 2 : rs - 1);
+                at_wait_dma<2>();
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = rb[rs * 64 + u * 16];
+                    pr[u] = *reinterpret_cast<const at_f4 *>(Sq + (size_t)(j + NW * u) * G);
+                }
+                rs = rs == 2 ? 0 : rs + 1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) mac4(v[u], pr[u]);
+            }
+            at_wait_dma<0>();                                                    // (also: the ring is quiet before the area becomes pvp)
+            if (j < Tmax) {                               // the last, partial trip: requested already (slot rs)
+                at_f4 v[4], pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = rb[rs * 64 + u * 16];
+                    pr[u] = *reinterpret_cast<const at_f4 *>(Sq + (size_t)min(j + NW * u, t_cap - 1) * G);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (j + NW * u < Tmax) mac4(v[u], pr[u]);   // (a key past Tmax is not touched: its V row may never have been written)
+            }
+        } else {
         for (; j + 3 * NW < Tmax; j += 4 * NW) {
             at_f4 v[4], pr[4];
 #pragma unroll
@@ -1025,8 +1123,10 @@ __global__ __launch_bounds__(512, 4) void attn_tile_kernel(const AttnParams p) {
             for (int u = 0; u < 4; u++)
                 if (j + NW * u < Tmax) mac4(v[u], pr[u]);   // (a key past Tmax is not touched: its V row may never have been written)
         }
+        }
     }
     ATTN_STAMP(3);
+    __builtin_amdgcn_s_setprio(3);
     __syncthreads();                                      // every read of S is done: the area becomes pvp
     {
         const int qg = lane >> 4, dg = lane & 15;

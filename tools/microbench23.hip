@@ -1,4 +1,4 @@
-// attn_tile_kernel<16> (csrc/kernels_fast.hip.h) alone: one layer's attention of a 512-column prompt pass (-b 8 visibility), with per-workgroup stamps at the phase borders.
+// attn_tile_kernel<16, MB_DMA> (csrc/kernels_fast.hip.h) alone: one layer's attention of a 512-column prompt pass (-b 8 visibility), with per-workgroup stamps at the phase borders.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DATTN_STAMPS -Ibiogpt.cpp_amd/csrc -Iinclude -o tools/microbench23 tools/microbench23.hip && tools/microbench23
 #include "kernels_fast.hip.h"
 #include <cstdio>
@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cmath>
 using namespace bgk;
+#ifndef MB_DMA
+#define MB_DMA true
+#endif
 typedef unsigned long long u64;
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 512, H = 16, D = 1024, P = 1024, DK = 64;
@@ -26,13 +29,13 @@ int main(int argc, char **argv) {
     AttnParams a{}; a.q = q; a.kcache = kc; a.vcache = vc; a.out = out; a.st = st; a.exp_tab = et; a.N = N; a.D = D; a.dk = DK; a.P = P; a.t_cap = std::min(P, N);
     a.oq_q = oq; a.oq_d = od; a.oq_s = os; a.tstamp = ts;
     const size_t smb = attn_tile_smem_bytes<16>(a.t_cap);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(attn_tile_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_tile_smem_bytes<16>(P));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((attn_tile_kernel<16>), dim3(H, ny), dim3(512), smb, 0, a);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(attn_tile_kernel<16, MB_DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_tile_smem_bytes<16>(P));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((attn_tile_kernel<16, MB_DMA>), dim3(H, ny), dim3(512), smb, 0, a);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((attn_tile_kernel<16>), dim3(H, ny), dim3(512), smb, 0, a);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((attn_tile_kernel<16, MB_DMA>), dim3(H, ny), dim3(512), smb, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const size_t nwg = (size_t)H * ny;
