@@ -42,6 +42,7 @@
 namespace bgk {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
+typedef float mm_f2 __attribute__((ext_vector_type(2)));
 
 // ---- row-tiled, EXPANDED weight image -------------------------------------------------------------------------
 // src (SoA arena): qs[(row*BPR + b) * QB], sc[(row*BPR + b)], qh[(row*BPR + b)]
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
     // order: inside a computing wave a wait for an A operand would also wait for whatever DMA was issued before it (and the compiler, seeing LDS written by VMEM,
     // drains vmcnt before the next ds_read of any address).
     if (NW == 5 && wv == 4) {
-        int ls = threadIdx.x & 63; asm volatile("" : "+v"(ls));                 // (the compiler lays this block out BEHIND the computing waves' code and would hold the lane index over all of it)
+        int ls = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(ls));                 // (the compiler lays this block out BEHIND the computing waves' code and would hold the lane index over all of it)
 #pragma unroll 1
         for (int ph = 0; ph < NPH; ph++) {
             __builtin_amdgcn_s_waitcnt(0x0f70);                                 // vmcnt(0): landed
@@ -236,11 +237,16 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
     const int o_d = L::OFF_D + li * 16, o_s = L::OFF_S + li * 16;               // the column's block scales / sums; batch n is 256 bytes further
     const int o_w = L::OFF_W + wv * (BPP * SWF * 4) + 16 * g;                   // rows 4g .. 4g+3 of the tile's scales; block b is SWF * 4 bytes further
 
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    mm_f2 acc2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};                               // the lane's four sums, as two register pairs (packed f32 arithmetic)
     long sb[2][CH];                                                             // B operands of batch n: sb[n & 1]
     float4 sw[2][CH], sm[2][CH], xd[2], xs[2];                                  // weight scales / mins, activation scales / sums of batch n
     i32x4 cc[CH];                                                               // integer dots: block j of batch n until step n has converted them, then block j of batch n + 1
-    const i32x4 zero = {0, 0, 0, 0};
+    // The matrix core starts every block's integer dot at 0x4B400000 = the bit pattern of 12582912.0f (1.5 x 2^23): for |dot| < 2^22 (a block of 32 int8 products is below
+    // 2^19.1) the int32 result READ AS A FLOAT is 12582912 + dot exactly, and (that - 12582912.0f) is (float)dot -- one full-rate v_pk_add_f32 for two conversions where
+    // v_cvt_f32_i32 issues at half rate (tools/microbench24: 3.84 against 2.04 cycles per wave-instruction and SIMD at four waves).  Same value, bit for bit.
+    i32x4 zero = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};
+    asm volatile("" : "+v"(zero));                                              // (held in registers: the C operand of an MFMA is a register quad)
+    const mm_f2 bias2 = {__int_as_float(zero[0]), __int_as_float(zero[1])};    // 12582912.0f twice: the registers of the C operand, read as floats (no constant of its own)
 
     // one phase; LAST (compile time): the epilogue's inputs are requested inside it (the last phase is peeled off the loop so that they are not loop-carried)
     auto phase = [&](const int ph, auto last_tag) {
@@ -278,18 +284,19 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
             if (n + 1 < NB) lds_s(n + 1, (n + 1) & 1);
             if (n + 2 < NB) lds_b(n + 2, sb[n & 1]);                           // batch n's operands went into its MFMAs one step ago
             if (n == NB - QDEPTH && LAST) {                                     // the A-operand registers of the batches past the end are free from here
-                int t2 = threadIdx.x; asm volatile("" : "+v"(t2));              // indices recomputed, not held over the loop (the pipeline fills all 128 registers)
+                int t2 = wv * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(t2));   // indices recomputed from the wave's SGPR and the lane counter, not held over the loop (the pipeline fills all 128 registers; threadIdx.x itself would be one more)
                 const int orc2 = min((int)(blockIdx.x * 4 + (t2 >> 6)) * 16 + ((t2 >> 2) & 12), M - 4), colc2 = min(col0 + (t2 & 15), p.N - 1);
                 if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc2);
                 if (EPI == EPI_RESID) e_res = *reinterpret_cast<const float4 *>(p.resid + (size_t)colc2 * p.ldr + orc2);
             }
             // The arithmetic of the step in stages that the scheduler may not mix (sched_barrier): inside a stage every instruction is independent of its neighbours
             // (left to itself the compiler walks block by block -- cvt, mul, mul, add back to back, each waiting out the latency of the one before).
-            float t[CH][4];
+            mm_f2 t[CH][2];
 #pragma unroll
-            for (int j = 0; j < CH; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) t[j][r] = (float)cc[j][r];          // stage 1: the 16 conversions; the dots' registers are free
+            for (int j = 0; j < CH; j++) {                                      // stage 1: the 16 conversions as 8 packed adds; the dots' registers are free
+                const mm_f2 lo = {__int_as_float(cc[j][0]), __int_as_float(cc[j][1])}, hi = {__int_as_float(cc[j][2]), __int_as_float(cc[j][3])};
+                t[j][0] = lo - bias2; t[j][1] = hi - bias2;
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < CH; j++) {                                      // stage 2: the next batch's MFMAs, one per four first products
@@ -299,16 +306,12 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
                 }
                 const float4 dw = sw[n & 1][j];
                 const float xdj = j == 0 ? xd[n & 1].x : j == 1 ? xd[n & 1].y : j == 2 ? xd[n & 1].z : xd[n & 1].w;
-                const float dwr[4] = {dw.x, dw.y, dw.z, dw.w};
+                const mm_f2 dw2[2] = {{dw.x, dw.y}, {dw.z, dw.w}}, xd2 = {xdj, xdj};
                 if (WT == W_Q4_0) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) t[j][r] = __fmul_rn(t[j][r], dwr[r]);          // (dot * d_w) ...
-                } else {                                                        // d_w * d_x first: both products here, four apart (16 more registers if they waited for stage 3)
-                    float dx[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) dx[r] = __fmul_rn(dwr[r], xdj);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) t[j][r] = (WT == W_Q8_0) ? __fmul_rn(t[j][r], dx[r]) : __fmul_rn(dx[r], t[j][r]);   // dot * (d_w d_x) / (d_w d_x) * dot
+                    t[j][0] = t[j][0] * dw2[0]; t[j][1] = t[j][1] * dw2[1];                     // (dot * d_w) ...
+                } else {                                                        // d_w * d_x first: both products here
+                    const mm_f2 dx0 = dw2[0] * xd2, dx1 = dw2[1] * xd2;
+                    t[j][0] = t[j][0] * dx0; t[j][1] = t[j][1] * dx1;                           // dot * (d_w d_x) / (d_w d_x) * dot: the same product
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -317,27 +320,18 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
                 const float xdj = j == 0 ? xd[n & 1].x : j == 1 ? xd[n & 1].y : j == 2 ? xd[n & 1].z : xd[n & 1].w;
                 const float xsj = !Q81 ? 0.0f : j == 0 ? xs[n & 1].x : j == 1 ? xs[n & 1].y : j == 2 ? xs[n & 1].z : xs[n & 1].w;
                 const float4 mw = Q81 ? sm[n & 1][j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float mwr[4] = {mw.x, mw.y, mw.z, mw.w};
-                if (WT == W_Q4_0) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) t[j][r] = __fmul_rn(t[j][r], xdj);             // ... * d_x
-                }
-                if (Q81) {
-                    float ms[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ms[r] = __fmul_rn(mwr[r], xsj);                // m_w * s_x
-#pragma unroll
-                    for (int r = 0; r < 4; r++) t[j][r] = __fadd_rn(t[j][r], ms[r]);
-                }
+                const mm_f2 xd2 = {xdj, xdj}, xs2 = {xsj, xsj}, mw2[2] = {{mw.x, mw.y}, {mw.z, mw.w}};
+                if (WT == W_Q4_0) { t[j][0] = t[j][0] * xd2; t[j][1] = t[j][1] * xd2; }         // ... * d_x
+                if (Q81) { t[j][0] = t[j][0] + mw2[0] * xs2; t[j][1] = t[j][1] + mw2[1] * xs2; }   // + m_w * s_x (-ffp-contract=off: a product and a sum)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < CH; j++)                                        // stage 4: the sums, in block order (the one true dependence across blocks)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[r] = __fadd_rn(acc[r], t[j][r]);
+            for (int j = 0; j < CH; j++) {                                      // stage 4: the sums, in block order (the one true dependence across blocks)
+                acc2[0] = acc2[0] + t[j][0]; acc2[1] = acc2[1] + t[j][1];
+            }
             // the step's arithmetic is DONE in the step: without a side effect that names the sums, instruction selection sinks all of a one-phase kernel's
             // cvt / mul / add behind its last MFMA (the sums are only used by the epilogue) and every block's integer dots and scales stay live -- spills
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
         }
     };
 #pragma unroll 1
@@ -345,6 +339,7 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
     phase(NPH - 1, std::true_type{});
 
     MFMA_STAMP(2); MFMA_STAMP(5);
+    const float acc[4] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
     if (EPI == EPI_GELU_Q8) {
         __syncthreads();                                                        // everyone is done reading the activation area
         {
@@ -380,7 +375,7 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
         }
         return;
     }
-    int t3 = threadIdx.x; asm volatile("" : "+v"(t3));                          // (as above)
+    int t3 = wv * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(t3));   // (as above)
     const int orow = (int)(blockIdx.x * 4 + (t3 >> 6)) * 16 + ((t3 >> 2) & 12), col = col0 + (t3 & 15);
     if (!(col < p.N && orow < M)) return;
     if (EPI == EPI_QKV) {
