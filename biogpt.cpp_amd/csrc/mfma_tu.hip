@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -17,10 +18,12 @@ namespace {
 std::mutex g_attr_mu;
 std::set<std::pair<int, const void *>> g_attr_done;      // (device, kernel): > 64 KB of dynamic LDS needs the opt-in attribute once per device
 
-template <int WT, int EPI, int K>
+bool walk_ok() { static const bool on = [] { const char *e = getenv("BIOGPT_HIP_MFMA_WALK"); return !(e && e[0] == '0'); }(); return on; }
+
+template <int WT, int EPI, int K, int J = 1>
 hipError_t launch_one(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
-    const size_t sm = bgk::matmul_mfma_smem_bytes(K, bgk::TypeInfo<WT>::q81, EPI == bgk::EPI_GELU_Q8);
-    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K>);
+    const size_t sm = bgk::matmul_mfma_smem_bytes(K, bgk::TypeInfo<WT>::q81, EPI == bgk::EPI_GELU_Q8, J);
+    const void *fn = reinterpret_cast<const void *>(bgk::matmul_mfma_kernel<WT, EPI, K, J>);
     if (sm > 64 * 1024) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -31,16 +34,22 @@ hipError_t launch_one(const bgk::MatvecParams &p, const bgk::DevMatrix &img, hip
             g_attr_done.insert({dev, fn});
         }
     }
-    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K>), dim3((p.W.M + 63) / 64, (p.N + 15) / 16), dim3(bgk::mfma_threads(K)), sm, st, p, img);
+    hipLaunchKernelGGL((bgk::matmul_mfma_kernel<WT, EPI, K, J>), dim3((p.W.M + 64 * J - 1) / (64 * J), (p.N + 15) / 16), dim3(bgk::mfma_threads(K)), sm, st, p, img);
     return hipGetLastError();
 }
 
 template <int WT>
 hipError_t launch_t(int op, const bgk::MatvecParams &p, const bgk::DevMatrix &img, hipStream_t st) {
     switch (op) {      // the chain's sites (engine.hip ChainOp)
+        // fc1, the tallest site (Q4_0 / Q5_0 / Q8_0): a wave walks two row tiles when the rows allow it (32 | M) and the launch still has >= 2 workgroups per compute unit
+        // (kernels_mfma.hip.h, J); BIOGPT_HIP_MFMA_WALK=0 (read once per process): the one-tile kernel (A/B)
         case 0: return launch_one<WT, bgk::EPI_QKV, 1024>(p, img, st);
         case 1: return launch_one<WT, bgk::EPI_RESID, 1024>(p, img, st);
-        case 2: return launch_one<WT, bgk::EPI_GELU_Q8, 1024>(p, img, st);
+        case 2:
+            if constexpr (!bgk::TypeInfo<WT>::q81) {
+                if (walk_ok() && p.W.M % 32 == 0 && (int64_t)(p.W.M / 128) * ((p.N + 15) / 16) >= 512) return launch_one<WT, bgk::EPI_GELU_Q8, 1024, 2>(p, img, st);
+            }
+            return launch_one<WT, bgk::EPI_GELU_Q8, 1024>(p, img, st);
         case 3: return launch_one<WT, bgk::EPI_RESID, 4096>(p, img, st);
         case 4: return launch_one<WT, bgk::EPI_LOGITS, 1024>(p, img, st);
         default: return hipErrorInvalidValue;

@@ -113,3 +113,33 @@ def test_algorithmic_bytes_match_survey(pkg):
     assert int(w) == 195569792                      # W(Q4_0)
     assert pkg.decode_bytes_per_token(hp, 1024) - pkg.decode_bytes_per_token(hp, 0) == 196608 * 1024
     assert 209 < pkg.arena_bytes_for(hp) / 2 ** 20 < 213   # tensor bytes 210.35 MiB + padding + tables
+
+
+def test_pass_kernels_use_no_scratch(pkg, tmp_path):
+    """The many-column kernels sit at their register bound (128 / 168 VGPRs) on purpose; a single spilled register gives a launch a
+    scratch allocation and costs it its dispatch rate (measured: 60 us instead of 20).  Checked where it can be checked without a GPU:
+    the kernel descriptors of the built objects (private_segment_fixed_size of every matmul_mfma_kernel / attn_tile_kernel / lnq_kernel)."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/clang-offload-bundler") and shutil.which("objcopy")):
+        pytest.skip("no clang-offload-bundler / objcopy in this image")
+    pkg.build()
+    seen = 0
+    for obj, pat in (("mfma_tu.o", r"matmul_mfma_kernel"), ("engine.o", r"attn_tile_kernel|lnq_kernel")):
+        path = os.path.join(ROOT, "biogpt.cpp_amd", "csrc", "obj", obj)
+        assert os.path.exists(path), path
+        fat, co = str(tmp_path / (obj + ".fatbin")), str(tmp_path / (obj + ".co"))
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, fat])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name and re.search(pat, name):
+                assert int(m.group(1)) == 0, "%s uses %s bytes of scratch per lane" % (name, m.group(1))
+                seen += 1
+    assert seen >= 28

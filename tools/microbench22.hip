@@ -9,7 +9,7 @@
 using namespace bgk;
 typedef unsigned long long u64;
 
-template <int EPI, int K>
+template <int EPI, int K, int J = 1>
 void run(const char *name, int M, int N, size_t sm_override = 0) {
     const int BPR = K / 32;
     const size_t nblk = (size_t)M * BPR;
@@ -19,7 +19,7 @@ void run(const char *name, int M, int N, size_t sm_override = 0) {
     hipMalloc((void **)&kc, (size_t)16 * 1024 * 64 * 4); hipMalloc((void **)&vc, (size_t)16 * 1024 * 64 * 4); hipMalloc((void **)&qo, (size_t)N * 1024 * 4);
     hipMalloc((void **)&oq, (size_t)N * M); hipMalloc((void **)&od, (size_t)N * (M / 32) * 4); hipMalloc((void **)&os, (size_t)N * (M / 32) * 4);
     hipMalloc((void **)&gelu, 65536 * 2); hipMalloc((void **)&st, 4096 * 8 + 64);
-    const dim3 grid((M + 63) / 64, (N + 15) / 16);
+    const dim3 grid((M + 64 * J - 1) / (64 * J), (N + 15) / 16);
     const size_t nst = (size_t)grid.x * grid.y * 5 * 8;
     hipMalloc((void **)&ts, nst * 8);
     std::vector<uint8_t> h(nblk * 32); for (size_t i = 0; i < h.size(); i++) h[i] = (uint8_t)((i * 2654435761u >> 13) % 15 - 7);
@@ -35,22 +35,22 @@ void run(const char *name, int M, int N, size_t sm_override = 0) {
     p.q_out = qo; p.kcache = kc; p.vcache = vc; p.dk = 64; p.dk_log2 = 6; p.P = 1024; p.D = 1024; p.q_scale = 0.125f; p.st = st; p.gelu_tab = gelu;
     p.oq_q = oq; p.oq_d = od; p.oq_s = os; p.tstamp = ts;
     DevMatrix img{}; img.qs = iq; img.sc = is; img.M = M; img.K = K;
-    const size_t sm = sm_override ? sm_override : matmul_mfma_smem_bytes(K, false, EPI == EPI_GELU_Q8);
-    if (sm > 65536) hipFuncSetAttribute(reinterpret_cast<const void *>(matmul_mfma_kernel<W_Q4_0, EPI, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    const size_t sm = sm_override ? sm_override : matmul_mfma_smem_bytes(K, false, EPI == EPI_GELU_Q8, J);
+    if (sm > 65536) hipFuncSetAttribute(reinterpret_cast<const void *>(matmul_mfma_kernel<W_Q4_0, EPI, K, J>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((matmul_mfma_kernel<W_Q4_0, EPI, K>), grid, dim3(mfma_threads(K)), sm, 0, p, img);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((matmul_mfma_kernel<W_Q4_0, EPI, K, J>), grid, dim3(mfma_threads(K)), sm, 0, p, img);
     hipDeviceSynchronize();
     const int reps = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((matmul_mfma_kernel<W_Q4_0, EPI, K>), grid, dim3(mfma_threads(K)), sm, 0, p, img);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((matmul_mfma_kernel<W_Q4_0, EPI, K, J>), grid, dim3(mfma_threads(K)), sm, 0, p, img);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<u64> t(nst); hipMemcpy(t.data(), ts, nst * 8, hipMemcpyDeviceToHost);
     u64 tmin = ~0ull, tmax = 0;
-    double c01 = 0, c12 = 0, s01 = 0, s12 = 0, s03 = 0; size_t nw = 0, nwg = grid.x * grid.y;
+    double c01 = 0, c12 = 0, c23 = 0, s01 = 0, s12 = 0, s03 = 0; std::vector<double> fin; size_t nw = 0, nwg = grid.x * grid.y;
     std::vector<double> start, wend;
     for (size_t w = 0; w < nwg; w++) {
-        for (int v = 0; v < 4; v++) { const u64 *q = &t[(w * 5 + v) * 8]; wend.push_back((double)q[5]); c01 += (double)(q[1] - q[0]); c12 += (double)(q[2] - q[1]); s01 += (double)(q[1] - q[0]); nw++; }
+        for (int v = 0; v < 4; v++) { const u64 *q = &t[(w * 5 + v) * 8]; wend.push_back((double)q[5]); c01 += (double)(q[1] - q[0]); c12 += (double)(q[2] - q[1]); c23 += (double)(q[3] - q[2]); fin.push_back((double)q[7]); s01 += (double)(q[1] - q[0]); nw++; }
         if (K > 1024) { const u64 *q = &t[(w * 5 + 4) * 8]; s12 += (double)(q[2] - q[1]); s03 += (double)(q[3] - q[0]); }
         start.push_back((double)t[(w * 5) * 8 + 4]);
     }
@@ -72,14 +72,18 @@ void run(const char *name, int M, int N, size_t sm_override = 0) {
         }
         avgconc /= std::max(1, ncu);
     }
-    std::sort(start.begin(), start.end()); std::sort(wend.begin(), wend.end());
-    printf("%-10s M %5d K %5d N %4d  %4zu workgroups  %7.2f us per launch | computing waves: entry -> phase-0 DMAs issued %7.0f cyc, from there to the loop's end %7.0f cyc | (the same, all waves) +%6.0f; staging wave: landed +%6.0f, exit %7.0f | wall (10 ns ticks): entries median +%.0f last +%.0f, loop ends first +%.0f median +%.0f last +%.0f | %d compute units seen, workgroups at a time on one: max %d, mean of the per-unit maxima %.2f\n",
-           name, M, K, N, nwg, ms * 1000.0 / reps, c01 / nw, c12 / nw, s01 / nw, s12 / nwg, s03 / nwg, start[nwg / 2] - start[0], start[nwg - 1] - start[0], wend[0] - start[0], wend[wend.size() / 2] - start[0], wend.back() - start[0], ncu, maxconc, avgconc);
+    std::sort(start.begin(), start.end()); std::sort(wend.begin(), wend.end()); std::sort(fin.begin(), fin.end());
+    printf("%-10s M %5d K %5d N %4d  %4zu workgroups  %7.2f us per launch | computing waves: entry -> phase-0 DMAs issued %7.0f cyc, from there to the loop's end %7.0f cyc, epilogue %6.0f cyc (ends, wall: median +%.0f last +%.0f) | (the same, all waves) +%6.0f; staging wave: landed +%6.0f, exit %7.0f | wall (10 ns ticks): entries median +%.0f last +%.0f, loop ends first +%.0f median +%.0f last +%.0f | %d compute units seen, workgroups at a time on one: max %d, mean of the per-unit maxima %.2f\n",
+           name, M, K, N, nwg, ms * 1000.0 / reps, c01 / nw, c12 / nw, c23 / nw, fin[fin.size() / 2] - start[0], fin.back() - start[0], s01 / nw, s12 / nwg, s03 / nwg, start[nwg / 2] - start[0], start[nwg - 1] - start[0], wend[0] - start[0], wend[wend.size() / 2] - start[0], wend.back() - start[0], ncu, maxconc, avgconc);
     hipFree(iq); hipFree(is); hipFree(aq); hipFree(ad); hipFree(as); hipFree(bias); hipFree(resid); hipFree(out); hipFree(kc); hipFree(vc); hipFree(qo); hipFree(oq); hipFree(od); hipFree(os); hipFree(gelu); hipFree(st); hipFree(ts);
 }
 int main() {
+    if (getenv("MB_ONLY")) {      // one shape only (the ablation builds: tools/r6_ablate.sh)
+        run<EPI_GELU_Q8, 1024>("fc1", 4096, 512); run<EPI_GELU_Q8, 1024>("fc1", 4096, 64); run<EPI_RESID, 4096>("fc2", 1024, 512);
+        return 0;
+    }
     if (getenv("MB_GAPS")) {      // per compute unit: workgroup entries (+) and loop ends (-) in 10 ns ticks (the first six units)
-        if (atoi(getenv("MB_GAPS")) == 2) run<EPI_GELU_Q8, 1024>("fc1", 4096, 512); else run<EPI_RESID, 1024>("out_proj", 1024, 512);
+        if (atoi(getenv("MB_GAPS")) == 2) run<EPI_GELU_Q8, 1024>("fc1", 4096, 512); else if (atoi(getenv("MB_GAPS")) == 3) run<EPI_GELU_Q8, 1024, 2>("fc1 walk 2", 4096, 512); else run<EPI_RESID, 1024>("out_proj", 1024, 512);
         return 0;
     }
     for (int N : {512, 64}) {
@@ -87,6 +91,7 @@ int main() {
         run<EPI_RESID, 4096>("fc2", 1024, N);
         run<EPI_QKV, 1024>("q/k/v", 3072, N);
         run<EPI_GELU_Q8, 1024>("fc1", 4096, N);
+        run<EPI_GELU_Q8, 1024, 2>("fc1 walk 2", 4096, N);
         run<EPI_LOGITS, 1024>("lm_head", 42384, N);
     }
     return 0;
