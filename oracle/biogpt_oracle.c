@@ -568,6 +568,143 @@ static float vec_dot_simd(int wtype, int64_t k, const void *w, const void *yv) {
     }
     return hsum8(acc) + summs;
 }
+/* ---- the same shapes written with the intrinsics themselves (x86-64 with AVX2 + FMA; chosen at run time, bo_opts.assoc bit 2): what an AVX2 build of ggml [ggml-recall]
+ * executes per block -- bytes_from_nibbles_32, mul_sum_i8_pairs_float (vpsignb / vpmaddubsw / vpmaddwd), _mm256_fmadd_ps, hsum_float_8 -- so that the CPU baseline timed
+ * beside the GPU is SIMD code and not its scalar emulation.  Results equal vec_dot_simd / quantize_row_q8_*_simd bit for bit (tests/test_oracle_assoc.py). ---- */
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#define BO_HAVE_AVX2 1
+#define BO_AVX2 __attribute__((target("avx2,fma")))
+static int bo_cpu_avx2(void) {
+    static int have = -1;
+    if (have < 0) { __builtin_cpu_init(); have = (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? 1 : 0; }
+    return have;
+}
+BO_AVX2 static inline float hsum8_avx2(__m256 x) {
+    __m128 res = _mm_add_ps(_mm256_castps256_ps128(x), _mm256_extractf128_ps(x, 1));     /* (a0+a4, a1+a5, a2+a6, a3+a7) */
+    res        = _mm_add_ps(res, _mm_movehl_ps(res, res));                                /* (r0+r2, r1+r3) */
+    res        = _mm_add_ss(res, _mm_movehdup_ps(res));
+    return _mm_cvtss_f32(res);
+}
+BO_AVX2 static inline __m256 mul_sum_i8_pairs_float(__m256i x, __m256i y) {              /* 8 lanes: float of the int32 sum of 4 consecutive byte products */
+    const __m256i ax  = _mm256_sign_epi8(x, x);
+    const __m256i sy  = _mm256_sign_epi8(y, x);
+    const __m256i dot = _mm256_maddubs_epi16(ax, sy);
+    return _mm256_cvtepi32_ps(_mm256_madd_epi16(dot, _mm256_set1_epi16(1)));
+}
+BO_AVX2 static inline __m256i bytes_from_nibbles_32(const uint8_t *rsi) {                /* elements 0..15 = low nibbles, 16..31 = high nibbles */
+    const __m128i tmp   = _mm_loadu_si128((const __m128i *)rsi);
+    const __m256i bytes = _mm256_set_m128i(_mm_srli_epi16(tmp, 4), tmp);
+    return _mm256_and_si256(_mm256_set1_epi8(0x0F), bytes);
+}
+BO_AVX2 static float vec_dot_avx2(int wtype, int64_t k, const void *w, const void *yv) {
+    __m256 acc   = _mm256_setzero_ps();
+    float summs  = 0.0f;
+    for (int64_t i = 0; i < k / QK; i++) {
+        __m256i bx, by;
+        float d;
+        switch (wtype) {
+            case BO_TYPE_Q4_0: {
+                const blk_q4_0 *x = (const blk_q4_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                bx = _mm256_sub_epi8(bytes_from_nibbles_32(x[i].qs), _mm256_set1_epi8(8));
+                by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                d  = F16(x[i].d) * F16(y[i].d);
+            } break;
+            case BO_TYPE_Q8_0: {
+                const blk_q8_0 *x = (const blk_q8_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                bx = _mm256_loadu_si256((const __m256i *)x[i].qs);
+                by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                d  = F16(x[i].d) * F16(y[i].d);
+            } break;
+            case BO_TYPE_Q4_1: {
+                const blk_q4_1 *x = (const blk_q4_1 *)w; const blk_q8_1 *y = (const blk_q8_1 *)yv;
+                bx = bytes_from_nibbles_32(x[i].qs);
+                by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                d  = F16(x[i].d) * y[i].d;
+                summs += F16(x[i].m) * y[i].s;
+            } break;
+            case BO_TYPE_Q5_0: case BO_TYPE_Q5_1: {       /* the fifth bits: unpacked in scalar code (ggml: bytes_from_bits_32), the dot is the vector one */
+                int8_t wb[32];
+                uint32_t qh;
+                if (wtype == BO_TYPE_Q5_0) {
+                    const blk_q5_0 *x = (const blk_q5_0 *)w; const blk_q8_0 *y = (const blk_q8_0 *)yv;
+                    memcpy(&qh, x[i].qh, 4);
+                    for (int j = 0; j < 16; j++) {
+                        wb[j]      = (int8_t)(((x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4)) - 16);
+                        wb[j + 16] = (int8_t)(((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4)) - 16);
+                    }
+                    by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                    d  = F16(x[i].d) * F16(y[i].d);
+                } else {
+                    const blk_q5_1 *x = (const blk_q5_1 *)w; const blk_q8_1 *y = (const blk_q8_1 *)yv;
+                    memcpy(&qh, x[i].qh, 4);
+                    for (int j = 0; j < 16; j++) {
+                        wb[j]      = (int8_t)((x[i].qs[j] & 0x0F) | (((qh >> j) & 1u) << 4));
+                        wb[j + 16] = (int8_t)((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1u) << 4));
+                    }
+                    by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+                    d  = F16(x[i].d) * y[i].d;
+                    summs += F16(x[i].m) * y[i].s;
+                }
+                bx = _mm256_loadu_si256((const __m256i *)wb);
+            } break;
+            default: return NAN;
+        }
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(d), mul_sum_i8_pairs_float(bx, by), acc);
+    }
+    return hsum8_avx2(acc) + summs;
+}
+BO_AVX2 static float vec_dot_f32_avx2(int64_t n, const float *x, const float *y) {
+    __m256 s0 = _mm256_setzero_ps(), s1 = s0, s2 = s0, s3 = s0;
+    const int64_t np = n & ~(int64_t)31;
+    for (int64_t i = 0; i < np; i += 32) {
+        s0 = _mm256_fmadd_ps(_mm256_loadu_ps(x + i), _mm256_loadu_ps(y + i), s0);
+        s1 = _mm256_fmadd_ps(_mm256_loadu_ps(x + i + 8), _mm256_loadu_ps(y + i + 8), s1);
+        s2 = _mm256_fmadd_ps(_mm256_loadu_ps(x + i + 16), _mm256_loadu_ps(y + i + 16), s2);
+        s3 = _mm256_fmadd_ps(_mm256_loadu_ps(x + i + 24), _mm256_loadu_ps(y + i + 24), s3);
+    }
+    s0 = _mm256_add_ps(s0, s2); s1 = _mm256_add_ps(s1, s3); s0 = _mm256_add_ps(s0, s1);
+    const __m128 t0 = _mm_add_ps(_mm256_castps256_ps128(s0), _mm256_extractf128_ps(s0, 1));
+    const __m128 t1 = _mm_hadd_ps(t0, t0);
+    float sumf      = _mm_cvtss_f32(_mm_hadd_ps(t1, t1));
+    for (int64_t i = np; i < n; i++) sumf += x[i] * y[i];
+    return sumf;
+}
+/* one block of quantize_row_q8_0 / q8_1 as AVX2 ggml does it: max |x| over 4 vectors, id = 127 / amax, nearest-even rounding, pack to int8; returns the block's integer sum */
+BO_AVX2 static inline int quantize_block_q8_avx2(const float *x, int8_t *qs, float *d_out) {
+    const __m256 sign = _mm256_set1_ps(-0.0f);
+    __m256 v0 = _mm256_loadu_ps(x), v1 = _mm256_loadu_ps(x + 8), v2 = _mm256_loadu_ps(x + 16), v3 = _mm256_loadu_ps(x + 24);
+    __m256 mx = _mm256_max_ps(_mm256_max_ps(_mm256_andnot_ps(sign, v0), _mm256_andnot_ps(sign, v1)), _mm256_max_ps(_mm256_andnot_ps(sign, v2), _mm256_andnot_ps(sign, v3)));
+    __m128 m4 = _mm_max_ps(_mm256_extractf128_ps(mx, 1), _mm256_castps256_ps128(mx));
+    m4        = _mm_max_ps(m4, _mm_movehl_ps(m4, m4));
+    m4        = _mm_max_ss(m4, _mm_movehdup_ps(m4));
+    const float amax = _mm_cvtss_f32(m4);
+    *d_out           = amax / 127.f;
+    const float id   = (amax != 0.0f) ? 127.f / amax : 0.0f;
+    const __m256 mul = _mm256_set1_ps(id);
+    __m256i i0 = _mm256_cvtps_epi32(_mm256_round_ps(_mm256_mul_ps(v0, mul), _MM_ROUND_NEAREST)), i1 = _mm256_cvtps_epi32(_mm256_round_ps(_mm256_mul_ps(v1, mul), _MM_ROUND_NEAREST));
+    __m256i i2 = _mm256_cvtps_epi32(_mm256_round_ps(_mm256_mul_ps(v2, mul), _MM_ROUND_NEAREST)), i3 = _mm256_cvtps_epi32(_mm256_round_ps(_mm256_mul_ps(v3, mul), _MM_ROUND_NEAREST));
+    const __m256i s8 = _mm256_add_epi32(_mm256_add_epi32(i0, i1), _mm256_add_epi32(i2, i3));
+    i0 = _mm256_packs_epi32(i0, i1); i2 = _mm256_packs_epi32(i2, i3); i0 = _mm256_packs_epi16(i0, i2);
+    i0 = _mm256_permutevar8x32_epi32(i0, _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7));       /* the packs interleave the 128-bit halves: put the bytes back in element order */
+    _mm256_storeu_si256((__m256i *)qs, i0);
+    __m128i h = _mm_add_epi32(_mm256_castsi256_si128(s8), _mm256_extracti128_si256(s8, 1));
+    h         = _mm_add_epi32(h, _mm_shuffle_epi32(h, 0x4E));
+    h         = _mm_add_epi32(h, _mm_shuffle_epi32(h, 0xB1));
+    return _mm_cvtsi128_si32(h);
+}
+BO_AVX2 static void quantize_row_q8_0_avx2(const float *x, blk_q8_0 *y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; i++) { float d; (void)quantize_block_q8_avx2(x + i * QK, y[i].qs, &d); y[i].d = bo_fp32_to_fp16(d); }
+}
+BO_AVX2 static void quantize_row_q8_1_avx2(const float *x, blk_q8_1 *y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; i++) { float d; const int sum = quantize_block_q8_avx2(x + i * QK, y[i].qs, &d); y[i].d = d; y[i].s = d * (float)sum; }
+}
+#else
+#define BO_HAVE_AVX2 0
+static int bo_cpu_avx2(void) { return 0; }
+#endif
+int bo_have_avx2(void) { return bo_cpu_avx2(); }
+
 /* ggml_vec_dot_f32 with GGML_SIMD (AVX2: step 32 = 4 accumulators x 8 lanes, fma; reduce 0+=2, 1+=3, 0+=1, then
  * low128 + high128 and two hadds; scalar leftovers in float) */
 static float vec_dot_f32_simd(int64_t n, const float *x, const float *y) {
@@ -584,6 +721,29 @@ static float vec_dot_f32_simd(int64_t n, const float *x, const float *y) {
     float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
     for (int64_t i = np; i < n; i++) sumf += x[i] * y[i];
     return sumf;
+}
+
+/* bit 2 of bo_opts.assoc: the intrinsics where the CPU has them (same values as the emulations above, several times faster) */
+static float vec_dot_simd_x(int intr, int wtype, int64_t k, const void *w, const void *yv) {
+#if BO_HAVE_AVX2
+    if (intr && bo_cpu_avx2()) return vec_dot_avx2(wtype, k, w, yv);
+#endif
+    (void)intr;
+    return vec_dot_simd(wtype, k, w, yv);
+}
+static float vec_dot_f32_simd_x(int intr, int64_t n, const float *x, const float *y) {
+#if BO_HAVE_AVX2
+    if (intr && bo_cpu_avx2()) return vec_dot_f32_avx2(n, x, y);
+#endif
+    (void)intr;
+    return vec_dot_f32_simd(n, x, y);
+}
+static void quantize_row_q8_simd_x(int intr, int q81, const float *x, void *y, int64_t k) {
+#if BO_HAVE_AVX2
+    if (intr && bo_cpu_avx2()) { if (q81) quantize_row_q8_1_avx2(x, (blk_q8_1 *)y, k); else quantize_row_q8_0_avx2(x, (blk_q8_0 *)y, k); return; }
+#endif
+    (void)intr;
+    if (q81) quantize_row_q8_1_simd(x, (blk_q8_1 *)y, k); else quantize_row_q8_0_simd(x, (blk_q8_0 *)y, k);
 }
 
 /* activation ("src1") row conversion to the weight type's vec_dot_type [SURVEY A.3] */
@@ -823,8 +983,8 @@ static void mul_mat(const bo_model *mdl, const bo_tensor *W, const float *x, int
     if (vt != BO_TYPE_F32) {
         y = (uint8_t *)malloc(yb * (size_t)N + 64);
         for (int n = 0; n < N; n++) {
-            if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_0) quantize_row_q8_0_simd(x + (size_t)n * K, (blk_q8_0 *)(y + (size_t)n * yb), K);
-            else if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_1) quantize_row_q8_1_simd(x + (size_t)n * K, (blk_q8_1 *)(y + (size_t)n * yb), K);
+            if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_0) quantize_row_q8_simd_x(mdl->opts.assoc & 4, 0, x + (size_t)n * K, y + (size_t)n * yb, K);
+            else if ((mdl->opts.assoc & 2) && vt == BO_TYPE_Q8_1) quantize_row_q8_simd_x(mdl->opts.assoc & 4, 1, x + (size_t)n * K, y + (size_t)n * yb, K);
             else bo_quantize(vt, x + (size_t)n * K, y + (size_t)n * yb, K, K);
         }
     }
@@ -837,8 +997,8 @@ static void mul_mat(const bo_model *mdl, const bo_tensor *W, const float *x, int
         const uint8_t *wrow = (const uint8_t *)W->data + (size_t)mm * wb;
         for (int n = 0; n < N; n++) {
             const void *yy            = (vt == BO_TYPE_F32) ? (const void *)(x + (size_t)n * K) : (const void *)(y + (size_t)n * yb);
-            out[(size_t)n * M + mm]   = simd ? vec_dot_simd(W->type, K, wrow, yy)
-                                             : ((mdl->opts.assoc & 1) && W->type == BO_TYPE_F32) ? vec_dot_f32_simd(K, (const float *)wrow, (const float *)yy)
+            out[(size_t)n * M + mm]   = simd ? vec_dot_simd_x(mdl->opts.assoc & 4, W->type, K, wrow, yy)
+                                             : ((mdl->opts.assoc & 1) && W->type == BO_TYPE_F32) ? vec_dot_f32_simd_x(mdl->opts.assoc & 4, K, (const float *)wrow, (const float *)yy)
                                                                                                : vec_dot_typed(W->type, K, wrow, yy);
         }
     }
@@ -943,7 +1103,7 @@ int bo_eval(bo_model *m, const int32_t *tokens, int N, int n_past, float *logits
             int Tlim = T;
             if (m->opts.causal) Tlim = n_past + i + 1;
             for (int j = 0; j < Tlim; j++) /* KQ = mul_mat(K, Q) */
-                S[j] = (m->opts.assoc & 1) ? vec_dot_f32_simd(dk, Kl + (size_t)j * D + (size_t)h * dk, qv) : vec_dot_f32(dk, Kl + (size_t)j * D + (size_t)h * dk, qv);
+                S[j] = (m->opts.assoc & 1) ? vec_dot_f32_simd_x(m->opts.assoc & 4, dk, Kl + (size_t)j * D + (size_t)h * dk, qv) : vec_dot_f32(dk, Kl + (size_t)j * D + (size_t)h * dk, qv);
             /* ggml_soft_max */
             float mx = -INFINITY;
             for (int j = 0; j < Tlim; j++)
@@ -967,7 +1127,7 @@ int bo_eval(bo_model *m, const int32_t *tokens, int N, int n_past, float *logits
                 float *vt_row = (float *)malloc(sizeof(float) * (size_t)Tlim);
                 for (int d = 0; d < dk; d++) {
                     for (int j = 0; j < Tlim; j++) vt_row[j] = Vl[(size_t)j * D + (size_t)h * dk + d];
-                    att[(size_t)i * D + (size_t)h * dk + d] = vec_dot_f32_simd(Tlim, vt_row, S);
+                    att[(size_t)i * D + (size_t)h * dk + d] = vec_dot_f32_simd_x(m->opts.assoc & 4, Tlim, vt_row, S);
                 }
                 free(vt_row);
             } else

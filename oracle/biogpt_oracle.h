@@ -53,6 +53,8 @@ typedef struct bo_opts {
                        *          a horizontal add at the end; F32 dots (QK^T, PV) as 4 x 8-lane fma accumulators
                        *   bit 1  activations quantized as the AVX2 kernels do: id = 127/amax, round to nearest-even
                        *   3      both = what an AVX2 build of the reference computes
+                       *   bit 2  (with bits 0 / 1) the same dots / conversions executed with AVX2 + FMA intrinsics where the CPU has them
+                       *          (bo_have_avx2()): identical values, the speed of SIMD code -- 7 is the CPU baseline bench.py times
                        * All are legal outcomes of "the reference's CPU path" (ggml is not bit-reproducible across ISAs);
                        * tests/test_oracle_assoc.py measures the envelope between them. */
 } bo_opts;
@@ -73,6 +75,7 @@ size_t bo_quantize(int type, const float *src, void *dst, int64_t n, int64_t k);
 void   bo_dequantize_row(int type, const void *src, float *dst, int64_t k);
 /* dot(W row, x) the way ggml's CPU mul_mat does it: x is converted to the type's vec_dot_type first */
 float  bo_vec_dot(int wtype, int64_t k, const void *wrow, const float *x);
+int    bo_have_avx2(void);                     /* 1: this CPU runs the AVX2 + FMA forms of the SIMD-shaped dots (bo_opts.assoc bit 2) */
 
 /* ---- model file ---- */
 bo_model *bo_load(const char *path, char *err, size_t errlen);

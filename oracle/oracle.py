@@ -61,6 +61,8 @@ def lib():
     L.bo_dequantize_row.restype = None
     L.bo_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
     L.bo_vec_dot.restype = C.c_float
+    L.bo_have_avx2.restype = C.c_int
+    L.bo_have_avx2.argtypes = []
     L.bo_vec_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     L.bo_load.restype = C.c_void_p
     L.bo_load.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
@@ -198,3 +200,8 @@ class OracleModel:
             self.close()
         except Exception:
             pass
+
+
+def have_avx2():
+    """True when the oracle's AVX2 + FMA forms of the SIMD-shaped dots run on this CPU (assoc bit 2 is then honoured)."""
+    return bool(lib().bo_have_avx2())

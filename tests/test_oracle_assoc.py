@@ -51,3 +51,41 @@ def test_envelope_between_ggml_association_modes(oracle, files, name):
         assert rows[0][1] < 5e-3
     # quantized weights: even the pure association change exceeds the 1e-3 logit contract of north_star, because a
     # 1-ulp difference can flip an int8 code of a downstream Q8 activation block -- documented, not asserted as a bar
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q8_0", "f32"])
+def test_avx2_intrinsics_equal_their_scalar_emulation(oracle, files, name):
+    """bench.py's SIMD cpu_baseline runs the AVX2 shape with real intrinsics (bo_opts.assoc = 7); the scalar emulation of the same
+    shape (assoc = 3) is what this file measures the envelope with.  Same arithmetic, so the logits must be equal bit for bit."""
+    if not oracle.have_avx2():
+        pytest.skip("this CPU has no AVX2 + FMA")
+    a = oracle.OracleModel(files[name], n_threads=8, assoc=3)
+    b = oracle.OracleModel(files[name], n_threads=8, assoc=7)
+    rng = np.random.default_rng(5)
+    prompt = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 10)]
+    la, lb = a.eval(prompt[:8], 0), b.eval(prompt[:8], 0)
+    assert (la == lb).all()
+    la, lb = a.eval(prompt[8:], 8), b.eval(prompt[8:], 8)
+    assert (la == lb).all()
+    n_past = len(prompt)
+    for _ in range(6):
+        t = int(la.argmax())
+        la, lb = a.eval([t], n_past), b.eval([t], n_past)
+        assert (la == lb).all()
+        n_past += 1
+    for which in (0, 1):
+        assert (a.kv(which) == b.kv(which)).all()
+
+
+@pytest.mark.parametrize("name", ["q4_1", "q5_0", "q5_1"])
+def test_avx2_intrinsics_equal_their_scalar_emulation_other_formats(oracle, pkg, files, tmp_path, name):
+    if not oracle.have_avx2():
+        pytest.skip("this CPU has no AVX2 + FMA")
+    path = str(tmp_path / (name + ".bin"))
+    pkg.quantize_file(files["f32"], path, name)
+    a = oracle.OracleModel(path, n_threads=8, assoc=3)
+    b = oracle.OracleModel(path, n_threads=8, assoc=7)
+    la, lb = a.eval([2, 77, 4000, 911, 12, 30000], 0), b.eval([2, 77, 4000, 911, 12, 30000], 0)
+    assert (la == lb).all()
+    la, lb = a.eval([int(la.argmax())], 6), b.eval([int(lb.argmax())], 6)
+    assert (la == lb).all()
