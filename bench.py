@@ -391,6 +391,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        # the timed steps' own launches: tokens of each multi-token pipelined launch of a continuation (the first token comes out of the prompt's eval) and the step's time per
+        # token; the kernel trace of exactly these launches: profiles/rocprofv3_kernel_stats_r6_headline.csv (dominant-kernel time x launches <= ms_per_step from the evidence)
+        **({"launch_tokens": model.generate_launches(), "us_per_token_in_launch": round(elapsed / args.steps / max(1, n_predict) * 1e6, 2)} if not prefill else {}),
         "dtype": "int8" if args.ftype.startswith("q") else args.ftype,  # W4/5/8 x A8 integer block dots, f32 scale/accumulate
         "data": "synthetic",
         "config": {
@@ -484,12 +487,19 @@ def main():
                 # quantized matrix of the arena (24 x {q/k/v, out_proj, fc1, fc2} + lm_head) x a resident Q8 activation of its shape in ONE launch, rows spread over the
                 # chip, two copies of the weights in turn so that the Infinity Cache cannot serve them (csrc/kernels_sweep.hip.h; SURVEY 7 "hard parts")
                 try:
-                    sw_s, sw_b, sw_chk = model.bench_sweep(reps=40)
+                    sw_s, sw_b, sw_chk = model.bench_sweep(reps=120)
                     out["matvec_sweep"] = {"what": "matvec_sweep_kernel<%s>: all %d block-quantized matrices of the model (the W of SURVEY 8(d)) as independent mat-vecs in one launch; int8 block "
                                                    "dots, block terms added in block order (the reference's arithmetic); launches alternate between two copies of the weights (2 x %.0f MB > the "
                                                    "256 MB Infinity Cache)" % (args.ftype.upper(), 4 * hp.n_layer + 1, sw_b / 1e6),
                                            "bytes": sw_b, "us": round(sw_s * 1e6, 2), "GBps": round(sw_b / sw_s / 1e9, 1), "frac": round(sw_b / sw_s / 1e9 / HBM_PEAK_GBS, 4),
-                                           "max_abs_diff_vs_host_recompute": sw_chk, "method": "HIP events around 40 back-to-back launches (launch gaps included)"}
+                                           "max_abs_diff_vs_host_recompute": sw_chk, "method": "HIP events around 120 back-to-back launches (launch gaps included)"}
+                    # the same kernel on each shape alone, as many copies of its weights in turn as exceed the Infinity Cache (SURVEY 8(d) words the bar per shape):
+                    # "k1024_dxd" = q/k/v + out_proj of every layer = the Q4_0 mat-vec at d_model = 1024 to the letter (biogpt.cpp:705-716,767)
+                    shapes = {}
+                    for key, which in (("k1024_dxd", 2), ("k4096_fc2", 3), ("k1024_fc1", 4), ("lm_head", 1)):
+                        s_s, s_b, s_chk = model.bench_sweep(reps=120, which=which)
+                        shapes[key] = {"bytes": s_b, "us": round(s_s * 1e6, 2), "GBps": round(s_b / s_s / 1e9, 1), "frac": round(s_b / s_s / 1e9 / HBM_PEAK_GBS, 4), "max_abs_diff_vs_host_recompute": s_chk}
+                    out["matvec_sweep"]["by_shape"] = shapes
                 except Exception as e:
                     out["matvec_sweep"] = {"error": str(e)[:200]}
             if args.ftype == "q4_0":

@@ -84,8 +84,11 @@ SYMBOLS = [
     ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
     ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_chunk_launches", C.c_int64, [_P]),
+    ("biogpt_hip_generate_launches", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int]),
     ("biogpt_hip_lineage_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_bench_sweep", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("biogpt_hip_bench_sweep_ex", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_size_t,
+                                            C.POINTER(C.c_int8), C.POINTER(C.c_float)]),
     ("biogpt_hip_eval_device", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("biogpt_hip_eval_topk", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("biogpt_hip_logits_device", _P, [_P]),
@@ -430,6 +433,12 @@ class BiogptModel:
             raise BiogptError(_err())
         return out[:got], secs.value
 
+    def generate_launches(self):
+        """Tokens of each multi-token pipelined launch of the last generate_greedy call (biogpt_hip_generate_launches)."""
+        buf = (C.c_int32 * 16)()
+        n = int(lib().biogpt_hip_generate_launches(self._h, buf, 16))
+        return [int(buf[i]) for i in range(max(0, min(n, 16)))]
+
     def chunk_launches(self):
         """Evals of 2 .. 8 tokens that went through the column-per-XCD launch (biogpt_hip_chunk_launches)."""
         return int(lib().biogpt_hip_chunk_launches(self._h))
@@ -450,6 +459,19 @@ class BiogptModel:
         if lib().biogpt_hip_bench_sweep(self._h, int(which), int(reps), C.byref(secs), C.byref(nbytes), C.byref(chk)) != 0:
             raise BiogptError(_err())
         return secs.value, nbytes.value, chk.value
+
+    def bench_sweep_rows(self, which=0, reps=4):
+        """The sweep launch's output rows and the two Q8 activation vectors they were computed with (biogpt_hip_bench_sweep_ex): (rows float32 [sum of the selected
+        matrices' rows], xq int8 [1024 + 4096], xd float32 [32 + 128])."""
+        hp = self.hparams
+        per_layer = {0: 3 * hp.d_model + hp.d_model + hp.d_ff + hp.d_model, 2: 4 * hp.d_model, 3: hp.d_model, 4: hp.d_ff, 1: 0}[int(which)]
+        n = per_layer * hp.n_layer + (hp.n_vocab if which in (0, 1) else 0)
+        rows = np.zeros(n, np.float32); xq = np.zeros(1024 + 4096, np.int8); xd = np.zeros(32 + 128, np.float32)
+        secs, nbytes, chk = C.c_double(0.0), C.c_double(0.0), C.c_double(-1.0)
+        if lib().biogpt_hip_bench_sweep_ex(self._h, int(which), int(reps), C.byref(secs), C.byref(nbytes), C.byref(chk), rows.ctypes.data_as(C.POINTER(C.c_float)), n,
+                                           xq.ctypes.data_as(C.POINTER(C.c_int8)), xd.ctypes.data_as(C.POINTER(C.c_float))) != 0:
+            raise BiogptError(_err())
+        return rows, xq, xd
 
     def bench_decode(self, n_past, reps=50):
         secs = C.c_double(0.0)

@@ -297,6 +297,7 @@ struct biogpt_hip_ctx {
     int xc_lds = 0;                        // 0 not tried, 1 the kernels' LDS attribute is set, -1 it could not be set (such evals keep the launch chain)
     int state_n_past = 0, state_chunk = 0; // what the last upload_state put into the device state
     int64_t xc_launches = 0;               // evals that went through the chunk launch (biogpt_hip_chunk_launches)
+    int32_t gen_launch_tokens[16] = {0}; int gen_launches = 0;   // the last biogpt_hip_generate_greedy: tokens of each multi-token pipelined launch (biogpt_hip_generate_launches)
     int xc_batch = 0;                      // biogpt_hip_generate_greedy_batch with 2 .. 8 sequences holds the device's pipeline slot: its decode steps run as column-per-XCD launches (streams mode)
     uint32_t *xp_ctl = nullptr;
     bgk::xp_u64 *xp_samp = nullptr;        // arg-max partials handed from token t to token t + 1 inside a multi-token launch
@@ -1990,6 +1991,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     } else if (!enqueue_argmax(ctx, last_cols)) {
         return -2;
     }
+    ctx->gen_launches = 0;
     for (int k = 1; k < n_predict; k++) {  // one eval + one sample per further token
         const int T = n_prompt + k;  // keys visible to this token: n_past + 1
         if (pending && !fused(T)) {  // leaving the fused range: record the token the unfused step will embed
@@ -1999,6 +2001,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
         const int multi = pending ? std::min(xpipe_multi_tokens(ctx, T), n_predict - k) : 0;
         if (multi > 1) {   // the generation loop itself runs on the device: `multi` tokens in ONE launch (kernels_xpipe.hip.h)
             if (!enqueue_decode_fused(ctx, bucket_tmax(ctx, graph_bucket(T)), 2, 1, 0, -1, -1, multi)) return -2;
+            if (ctx->gen_launches < 16) ctx->gen_launch_tokens[ctx->gen_launches++] = multi;
             k += multi - 1;
         } else if (use_graph) {
             HIP_TRY(-2, hipGraphLaunch(ctx->graph_step[pl_of(graph_bucket(T))][1][graph_bucket(T)], ctx->stream));
@@ -2042,6 +2045,11 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     return rc;
 }
 int64_t biogpt_hip_chunk_launches(const biogpt_hip_ctx *ctx) { return ctx ? ctx->xc_launches : -1; }
+int biogpt_hip_generate_launches(const biogpt_hip_ctx *ctx, int32_t *tokens_out, int cap) {
+    if (!ctx) return -1;
+    for (int i = 0; i < ctx->gen_launches && i < cap && tokens_out; i++) tokens_out[i] = ctx->gen_launch_tokens[i];
+    return ctx->gen_launches;
+}
 int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4) {
     if (!ctx || !out4) return -1;
     out4[0] = ctx->spec_hits; out4[1] = ctx->spec_misses; out4[2] = ctx->spec_streak; out4[3] = ctx->spec_need;

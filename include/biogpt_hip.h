@@ -163,6 +163,9 @@ int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4);
  * XCD, its own K / V cache: no exchange between XCDs) while contexts stay within 256 keys.  Returns how many such launches this context has enqueued or captured (evals;
  * batched generation: one per captured context bucket + the first step) (-1: null context). */
 int64_t biogpt_hip_chunk_launches(const biogpt_hip_ctx *ctx);
+/* the last biogpt_hip_generate_greedy call (the loop main.cpp:91-151 with --top_k 1): how many multi-token pipelined launches it took and the tokens of each (up to cap);
+ * 0 when every token was a launch / graph replay of its own.  Measurement aid: per-launch durations of a kernel trace divide by these. */
+int biogpt_hip_generate_launches(const biogpt_hip_ctx *ctx, int32_t *tokens_out, int cap);
 
 /* Same pass, logits stay in HBM (no PCIe); biogpt_hip_logits_device() returns the device pointer
  * to the n_vocab floats of the last evaluated token.  eval_device is asynchronous on the
@@ -312,7 +315,11 @@ int biogpt_hip_write_synthetic(const char *fname, const biogpt_hip_hparams *hp, 
  * 256 MB Infinity Cache cannot serve them.  seconds_out per launch, bytes_out = SURVEY 8(d)'s algorithmic bytes per launch, check_out = max |device - host| over
  * sampled rows (0 = bit-identical to the reference's arithmetic; -1 = format not checked).  The figure north_star's ">= 70 % of the HBM roofline on the Q4_0
  * single-token decode mat-vec at d_model = 1024" asks for; replaces nothing of biogpt.cpp (its loop body is biogpt.cpp:705-803). */
-int biogpt_hip_bench_sweep(biogpt_hip_ctx *ctx, int which /* 0: every matrix, two copies; 1: lm_head alone, 14 copies in turn */, int reps, double *seconds_out, double *bytes_out, double *check_out);
+int biogpt_hip_bench_sweep(biogpt_hip_ctx *ctx, int which /* 0: every matrix, two copies; 1: lm_head alone; 2: q/k/v + out_proj of every layer (the K = 1024, D x D shapes); 3: fc2 (K = 4096); 4: fc1 -- 1 .. 4 on as many copies in turn as exceed the Infinity Cache */, int reps, double *seconds_out, double *bytes_out, double *check_out);
+/* the same, and (each may be NULL) the launch's output rows (matrix after matrix: per layer q/k/v, out_proj, fc1, fc2, then lm_head -- those `which` selects) and the two Q8
+ * activation vectors (xq_out: 1024 + 4096 int8, xd_out: 32 + 128 block scales) they were computed with, so that a test can recompute rows with the oracle's vec_dot of
+ * biogpt.cpp:705-716,767,803's mat-vecs */
+int biogpt_hip_bench_sweep_ex(biogpt_hip_ctx *ctx, int which, int reps, double *seconds_out, double *bytes_out, double *check_out, float *rows_out, size_t rows_cap, int8_t *xq_out, float *xd_out);
 
 /* Single-token evals of a context that does not hold the device's pipeline slot are replayed as a captured five-launch step.  The row of such a replay carries the
  * sequence number its first node fetched (forwarded by the last layer's last kernel and by the lm_head as they start); biogpt_hip_eval / biogpt_hip_eval_inplace /

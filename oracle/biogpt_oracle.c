@@ -784,6 +784,13 @@ float bo_vec_dot(int wtype, int64_t k, const void *wrow, const float *x) {
     return r;
 }
 
+/* the same with the activation row already in the weight type's vec_dot_type blocks (blk_q8_0 / blk_q8_1 bytes): the scalar vec_dot alone */
+float bo_vec_dot_q(int wtype, int64_t k, const void *wrow, const void *yblocks) {
+    init_tables();
+    if (vec_dot_type(wtype) < 0) return NAN;
+    return vec_dot_typed(wtype, k, wrow, yblocks);
+}
+
 /* ------------------------------------------------------------------------------------------
  * model file
  * ---------------------------------------------------------------------------------------- */

@@ -75,6 +75,7 @@ size_t bo_quantize(int type, const float *src, void *dst, int64_t n, int64_t k);
 void   bo_dequantize_row(int type, const void *src, float *dst, int64_t k);
 /* dot(W row, x) the way ggml's CPU mul_mat does it: x is converted to the type's vec_dot_type first */
 float  bo_vec_dot(int wtype, int64_t k, const void *wrow, const float *x);
+float  bo_vec_dot_q(int wtype, int64_t k, const void *wrow, const void *yblocks);   /* activation row given as Q8_0 / Q8_1 blocks */
 int    bo_have_avx2(void);                     /* 1: this CPU runs the AVX2 + FMA forms of the SIMD-shaped dots (bo_opts.assoc bit 2) */
 
 /* ---- model file ---- */

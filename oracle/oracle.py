@@ -61,6 +61,8 @@ def lib():
     L.bo_dequantize_row.restype = None
     L.bo_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
     L.bo_vec_dot.restype = C.c_float
+    L.bo_vec_dot_q.restype = C.c_float
+    L.bo_vec_dot_q.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     L.bo_have_avx2.restype = C.c_int
     L.bo_have_avx2.argtypes = []
     L.bo_vec_dot.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
@@ -205,3 +207,8 @@ class OracleModel:
 def have_avx2():
     """True when the oracle's AVX2 + FMA forms of the SIMD-shaped dots run on this CPU (assoc bit 2 is then honoured)."""
     return bool(lib().bo_have_avx2())
+
+
+def vec_dot_q(wtype, k, wrow_bytes, yblocks_bytes):
+    """The reference's scalar vec_dot of one weight row (file-format bytes) against an activation row already quantized to Q8_0 / Q8_1 blocks."""
+    return float(lib().bo_vec_dot_q(int(wtype), int(k), C.c_char_p(bytes(wrow_bytes)), C.c_char_p(bytes(yblocks_bytes))))

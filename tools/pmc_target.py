@@ -25,6 +25,12 @@ elif len(sys.argv) > 2 and sys.argv[2] == "dual":      # the two-workgroups-per-
 elif len(sys.argv) > 2 and sys.argv[2] == "sweep":     # matvec_sweep_kernel: every block-quantized matrix of the model in one launch (kernels_sweep.hip.h)
     s, b, c = g.bench_sweep(40)
     print("sweep", round(s * 1e6, 2), "us", b, "bytes", round(b / s / 1e9, 1), "GB/s, check", c, flush=True)
+elif len(sys.argv) > 2 and sys.argv[2] == "headline":  # the headline's own work and nothing else: 200-token greedy continuations of 4-token prompts (bench.py's timed step), multi-token launches
+    rng = np.random.default_rng(1000)
+    for k in range(6):
+        pr = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 3)]
+        ids, secs = g.generate_greedy(pr, 200, n_batch=8)
+        print("continuation", k, round(secs * 1e3, 3), "ms", g.generate_launches(), flush=True)
 elif len(sys.argv) > 2 and sys.argv[2] == "xpipe":     # only the XCD-pipelined single-token launch at 104 keys (bench.py's roofline.traffic pass)
     if g.xpipe_state() == 1:
         s, b = g.bench_matvec(11, 0, 24)
