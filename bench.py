@@ -134,6 +134,41 @@ def pmc_traffic(model_path):
     return round(fetch_b + write_b, 0), detail
 
 
+def pmc_chunk_traffic(model_path):
+    """FETCH_SIZE of the column-per-XCD chunk launch (dec_xcols_kernel), one rocprofv3 --pmc pass over tools/pmc_target.py <model> chunk (8-token evals at 0 .. 64 keys and at
+    296 .. 360 keys): bytes fetched per launch (KiB x 1024 x 2, the gfx950 correction of pmc_traffic), per context variant."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"):
+        raise RuntimeError("this run is itself under a profiler")
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = tempfile.mkdtemp(prefix="biogpt_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(here, "tools", "pmc_target.py"), model_path, "chunk"]
+        subprocess.run(cmd, timeout=200, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=False)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if not dbs:
+            raise RuntimeError("no rocprofv3 database")
+        con = sqlite3.connect(dbs[0])
+        rows = list(con.execute("select kernel_name, value from counters_collection where counter_name = 'FETCH_SIZE' and kernel_name like '%dec_xcols_kernel%'"))
+        con.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    per = {}
+    for name, v in rows:
+        k = name.split("(")[0].split("dec_xcols_kernel")[-1]
+        per.setdefault(k, []).append(v)
+    if not per:
+        raise RuntimeError("no dec_xcols_kernel dispatch in the pass")
+    return {k: {"fetched_bytes_per_launch": round(sum(v) / len(v) * 1024.0 * 2.0, 0), "dispatches": len(v)} for k, v in per.items()}
+
+
 def pmc_mfma_busy(model_path, pass_seconds):
     """SQ_VALU_MFMA_BUSY_CYCLES of one 512-column prompt pass (its own rocprofv3 --pmc pass over tools/pmc_target.py <model> prefill, --kernel-trace only beside it), as a
     fraction of the SIMD cycles of the pass: busy / (pass time x 2.4 GHz x 1024 SIMDs).  The counter sums over the SIMDs; one v_mfma_i32_16x16x32_i8 is 16 busy cycles."""
@@ -559,7 +594,7 @@ def main():
                                                "bound": "neither peak: the chain is VALU-bound -- every v_mfma_i32_16x16x32_i8 (16 cycles) is followed by the exact per-block f32 scaling of its 4 outputs per lane "
                                                         "(the reference's arithmetic), and the attention (exact double sums) runs on the VALU"},
                                   "note": "512-token prompt, 64 reference evals of n_batch=8 in one pass (bench.py --workload prefill is the full bench line)"}
-            # the reference's OWN prompt loop (main.cpp:129-137): one biogpt_eval per n_batch = 8 tokens, the row copied out every time.  Up to 256 keys such an eval is ONE
+            # the reference's OWN prompt loop (main.cpp:129-137): one biogpt_eval per n_batch = 8 tokens, the row copied out every time.  Up to 512 keys such an eval is ONE
             # persistent launch with one column per XCD (csrc/kernels_xcols.hip.h), beyond that the launch chain of kernels_fast.hip.h
             try:
                 def chunk_loop(n_tok):
@@ -577,7 +612,7 @@ def main():
                                              "tokens_per_s_512_token_prompt": round(512 / t512, 1), "ms_per_eval_257_512_keys": round((t512 - t256) / 32 * 1e3, 3),
                                              "note": "biogpt_hip_eval per 8-token chunk from Python (ctypes), rows copied to the host; 0 .. 256 keys: the column-per-XCD launch "
                                                      "(every XCD streams all weights: 16.7 us per layer against 9.8 us of pure weight stream and ~ 11 us of dependent chain, HISTORY.md round 4; profiles/xcols_timeline_r4.txt), "
-                                                     "257 .. 512 keys: the launch chain (round 3: 0.86 ms per eval at every context)"}
+                                                     "257 .. 512 keys: the same launch in its 512-key variant (round 6: the second half of a head's old K / V rows requested at the start of the attention stage; the launch chain it replaces: 0.92 ms per eval); beyond 512 keys the launch chain"}
             except Exception as e:
                 out["prompt_chunk_evals"] = {"error": str(e)[:300]}
             # the drop-in API loop as a C++ caller runs it (main.cpp:91-151: one eval call per token, sampler on the host; never
@@ -716,6 +751,18 @@ def main():
             out["roofline"]["traffic_detail"] = detail
         except Exception as e:
             out["roofline"]["traffic_detail"] = {"error": str(e)[:300]}
+
+    if world == 1 and not prefill and not args.no_pmc and isinstance(out.get("prompt_chunk_evals"), dict) and "error" not in out["prompt_chunk_evals"]:
+        # fetched / algorithmic bytes of the chunk launch: every XCD streams ALL weights (kernels_xcols.hip.h), so an 8-token eval fetches ~ 8 x the 196 MB a single stream needs
+        try:
+            tr = pmc_chunk_traffic(path)
+            alg = float(pkg.decode_bytes_per_token(hp, 64))
+            out["prompt_chunk_evals"]["traffic"] = {k: dict(v, fetched_over_algorithmic=round(v["fetched_bytes_per_launch"] / alg, 2)) for k, v in tr.items()}
+            out["prompt_chunk_evals"]["traffic"]["algorithmic_bytes_per_eval"] = alg
+            out["prompt_chunk_evals"]["traffic"]["how"] = ("one rocprofv3 --pmc FETCH_SIZE pass (kernel-trace only beside it) over tools/pmc_target.py <model> chunk; KiB x 1024 x 2 (gfx950); "
+                                                            "algorithmic = the weights once + K / V rows (SURVEY 8(d), B at 64 keys)")
+        except Exception as e:
+            out["prompt_chunk_evals"]["traffic"] = {"error": str(e)[:300]}
 
     if world == 1 and not prefill and not args.no_pmc and isinstance(out.get("prompt_pass"), dict) and "roofline" in out["prompt_pass"]:
         try:

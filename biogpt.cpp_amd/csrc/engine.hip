@@ -861,7 +861,7 @@ extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes);
 // model / device / options fit, and the launch's buffers exist (allocated here: never inside a stream capture)
 bool xcols_prepare(biogpt_hip_ctx *c, int N, int t_max) {
     const int32_t wt = ftype_to_type(c->hp.ftype);
-    if (!c->opt.xcols || c->opt.causal || N < 2 || N > 8 || t_max > 256 || c->xc_lds < 0) return false;
+    if (!c->opt.xcols || c->opt.causal || N < 2 || N > 8 || t_max > 512 || c->xc_lds < 0) return false;      // (257 .. 512 keys: the variant that requests the second half of a head's old rows inside the attention stage)
     if (!(wt == T_Q4_0 || wt == T_Q4_1 || wt == T_Q5_0 || wt == T_Q5_1 || wt == T_Q8_0)) return false;
     if (!fused_decode_ok(c, t_max) || c->xp_state != 1) return false;
     if (c->xc_gran && c->xc_lds == 1) return true;
@@ -886,7 +886,7 @@ bool xcols_prepare(biogpt_hip_ctx *c, int N, int t_max) {
 }
 bool xcols_usable(biogpt_hip_ctx *c, int N, int t_max) {
     if (c->state_chunk != 0 || !xcols_prepare(c, N, t_max)) return false;
-    return xpipe_usable(c, t_max);
+    return xpipe_usable(c, std::min(t_max, 256));      // the device's pipeline slot (a chunk launch needs none of the long-context launch's regions)
 }
 
 // the N columns of the device state (upload_state) through all layers in one launch, then the ordinary final LayerNorm + lm_head launch on the LAST column (F8)

@@ -19,7 +19,7 @@
 // tickets and leave.  Workgroups 16 .. 31 of an XCD: LayerNorm -> Q8 -> the 192 q / k / v rows of head slot - 16 (+ KV append at row n_past + column);
 // workgroups 0 .. 15: attention of head `slot` over the n_past old keys (registers, requested a layer ahead) and the N new ones (LDS); all 32: out_proj rows,
 // LayerNorm + fc1 + GELU, fc2 rows.  The final LayerNorm + lm_head of the LAST column (F8) is the ordinary stand-alone launch behind this one.
-// Contexts up to 256 keys (n_past + N <= 256; the one-lane-per-key path for 257 .. 512 keys -- LPK = 1, KCAP = 512 -- is slower than the launch chain there and not instantiated), all five block formats (Q8_0 with its q / k / v units requested late: 9 registers per unit).
+// Contexts up to 512 keys (n_past + N <= 512; beyond 256 the second half of a head's old rows is requested inside the attention stage: xc_run, SEG2), all five block formats (Q8_0 with its q / k / v units requested late: 9 registers per unit).
 #pragma once
 
 #include "kernels_xpipe.hip.h"
@@ -98,8 +98,14 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     constexpr bool ATTN = ROLE == 0;
     constexpr int NW = 8, NT = 512, DK = 64;
     constexpr int QS = 96 / NW, OS = 16 / NW, FS = 64 / NW, F2R = 32 / NW;
-    static_assert(KCAP % NW == 0 && KCAP <= NW * 64 / LPK, "key capacity of the launch");
-    constexpr int NF4 = 16 / LPK, NV = KCAP / NW;
+    // 512-key variant (SEG2; LPK = 2): the lane pair of key k also takes key k + 256.  Keys 0 .. 255 wait in registers as in the 256-key variant (requested a layer
+    // ahead); the rows of keys 256 .. 511 are requested at the START of the stage, in front of the poll for the layer's new rows (which waits for the other workgroups' stage A
+    // anyway): 64 registers for the length of the stage instead of 128 more held through the layer (the one-lane-per-key form of round 4: slower than the launch chain).
+    // The chain of kernels_fast.hip.h costs 0.92 ms per 8-token eval there.
+    constexpr bool SEG2 = KCAP > 256;
+    constexpr int KREG = SEG2 ? 256 : KCAP;      // keys whose rows are register-resident
+    static_assert(KCAP % NW == 0 && KREG <= NW * 64 / LPK && (!SEG2 || (LPK == 2 && KCAP == 512)), "key capacity of the launch");
+    constexpr int NF4 = 16 / LPK, NV = KREG / NW;
     // 256-key variant (Q8_0, 9 registers per unit: beyond 64 keys), attention workgroups: the head's K / V rows + 18 units + the dots' temporaries do not fit; there the fc1 /
     // fc2 units are requested when the attention is done (one / two stages ahead of their use: the poll in between waits for them) and never wait beside the K / V rows.
     // UNCOND (Q8_0): the end-of-layer requests are unconditional (the last layer asks for its own units once more): a request under `if (more)` keeps the OLD registers alive
@@ -314,6 +320,23 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             // ================= stage B (workgroups 0-15): attention of head `head`, query = this column (biogpt.cpp:729-764, no mask inside the eval: F1) =================
             const int ksub = tid & (LPK - 1), kidx = tid / LPK;
             const int dd = tid & (DK - 1), sl = tid >> 6;
+            // SEG2: the rows of keys 256 .. 511 (written by earlier evals; where a key is one of THIS eval's its pieces are replaced from LDS below) -- the K pieces of key
+            // kidx + 256 and the V values of keys 256 + sl + 8 k, requested HERE, in front of the poll for the layer's new q / k / v rows: that poll waits for stage A of the
+            // other workgroups (microseconds) anyway, and a wave's loads return in order -- the round trip to the memory side hides behind it instead of standing in the stage
+            float4 kr2[SEG2 ? NF4 : 1];
+            float vr2[SEG2 ? NV : 1];
+            if constexpr (SEG2) {
+                const float *kb = p.layers[L].kcache + (size_t)head * p.P * DK, *vb = p.layers[L].vcache + (size_t)head * p.P * DK;
+                const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
+                const int ko = ((kidx + 256) * DK + 4 * ksub) * 4, vo = ((256 + sl) * DK + dd) * 4;
+#pragma unroll
+                for (int m = 0; m < NF4; m++) {
+                    const xp_v4u t = __builtin_amdgcn_raw_buffer_load_b128(krs, ko, LPK * m * 16, 2);
+                    kr2[m] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                }
+#pragma unroll
+                for (int k = 0; k < NV; k++) vr2[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, vo, NW * k * DK * 4, 2));
+            }
             if (wave < PW) {   // this column's q row (own XCD) and the k / v rows of ALL columns (their XCDs): up to 64 + 1024 granules, at most five per lane, in ONE poll loop
                 const xp_u64 *gq = G + XP_G_QKV + head * 64 + (tid & 63);
                 const bool aq = tid < 64;
@@ -345,7 +368,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             }
             __syncthreads();
             XC_WALL(7);
-            float sc = -INFINITY;
+            float sc = -INFINITY, sc2 = -INFINITY;
             if ((tid & ~63) < LPK * T) {        // whole waves past the context skip the double-precision work
                 if (kidx >= n_old && kidx < T) {
 #pragma unroll
@@ -366,8 +389,30 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                     sc = (float)acc;
                 }
             }
+            if constexpr (SEG2) {
+                const int k2 = kidx + 256;
+                if ((tid & ~63) < LPK * (T - 256)) {
+                    if (k2 >= n_old && k2 < T) {
+#pragma unroll
+                        for (int m = 0; m < NF4; m++) kr2[m] = *reinterpret_cast<const float4 *>(s_new + (k2 - n_old) * 128 + 4 * (LPK * m + ksub));
+                    }
+                    if (k2 < T) {
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NF4; m++) {
+                            const float4 qm = *reinterpret_cast<const float4 *>(s_cur + 4 * (LPK * m + ksub));
+                            a0 += (double)__fmul_rn(kr2[m].x, qm.x); a1 += (double)__fmul_rn(kr2[m].y, qm.y);
+                            a2 += (double)__fmul_rn(kr2[m].z, qm.z); a3 += (double)__fmul_rn(kr2[m].w, qm.w);
+                        }
+                        double acc = (a0 + a1) + (a2 + a3);
+                        acc += dpp_d<DPP_QUAD_XOR1>(acc);
+                        sc2 = (float)acc;
+                    }
+                }
+            }
             const bool valid = kidx < T && ksub == 0;      // this lane holds a score of the head
-            float mx = wave_max_f32(sc);
+            const bool valid2 = SEG2 && kidx + 256 < T && ksub == 0;
+            float mx = wave_max_f32(fmaxf(sc, sc2));
             if (lane == 0) s_redf[wave] = mx;
             __syncthreads();
             mx = s_redf[0];
@@ -379,6 +424,11 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                 const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc, mx))]);      // ggml_soft_max: fp16 exp table (every workgroup's LDS slice is GELU's here)
                 s_S[kidx] = val;
                 sum = (double)val;
+            }
+            if (valid2) {
+                const float val = h2f(p.exp_tab[f2h(__fsub_rn(sc2, mx))]);
+                s_S[kidx + 256] = val;
+                sum += (double)val;      // (a sum of fp16 values in double: exact in any order)
             }
             sum = wave_sum_f64(sum);
             if (lane == 0) s_redd[wave] = sum;
@@ -408,6 +458,26 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                         const double c1 = (double)__fmul_rn(j1 >= n_old ? vn[k + 1] : vr[k0 + k + 1], __fmul_rn(pj[k + 1], inv));
                         a0 += (j0 < T) ? c0 : 0.0;
                         a1 += (j1 < T) ? c1 : 0.0;
+                    }
+                }
+                if constexpr (SEG2) {      // the same for keys 256 + sl + 8 k
+#pragma unroll
+                    for (int k0 = 0; k0 < NV; k0 += CH) {
+                        float pj[CH], vn[CH];
+#pragma unroll
+                        for (int k = 0; k < CH; k++) {
+                            const int j = 256 + sl + NW * (k0 + k), nj = j - n_old;
+                            pj[k] = s_S[j];
+                            vn[k] = s_new[((nj < 0 || nj > 7) ? 0 : nj) * 128 + 64 + dd];
+                        }
+#pragma unroll
+                        for (int k = 0; k < CH; k += 2) {
+                            const int j0 = 256 + sl + NW * (k0 + k), j1 = j0 + NW;
+                            const double c0 = (double)__fmul_rn(j0 >= n_old ? vn[k] : vr2[k0 + k], __fmul_rn(pj[k], inv));
+                            const double c1 = (double)__fmul_rn(j1 >= n_old ? vn[k + 1] : vr2[k0 + k + 1], __fmul_rn(pj[k + 1], inv));
+                            a0 += (j0 < T) ? c0 : 0.0;
+                            a1 += (j1 < T) ? c1 : 0.0;
+                        }
                     }
                 }
                 s_pv[tid] = a0 + a1;

@@ -1,5 +1,5 @@
-// Translation unit of the column-per-XCD chunk launches (kernels_xcols.hip.h: biogpt_eval with 2 .. 8 tokens as one persistent launch): 5 block formats x 3 context
-// variants (<= 64 / 128 / 256 keys).  Same arrangement as xpipe_tu.hip: own namespace name for the headers' non-inline kernels, the parameter block crosses as bytes.
+// Translation unit of the column-per-XCD chunk launches (kernels_xcols.hip.h: biogpt_eval with 2 .. 8 tokens as one persistent launch): 5 block formats x 4 context
+// variants (<= 64 / 128 / 256 / 512 keys).  Same arrangement as xpipe_tu.hip: own namespace name for the headers' non-inline kernels, the parameter block crosses as bytes.
 #define bgk bgk_xc
 #include <hip/hip_runtime.h>
 
@@ -15,14 +15,15 @@ hipError_t launch_t(int t_cap, size_t sm, hipStream_t st, const bgk::XcParams &x
     if (t_cap <= 64) hipLaunchKernelGGL((bgk::dec_xcols_kernel<WT, 8, 64>), dim3(256), dim3(512), sm, st, xc);
     else if (t_cap <= 128) hipLaunchKernelGGL((bgk::dec_xcols_kernel<WT, 4, 128>), dim3(256), dim3(512), sm, st, xc);
     else if (t_cap <= 256) hipLaunchKernelGGL((bgk::dec_xcols_kernel<WT, 2, 256>), dim3(256), dim3(512), sm, st, xc);
+    else if (t_cap <= 512 && xc.seq == nullptr) hipLaunchKernelGGL((bgk::dec_xcols_kernel<WT, 2, 512>), dim3(256), dim3(512), sm, st, xc);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 template <int WT>
 hipError_t set_lds_t(size_t sm) {
-    const void *fns[3] = {reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 8, 64>), reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 4, 128>),
-                          reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 2, 256>)};
+    const void *fns[4] = {reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 8, 64>), reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 4, 128>),
+                          reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 2, 256>), reinterpret_cast<const void *>(bgk::dec_xcols_kernel<WT, 2, 512>)};
     for (const void *fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;

@@ -1,7 +1,7 @@
 """biogpt_eval with 2 .. 8 tokens -- the chunks of the reference's prompt loop (main.cpp:129-137; no mask inside an eval, F1; biogpt.cpp:664-811) -- through the
 column-per-XCD persistent launch (csrc/kernels_xcols.hip.h) against (a) the launch chain it replaces (BIOGPT_HIP_XCOLS=0) bit for bit, logits and appended
-K / V rows, and (b) the oracle within the contract; all five block formats, chunk sizes 2 .. 8, every context variant (<= 64 / 128 / 256 keys) and the border
-where the chain takes over (n_past + N > 256); float files keep the chain; the full 24-layer model; a disturbed launch."""
+K / V rows, and (b) the oracle within the contract; all five block formats, chunk sizes 2 .. 8, every context variant (<= 64 / 128 / 256 / 512 keys) and the border
+where the chain takes over (n_past + N > 512); float files keep the chain; the full 24-layer model; a disturbed launch."""
 import numpy as np
 import pytest
 
@@ -45,18 +45,20 @@ def test_chunk_launch_equals_the_launch_chain_and_the_oracle(pkg, oracle, files,
         pytest.skip("XCD pipeline not available on this device (xpipe_state %d)" % g.xpipe_state())
     o = oracle.OracleModel(files[name], n_threads=16)
     rng = np.random.default_rng(61)
-    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 299)]
-    sizes = [8, 2, 3, 8, 5, 7, 8, 4, 6, 8, 8, 8, 5, 8, 3, 8] + [8] * 12 + [7, 8, 2, 8, 8, 6, 8, 3, 5, 8, 8]      # borders at 64, 128, 256 keys crossed by chunks
+    toks = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 539)]
+    # borders at 64, 128, 256 keys crossed by chunks; then on to the 512-key variant (the second half of a head's old rows requested inside the attention stage) and across
+    # ITS border at 512 keys, where the launch chain takes over
+    sizes = [8, 2, 3, 8, 5, 7, 8, 4, 6, 8, 8, 8, 5, 8, 3, 8] + [8] * 12 + [7, 8, 2, 8, 8, 6, 8, 3, 5, 8, 8] + [8] * 6 + [3, 8, 5] + [8] * 20 + [7, 8, 6, 8, 8]
     n_past, worst, through = 0, 0.0, 0
     for n in sizes:
-        if n_past + n > 280:
+        if n_past + n > 530:
             break
         chunk = toks[n_past:n_past + n]
         _opts(g, monkeypatch, BIOGPT_HIP_XCOLS="1")
         before = g.chunk_launches()
         lx = g.eval(chunk, n_past)
         used = g.chunk_launches() - before
-        assert used == (1 if n_past + n <= 256 else 0), "n_past %d n %d: %d chunk launches" % (n_past, n, used)
+        assert used == (1 if n_past + n <= 512 else 0), "n_past %d n %d: %d chunk launches" % (n_past, n, used)
         through += used
         assert g.xpipe_state() == 1, "pipeline abandoned at n_past %d" % n_past
         kx = _kv(g, n_past, n)
@@ -71,7 +73,7 @@ def test_chunk_launch_equals_the_launch_chain_and_the_oracle(pkg, oracle, files,
         worst = max(worst, float(np.abs(lx - lo).max()))
         assert int(lx.argmax()) == int(lo.argmax())
         n_past += n
-    assert n_past > 256 and through >= 30
+    assert n_past > 512 and through >= 60
     print("%s: %d chunk evals through the column-per-XCD launch, worst |diff| vs oracle %.2e" % (name, through, worst))
     assert worst <= ATOL
     g.close()
@@ -156,6 +158,39 @@ def test_24_layers_prompt_in_chunks_of_8(pkg, oracle, tmp_path):
             got = g.read_kv(w, l * kw["n_positions"] * kw["d_model"], 48 * kw["d_model"]).reshape(48, kw["d_model"])
             assert np.abs(got - ref[l, :48]).max() <= ATOL, (w, l)
     print("24 layers: worst |diff| vs oracle %.2e" % worst)
+    assert worst <= ATOL
+    g.close()
+
+
+def test_24_layers_chunks_of_8_from_296_to_512_keys(pkg, oracle, tmp_path):
+    """The second half of a 512-token prompt as the reference's unchanged loop issues it (main.cpp:129-137: biogpt_eval per 8 tokens) at BioGPT-base depth: 27 chunk
+    launches of the 512-key variant on top of a 296-token prefix, every returned row and the K / V rows of layers 0 / 11 / 23 against the oracle."""
+    kw = dict(KW, n_layer=24, n_vocab=8192, n_merges=100)
+    f32, q = str(tmp_path / "f32.bin"), str(tmp_path / "q4_0.bin")
+    pkg.write_synthetic(f32, seed=25, **kw)
+    pkg.quantize_file(f32, q, "q4_0")
+    g = pkg.BiogptModel.load(q)
+    if g.xpipe_state() != 1:
+        pytest.skip("XCD pipeline not available on this device")
+    o = oracle.OracleModel(q, n_threads=16)
+    rng = np.random.default_rng(69)
+    toks = [2] + [int(v) for v in rng.integers(4, kw["n_vocab"], 511)]
+    g.eval_prompt(toks[:296], 0, 8)
+    for at in range(0, 296, 8):
+        o.eval(toks[at:at + 8], at)
+    before, worst, exact = g.chunk_launches(), 0.0, 0
+    for at in range(296, 512, 8):
+        lg, lo = g.eval(toks[at:at + 8], at), o.eval(toks[at:at + 8], at)
+        worst = max(worst, float(np.abs(lg - lo).max()))
+        exact += int((lg == lo).all())
+        assert int(lg.argmax()) == int(lo.argmax()), at
+    assert g.chunk_launches() - before == 27 and g.xpipe_state() == 1
+    for w in (0, 1):
+        ref = o.kv(w)
+        for l in (0, 11, 23):
+            got = g.read_kv(w, (l * kw["n_positions"] + 296) * kw["d_model"], 216 * kw["d_model"]).reshape(216, kw["d_model"])
+            assert np.abs(got - ref[l, 296:512]).max() <= ATOL, (w, l)
+    print("24 layers, chunks at 296 .. 512 keys: worst |diff| vs oracle %.2e, %d/27 rows bit-identical" % (worst, exact))
     assert worst <= ATOL
     g.close()
 

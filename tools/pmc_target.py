@@ -13,12 +13,17 @@ if len(sys.argv) > 2 and sys.argv[2] == "prefill":
     g.eval_prompt(toks, 0, 8, want_logits=False); g.synchronize()
 elif len(sys.argv) > 2 and sys.argv[2] == "long":      # the pipelined launch of a 1024-key step (kernels_xlong.hip.h): graph replays at n_past = 1023
     print("T=1024", round(g.bench_decode(1023, 40) * 1e6, 2), "us per token", flush=True)
-elif len(sys.argv) > 2 and sys.argv[2] == "chunk":     # the column-per-XCD chunk launch (kernels_xcols.hip.h): 8-token evals at 0 .. 64 keys
+elif len(sys.argv) > 2 and sys.argv[2] == "chunk":     # the column-per-XCD chunk launch (kernels_xcols.hip.h): 8-token evals at 0 .. 64 keys and at 296 .. 360 keys
     rng = np.random.default_rng(7000)
     toks = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 63)]
     for rep in range(3):
         for at in range(0, 64, 8):
             g.eval(toks[at:at + 8], at)
+    more = [2] + [int(v) for v in rng.integers(4, g.hparams.n_vocab, 359)]      # ... and at 296 .. 360 keys: the 512-key variant of the launch
+    g.eval_prompt(more[:296], 0, 8)
+    for rep in range(3):
+        for at in range(296, 360, 8):
+            g.eval(more[at:at + 8], at)
     print("chunk launches", g.chunk_launches(), flush=True)
 elif len(sys.argv) > 2 and sys.argv[2] == "dual":      # the two-workgroups-per-head launch at 400 keys: graph replays at n_past = 399
     print("T=400", round(g.bench_decode(399, 40) * 1e6, 2), "us per token", flush=True)
