@@ -134,6 +134,19 @@ struct XpParams {
 #define XP_TAIL(tok, k) do {} while (0)
 #endif
 
+// Parameters that are read once per token (the sampler's and the lm_head pass's buffers, everything of the resident form) are NOT held in scalar registers over the launch:
+// XPK(field) reads the field from the kernel-argument segment where it is used, through a pointer the optimiser cannot look through (otherwise every field is loaded at
+// the top of the kernel and lives -- or is spilled to VGPR lanes: 149 / 276 spilled SGPRs in the ordinary / resident 128-key kernels, v_readlane on the stages' critical
+// path -- for the whole layer loop).  XpParams is the launch's ONLY argument: offset 0 of the segment.
+typedef const XpParams __attribute__((address_space(4))) *XpKernargPtr;
+__device__ __forceinline__ XpKernargPtr xp_kernarg() {
+    XpKernargPtr k = (XpKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+#define XPK(field) (xp_kernarg()->field)
+#define XPK_MATRIX(field) DevMatrix{XPK(field.qs), XPK(field.sc), XPK(field.qh), XPK(field.type), XPK(field.M), XPK(field.K)}
+
 // to ANOTHER XCD (the layer output): write-through (sc1) store, visible at the memory side
 __device__ __forceinline__ void xp_put(xp_u64 *g, uint32_t epoch, uint32_t v) { __hip_atomic_store(g, ((xp_u64)epoch << 32) | v, XP_RLX); }
 // inside the XCD (every other hand-off): a plain 8-byte store keeps the line in the XCD's L2, where the pollers' sc1 loads
@@ -570,9 +583,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             if (L == 0) {
                 int tok;
                 // the position's row of embed_positions does not depend on the token: requested before the sampler, in registers when the token is known
-                const bool emb_fast = p.tok_emb.type == WT && p.pos_emb.type == WT;
+                const bool emb_fast = XPK(tok_emb.type) == WT && XPK(pos_emb.type) == WT;
                 uint32_t pq = 0u, psc = 0u, pqh = 0u;
-                if (emb_fast && worker) xp_row4_request<WT>(p.pos_emb, n_past + 2, tid, pq, psc, pqh);
+                if (emb_fast && worker) xp_row4_request<WT>(XPK_MATRIX(pos_emb), n_past + 2, tid, pq, psc, pqh);
                 // greedy sampler of the previous token of THIS launch: its per-block partials arrive as granules from the
                 // XCDs that computed the logits (two blocks per thread at most: lm_blocks <= 1024); every thread returns the arg-max
                 auto sample_prev = [&]() __attribute__((always_inline)) -> int {
@@ -580,17 +593,17 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     int bi = 0x7fffffff;
                     {
                         uint32_t v[4] = {0u, 0u, 0u, 0u};
-                        const bool a0 = tid < p.lm_blocks, a1 = tid + NT < p.lm_blocks;
+                        const bool a0 = tid < XPK(lm_blocks), a1 = tid + NT < XPK(lm_blocks);
                         const uint32_t prev = epoch - 1u;
                         for (uint32_t spins = 0; !RES || etag != 0u; spins++) {
                             bool ok = true;
                             if (a0) {
-                                const xp_u64 x0 = __hip_atomic_load(p.samp + tid, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid, XP_RLX);
+                                const xp_u64 x0 = __hip_atomic_load(XPK(samp) + tid, XP_RLX), x1 = __hip_atomic_load(XPK(samp) + 1024 + tid, XP_RLX);
                                 v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
                                 ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                             }
                             if (a1) {
-                                const xp_u64 x0 = __hip_atomic_load(p.samp + tid + NT, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid + NT, XP_RLX);
+                                const xp_u64 x0 = __hip_atomic_load(XPK(samp) + tid + NT, XP_RLX), x1 = __hip_atomic_load(XPK(samp) + 1024 + tid + NT, XP_RLX);
                                 v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
                                 ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                             }
@@ -613,34 +626,34 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                     for (int w = 1; w < NW; w++)
                         if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
-                    if (bi < 0 || bi >= p.n_vocab) bi = 0;
+                    if (bi < 0 || bi >= XPK(n_vocab)) bi = 0;
                     return bi;
                 };
-                if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)XPK(res_spec0); s_spec[1] = 0xffffffffu; }
                 if (RES && p.resident != 0 && tk > 0) {
                     // resident launch: the next token is the one the NEXT biogpt_eval() call posts in the pinned mailbox -- or, speculating, the device's own
                     // arg-max of the previous one, which that post must then confirm.  Workgroup 0 decides and hands the token to the XCD's other workgroups
                     // as a granule; a wait for the host lasts at most idle_ticks, then the launch ends cleanly (xp_quit)
-                    xp_u64 *const gt = p.samp + 2048;
+                    xp_u64 *const gt = XPK(samp) + 2048;
                     if (slot == 0) {
-                        unsigned long long *const wl4 = ((p.res_dbg & 32) && p.wall && tid == 0) ? p.wall + 32768 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 4 : nullptr;
+                        unsigned long long *const wl4 = ((XPK(res_dbg) & 32) && XPK(wall) && tid == 0) ? XPK(wall) + 32768 + (size_t)((XPK(mbox_seq0) + (uint32_t)tk) & 4095u) * 4 : nullptr;
                         if (wl4) wl4[0] = wall_clock64();
-                        const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
+                        const uint32_t want = XPK(mbox_seq0) + (uint32_t)tk;
                         // the post with sequence number seq, for position np (ONE 8-byte word, xp_post): its token (>= 0) and "speculate the token after this one",
                         // or -1: time-out / the host asks the launch to leave / the launch is failing
                         auto wait_post = [&](uint32_t seq, int np, int &spec) __attribute__((always_inline)) -> int {
-                            const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(p.mbox) + (size_t)(seq & 63u) * 4;
+                            const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(XPK(mbox)) + (size_t)(seq & 63u) * 4;
                             const unsigned long long t0 = wall_clock64();
                             for (;;) {
                                 const xp_u64 w = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 if ((uint32_t)(w >> 40) == (seq & 0xffffffu)) {
                                     const int tv = (int)(w & 0xffffffu), pn = (int)((w >> 24) & 0x1fffu);
                                     spec = (int)((w >> 37) & 1u);
-                                    return (pn == np && tv < p.n_vocab) ? tv : -1;      // anything else is the host's request to leave
+                                    return (pn == np && tv < XPK(n_vocab)) ? tv : -1;      // anything else is the host's request to leave
                                 }
-                                if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) return -1;
+                                if (wall_clock64() - t0 > (unsigned long long)XPK(idle_ticks)) return -1;
                                 if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return -1;
-                                if (!(p.res_dbg & 2)) __builtin_amdgcn_s_sleep(4);
+                                if (!(XPK(res_dbg) & 2)) __builtin_amdgcn_s_sleep(4);
                             }
                         };
                         // A pass that was started unasked (from the device's own arg-max): the host's post for it -- made while that pass was running, long ago
@@ -661,7 +674,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                             const bool ahead = (int)s_spec[1] >= 0 || spec != 0;
                             int got = -1;
                             if (s_spec[2] != 0u) {
-                                if (p.spec_rec) __hip_atomic_store(p.spec_rec, ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (XPK(spec_rec)) __hip_atomic_store(XPK(spec_rec), ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 got = ahead ? guess : wait_post(want, n_past, spec);
                             }
                             if (got >= 0) {
@@ -669,31 +682,31 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                                 xp_put(gt + 1, epoch, 1u);      // the lm_head workgroups write this pass's rows only behind this word
                                 s_spec[0] = (uint32_t)spec; s_spec[1] = ahead ? (uint32_t)guess : 0xffffffffu;
                             } else xp_quit(p);
-                            if ((p.res_dbg & 32) && p.wall) p.wall[(size_t)(want & 4095u) * 2] = wall_clock64();
+                            if ((XPK(res_dbg) & 32) && XPK(wall)) XPK(wall)[(size_t)(want & 4095u) * 2] = wall_clock64();
                             if (wl4) wl4[2] = wall_clock64();
                         }
                     }
                     uint32_t v[1];
                     xp_sweep_q<RES, 1>(gt, true, epoch, v, p, etag);
                     tok = (int)v[0];
-                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                    if (tok < 0 || tok >= XPK(n_vocab)) tok = 0;
                 } else if (tk > 0) {
                     tok = sample_prev();
                     if (slot == 0 && tid == 0) {
-                        int32_t *tokens = state_tokens(p.st);
+                        int32_t *tokens = state_tokens(XPK(st));
                         const int g = n_gen0 + tk;
-                        if (g < p.n_positions) tokens[p.n_positions + g] = tok;
+                        if (g < XPK(n_positions)) tokens[XPK(n_positions) + g] = tok;
                         tokens[0] = tok;
                     }
                     __syncthreads();       // s_redf is reused by the attention workgroups
-                } else if (p.tok_src == 2) {
+                } else if (XPK(tok_src) == 2) {
                     // greedy sampler of the PREVIOUS token (main.cpp:109-128, top_k = 1): arg-max over the lm_head kernel's
                     // per-workgroup partials, lowest id wins ties; workgroup 0 records it
                     float bv = -INFINITY;
                     int bi = 0x7fffffff;
-                    for (int k = tid; k < p.nparts; k += NT) {
-                        const float v = p.pmax_val[k];
-                        const int ix = p.pmax_idx[k];
+                    for (int k = tid; k < XPK(nparts); k += NT) {
+                        const float v = XPK(pmax_val)[k];
+                        const int ix = XPK(pmax_idx)[k];
                         if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
                     }
     #pragma unroll
@@ -709,31 +722,31 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     for (int w = 1; w < NW; w++)
                         if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
                     tok = bi;
-                    if (tok < 0 || tok >= p.n_vocab) tok = 0;
+                    if (tok < 0 || tok >= XPK(n_vocab)) tok = 0;
                     if (slot == 0 && tid == 0) {
-                        int32_t *tokens = state_tokens(p.st);
+                        int32_t *tokens = state_tokens(XPK(st));
                         const int g = n_gen0;
-                        if (g < p.n_positions) tokens[p.n_positions + g] = tok;
+                        if (g < XPK(n_positions)) tokens[XPK(n_positions) + g] = tok;
                         tokens[0] = tok;
                     }
                 } else {
-                    tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
+                    tok = (RES && p.resident != 0) ? XPK(res_tok0) : state_tokens(XPK(st))[0];
                 }
                 if (slot == 0) XP_TAIL(tk, 5);
                 if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
                     float e[4];
                     if (emb_fast) {
                         uint32_t tq, tsc, tqh;
-                        xp_row4_request<WT>(p.tok_emb, tok, tid, tq, tsc, tqh);
+                        xp_row4_request<WT>(XPK_MATRIX(tok_emb), tok, tid, tq, tsc, tqh);
                         float te[4], pe[4];
                         xp_row4_values<WT>(pq, psc, pqh, tid, pe);
                         xp_row4_values<WT>(tq, tsc, tqh, tid, te);
     #pragma unroll
-                        for (int j = 0; j < 4; j++) e[j] = __fadd_rn(__fmul_rn(te[j], p.embed_scale), pe[j]);
+                        for (int j = 0; j < 4; j++) e[j] = __fadd_rn(__fmul_rn(te[j], XPK(embed_scale)), pe[j]);
                     } else {
     #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                            e[j] = __fadd_rn(__fmul_rn(dequant_elem(XPK_MATRIX(tok_emb), tok, 4 * tid + j), XPK(embed_scale)), dequant_elem(XPK_MATRIX(pos_emb), n_past + 2, 4 * tid + j));
                     }
                     xv = make_float4(e[0], e[1], e[2], e[3]);
                 }
@@ -1313,7 +1326,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 const int lr = wave * F2R + lane, row = slot * 32 + lr;
                 const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
                 xp_put(Y.gx + xp_col_slot(row), etag, __float_as_uint(v));
-                if (L == p.n_layer - 1) p.x_final[row] = v;
+                if (L == p.n_layer - 1) XPK(x_final)[row] = v;
             }
         }
         XP_WALL(5);
@@ -1330,7 +1343,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
     // behind everyone else (profiles/api_loop_device_clock_r4.txt: "XCD group of the last one: 0 0 0 0 0 64").  Their share goes to workgroups 16 .. 31 of
     // XCD 0, which have been idle since that XCD's last unit (7 units ago) and are only needed again for the next token's out_proj.
     const int lm_rank = xp_lm_rank(xcd, slot, n_units);
-    if (p.lm != 0 && lm_rank >= 0 && lm_rank * 4 < p.lm_blocks) {
+    if (p.lm != 0 && lm_rank >= 0 && lm_rank * 4 < XPK(lm_blocks)) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6;
@@ -1339,23 +1352,23 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         constexpr int LMS = 128 / NW;                                         // 2-row steps per wave: 256 rows per workgroup
         const int row0 = lm_rank * 256;
         // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
-        const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
-        float *const lg_dev = alt ? p.logits_alt : p.logits;
-        float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
+        const bool alt = RES && p.resident != 0 && ((XPK(mbox_seq0) + (uint32_t)tk) & 1u) != 0u;
+        float *const lg_dev = alt ? XPK(logits_alt) : XPK(logits);
+        float *const lg_host = alt ? XPK(logits_host_alt) : XPK(logits_host);
         Unit<WT> wl[LMS];
 #pragma unroll
         for (int s = 0; s < LMS; s++) {
             const int row = row0 + s * 2 * NW + wave * 2 + rsub;
-            if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
+            if (row < XPK(n_vocab)) load_unit<WT>(wl[s], XPK_MATRIX(Wlm), (int64_t)row * 32 + sub);
             else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
         }
 #pragma unroll
         for (int s = 0; s < LMS; s++) xp_settle<WT, EXPAND>(wl[s]);
         float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
-        if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
-        if (RES && p.resident != 0 && tk > 0 && !(p.res_dbg & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
+        if (worker) { lnw = reinterpret_cast<const float4 *>(XPK(lm_ln_w))[tid]; lnb = reinterpret_cast<const float4 *>(XPK(lm_ln_b))[tid]; }
+        if (RES && p.resident != 0 && tk > 0 && !(XPK(res_dbg) & 64)) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
             uint32_t go[1];
-            xp_sweep_q<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, etag);
+            xp_sweep_q<RES, 1>(XPK(samp) + 2049, lane == 0, epoch, go, p, etag);
         }
         if (wave < 4) {
             uint32_t v[4];
@@ -1381,10 +1394,10 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         int best_idx = 0x7fffffff;
         if (lane < 2 * LMS) {
             const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
-            if (row < p.n_vocab) {
+            if (row < XPK(n_vocab)) {
                 const float v = sum32_in_order(part + lane * DEC_PS);
                 if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: no attention runs in this workgroup now)
-                else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
+                else { XPK(logits)[row] = v; if (XPK(logits_host)) XPK(logits_host)[row] = v; }
                 best_val = v; best_idx = row;
             }
         }
@@ -1403,25 +1416,25 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         // completion word for this token -- same wave, behind its own stores (the host collects one word per lm_head workgroup)
         if (RES && lg_host && wave == 1 && row_ok) {
             const int r = row0 + 4 * lane;
-            if (p.res_dbg & 4) {
-            } else if (r + 3 < p.n_vocab) {
+            if (XPK(res_dbg) & 4) {
+            } else if (r + 3 < XPK(n_vocab)) {
                 const xp_v4f v4 = *reinterpret_cast<const xp_v4f *>(s_S + 4 * lane);
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(lg_host + r), "v"(v4) : "memory");
                 *reinterpret_cast<xp_v4f *>(lg_dev + r) = v4;
             } else {
-                for (int j = r; j < p.n_vocab; j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
+                for (int j = r; j < XPK(n_vocab); j++) { __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
             }
             if (p.resident != 0) {
-                if (lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (the same maxima tid < 4 records below)
+                if (lane < 4 && lm_rank * 4 + lane < XPK(lm_blocks)) {      // the block maxima behind the row (the same maxima tid < 4 records below)
                     float bm = s_redf[lane * NW];
 #pragma unroll
                     for (int w = 1; w < NW; w++) bm = fmaxf(bm, s_redf[lane * NW + w]);
-                    __hip_atomic_store(lg_host + xp_blockmax_offset(p.n_vocab) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(lg_host + xp_blockmax_offset(XPK(n_vocab)) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                if (!(p.res_dbg & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((p.res_dbg & 32) && p.wall && lane == 0 && lm_rank == 0) p.wall[(size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 2 + 1] = wall_clock64();
-                if ((p.res_dbg & 32) && p.wall && lane == 0) p.wall[8192 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 63u) * 256 + lm_rank] = wall_clock64();
+                if (!(XPK(res_dbg) & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(XPK(done_host) + lm_rank, XPK(mbox_seq0) + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((XPK(res_dbg) & 32) && XPK(wall) && lane == 0 && lm_rank == 0) XPK(wall)[(size_t)((XPK(mbox_seq0) + (uint32_t)tk) & 4095u) * 2 + 1] = wall_clock64();
+                if ((XPK(res_dbg) & 32) && XPK(wall) && lane == 0) XPK(wall)[8192 + (size_t)((XPK(mbox_seq0) + (uint32_t)tk) & 63u) * 256 + lm_rank] = wall_clock64();
             }
         }
         if (tid < 4) {
@@ -1434,17 +1447,17 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
             const int blk = lm_rank * 4 + tid;
-            if (blk < p.lm_blocks) {
+            if (blk < XPK(lm_blocks)) {
                 // the device row and the partials, like the host row, only from a pass that really ran (a draining launch -- the host asked it to leave, or it gave up
                 // waiting -- still walks through the pass it was about to start, with nothing valid in its hands)
                 if (RES && !row_ok) {}
-                else if (RES && alt) { p.pmax_alt_val[blk] = bv; p.pmax_alt_idx[blk] = bi; }
-                else { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
+                else if (RES && alt) { XPK(pmax_alt_val)[blk] = bv; XPK(pmax_alt_idx)[blk] = bi; }
+                else { XPK(pmax_out_val)[blk] = bv; XPK(pmax_out_idx)[blk] = bi; }
                 if (tk + 1 < p.n_tok) {        // the sampler of the next token runs on XCD 0
-                    xp_put(p.samp + blk, etag, __float_as_uint(bv));
-                    xp_put(p.samp + 1024 + blk, etag, (uint32_t)bi);
+                    xp_put(XPK(samp) + blk, etag, __float_as_uint(bv));
+                    xp_put(XPK(samp) + 1024 + blk, etag, (uint32_t)bi);
                 }
-                if (RES && (p.res_dbg & 32) && p.wall && blk == 0) p.wall[32768 + (size_t)((p.mbox_seq0 + (uint32_t)tk) & 4095u) * 4 + 3] = wall_clock64();
+                if (RES && (XPK(res_dbg) & 32) && XPK(wall) && blk == 0) XPK(wall)[32768 + (size_t)((XPK(mbox_seq0) + (uint32_t)tk) & 4095u) * 4 + 3] = wall_clock64();
             }
         }
         if (lm_rank == 0) XP_TAIL(tk, 4);
@@ -1460,7 +1473,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             __hip_atomic_store(p.ctl, epoch0 + (uint32_t)p.n_tok, XP_RLX);
             __hip_atomic_store(p.ctl + 2, __hip_atomic_load(p.ctl + 2, XP_RLX) + 1u, XP_RLX);
         }
-        if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { p.st->n_past = n_past0 + p.n_tok; p.st->n_gen = n_gen0 + p.n_tok; }
+        if (xcd == (last_xcd == 1 ? 2 : 1) && slot == 0 && p.adv != 0) { XPK(st)->n_past = n_past0 + p.n_tok; XPK(st)->n_gen = n_gen0 + p.n_tok; }
     }
 }
 
