@@ -146,7 +146,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
     // lm_head: XCD 0 (the next token's layer 0) and the last unit's XCD take no part
     const int lm_xr = xcd - (xcd > 0 ? 1 : 0) - ((last_xcd != 0 && xcd > last_xcd) ? 1 : 0);
     const int lm_rank = slot + 32 * lm_xr;
-    const bool lm_mine = p.lm != 0 && xcd != 0 && xcd != last_xcd && lm_rank * 4 < p.lm_blocks;
+    const bool lm_mine = p.lm != 0 && xcd != 0 && xcd != last_xcd && lm_rank * 4 < XPK(lm_blocks);
 
     // this workgroup's share of the NEXT layer's old keys / values (rows of positions it has appended itself come back through its own L2)
     float4 kr[NF4];
@@ -483,17 +483,17 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             int bi = 0x7fffffff;
                             if (tk > 0) {
                                 uint32_t v[4] = {0u, 0u, 0u, 0u};
-                                const bool a0 = tid < p.lm_blocks, a1 = tid + NT < p.lm_blocks;
+                                const bool a0 = tid < XPK(lm_blocks), a1 = tid + NT < XPK(lm_blocks);
                                 const uint32_t prev = epoch - 1u;
                                 for (uint32_t spins = 0;; spins++) {
                                     bool ok = true;
                                     if (a0) {
-                                        const xp_u64 x0 = __hip_atomic_load(p.samp + tid, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid, XP_RLX);
+                                        const xp_u64 x0 = __hip_atomic_load(XPK(samp) + tid, XP_RLX), x1 = __hip_atomic_load(XPK(samp) + 1024 + tid, XP_RLX);
                                         v[0] = (uint32_t)x0; v[1] = (uint32_t)x1;
                                         ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                                     }
                                     if (a1) {
-                                        const xp_u64 x0 = __hip_atomic_load(p.samp + tid + NT, XP_RLX), x1 = __hip_atomic_load(p.samp + 1024 + tid + NT, XP_RLX);
+                                        const xp_u64 x0 = __hip_atomic_load(XPK(samp) + tid + NT, XP_RLX), x1 = __hip_atomic_load(XPK(samp) + 1024 + tid + NT, XP_RLX);
                                         v[2] = (uint32_t)x0; v[3] = (uint32_t)x1;
                                         ok &= (uint32_t)(x0 >> 32) == prev && (uint32_t)(x1 >> 32) == prev;
                                     }
@@ -508,9 +508,9 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                                 }
                             } else {
-                                for (int k = tid; k < p.nparts; k += NT) {
-                                    const float v = p.pmax_val[k];
-                                    const int ix = p.pmax_idx[k];
+                                for (int k = tid; k < XPK(nparts); k += NT) {
+                                    const float v = XPK(pmax_val)[k];
+                                    const int ix = XPK(pmax_idx)[k];
                                     if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
                                 }
                             }
@@ -527,28 +527,28 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                             for (int w = 1; w < NW; w++)
                                 if (s_redf[w] > bv || (s_redf[w] == bv && s_redi[w] < bi)) { bv = s_redf[w]; bi = s_redi[w]; }
-                            if (bi < 0 || bi >= p.n_vocab) bi = 0;
+                            if (bi < 0 || bi >= XPK(n_vocab)) bi = 0;
                             return bi;
                         };
-                        if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)p.res_spec0; s_spec[1] = 0xffffffffu; }
+                        if (RES && p.resident != 0 && tk == 0 && slot == 0 && tid == 0) { s_spec[0] = (uint32_t)XPK(res_spec0); s_spec[1] = 0xffffffffu; }
                         if (RES && p.resident != 0 && tk > 0) {
                             // resident launch (kernels_xpipe.hip.h, the same protocol): the token of this pass is the one the next biogpt_eval() call posts in the
                             // pinned mailbox -- or, running ahead of a greedy caller, the device's own arg-max, which that post must then confirm.  Workgroup 0
                             // decides and hands the token to the XCD's other workgroups; a wait for the host lasts at most idle_ticks, then the launch ends
-                            xp_u64 *const gt = p.samp + 2048;
+                            xp_u64 *const gt = XPK(samp) + 2048;
                             if (slot == 0) {
-                                const uint32_t want = p.mbox_seq0 + (uint32_t)tk;
+                                const uint32_t want = XPK(mbox_seq0) + (uint32_t)tk;
                                 auto wait_post = [&](uint32_t seq, int np, int &spec) __attribute__((always_inline)) -> int {
-                                    const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(p.mbox) + (size_t)(seq & 63u) * 4;
+                                    const xp_u64 *mb = reinterpret_cast<const xp_u64 *>(XPK(mbox)) + (size_t)(seq & 63u) * 4;
                                     const unsigned long long t0 = wall_clock64();
                                     for (;;) {
                                         const xp_u64 w = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                         if ((uint32_t)(w >> 40) == (seq & 0xffffffu)) {
                                             const int tv = (int)(w & 0xffffffu), pn = (int)((w >> 24) & 0x1fffu);
                                             spec = (int)((w >> 37) & 1u);
-                                            return (pn == np && tv < p.n_vocab) ? tv : -1;      // anything else is the host's request to leave
+                                            return (pn == np && tv < XPK(n_vocab)) ? tv : -1;      // anything else is the host's request to leave
                                         }
-                                        if (wall_clock64() - t0 > (unsigned long long)p.idle_ticks) return -1;
+                                        if (wall_clock64() - t0 > (unsigned long long)XPK(idle_ticks)) return -1;
                                         if (__hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return -1;
                                         __builtin_amdgcn_s_sleep(4);
                                     }
@@ -566,7 +566,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                                     const bool ahead = (int)s_spec[1] >= 0 || spec != 0;
                                     int got = -1;
                                     if (s_spec[2] != 0u) {
-                                        if (p.spec_rec) __hip_atomic_store(p.spec_rec, ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                        if (XPK(spec_rec)) __hip_atomic_store(XPK(spec_rec), ((unsigned long long)want << 32) | (unsigned long long)(uint32_t)guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                         got = ahead ? guess : wait_post(want, n_past, spec);
                                     }
                                     if (got >= 0) {
@@ -584,23 +584,23 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             uint32_t v[1];
                             xl_sweep<RES, 1>(gt, lane == 0, epoch, v, p, s_dead);
                             tok = __builtin_amdgcn_readfirstlane((int)v[0]);
-                            if (tok < 0 || tok >= p.n_vocab) tok = 0;
-                        } else if (tk > 0 || p.tok_src == 2) {
+                            if (tok < 0 || tok >= XPK(n_vocab)) tok = 0;
+                        } else if (tk > 0 || XPK(tok_src) == 2) {
                             tok = sample_prev();
                             if (slot == 0 && tid == 0) {
                                 int32_t *tokens = state_tokens(p.st);
-                                if (n_gen < p.n_positions) tokens[p.n_positions + n_gen] = tok;
+                                if (n_gen < XPK(n_positions)) tokens[XPK(n_positions) + n_gen] = tok;
                                 tokens[0] = tok;
                             }
                             __syncthreads();       // s_redf is reused by the helper duty
                         } else {
-                            tok = (RES && p.resident != 0) ? p.res_tok0 : state_tokens(p.st)[0];
+                            tok = (RES && p.resident != 0) ? XPK(res_tok0) : state_tokens(p.st)[0];
                         }
                         if (worker) {      // biogpt.cpp:664-686: embed_tokens[tok] * sqrt(D) + embed_positions[n_past + 2]
                             float e[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++)
-                                e[j] = __fadd_rn(__fmul_rn(dequant_elem(p.tok_emb, tok, 4 * tid + j), p.embed_scale), dequant_elem(p.pos_emb, n_past + 2, 4 * tid + j));
+                                e[j] = __fadd_rn(__fmul_rn(dequant_elem(XPK_MATRIX(tok_emb), tok, 4 * tid + j), XPK(embed_scale)), dequant_elem(XPK_MATRIX(pos_emb), n_past + 2, 4 * tid + j));
                             xv = make_float4(e[0], e[1], e[2], e[3]);
                         }
                     } else if (wave < 4) {
@@ -809,7 +809,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             const int lr = wave * F2R + lane, row = slot * 32 + lr;
                             const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
                             xp_put(p.layers[L].gx + xp_col_slot(row), epoch, __float_as_uint(v));
-                            if (L == n_layer - 1) p.x_final[row] = v;
+                            if (L == n_layer - 1) XPK(x_final)[row] = v;
                         }
                     }
                     XL_WALL2(5);
@@ -859,7 +859,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 for (int s = 0; s < LMS; s++) {
                     if (s < s0 || s >= s1) continue;
                     const int row = row0 + s * 2 * NW + wave * 2 + rsub;
-                    if (row < p.n_vocab) load_unit<WT>(wl[s], p.Wlm, (int64_t)row * 32 + sub);
+                    if (row < XPK(n_vocab)) load_unit<WT>(wl[s], XPK_MATRIX(Wlm), (int64_t)row * 32 + sub);
                     else { wl[s].q0 = make_uint4(0u, 0u, 0u, 0u); wl[s].q1 = wl[s].q0; wl[s].sc = 0u; wl[s].qh = 0u; }
                 }
 #pragma unroll
@@ -883,14 +883,14 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), lnw = xv, lnb = xv;
-            if (worker) { lnw = reinterpret_cast<const float4 *>(p.lm_ln_w)[tid]; lnb = reinterpret_cast<const float4 *>(p.lm_ln_b)[tid]; }
+            if (worker) { lnw = reinterpret_cast<const float4 *>(XPK(lm_ln_w))[tid]; lnb = reinterpret_cast<const float4 *>(XPK(lm_ln_b))[tid]; }
             // a resident pass with an odd sequence number writes the alternate row / partial buffers (XpParams::spec_rec)
-            const bool alt = RES && p.resident != 0 && ((p.mbox_seq0 + (uint32_t)tk) & 1u) != 0u;
-            float *const lg_dev = alt ? p.logits_alt : p.logits;
-            float *const lg_host = alt ? p.logits_host_alt : p.logits_host;
+            const bool alt = RES && p.resident != 0 && ((XPK(mbox_seq0) + (uint32_t)tk) & 1u) != 0u;
+            float *const lg_dev = alt ? XPK(logits_alt) : XPK(logits);
+            float *const lg_host = alt ? XPK(logits_host_alt) : XPK(logits_host);
             if (RES && p.resident != 0 && tk > 0) {      // "the rows of this pass may be written" (published by XCD 0 at the start of the pass, long ago: one poll)
                 uint32_t go[1];
-                xl_sweep<RES, 1>(p.samp + 2049, lane == 0, epoch, go, p, s_dead);
+                xl_sweep<RES, 1>(XPK(samp) + 2049, lane == 0, epoch, go, p, s_dead);
             }
             if (wave < 4) {
                 uint32_t v[4];
@@ -914,10 +914,10 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             int best_idx = 0x7fffffff;
             if (lane < 2 * LMS) {
                 const int row = row0 + (lane >> 1) * 2 * NW + wave * 2 + (lane & 1);
-                if (row < p.n_vocab) {
+                if (row < XPK(n_vocab)) {
                     const float v = sum32_in_order(part + lane * DEC_PS);
                     if constexpr (RES) s_S[row - row0] = v;        // staged for the copies below (s_S: this workgroup's helper duties of the token are over)
-                    else { p.logits[row] = v; if (p.logits_host) p.logits_host[row] = v; }
+                    else { XPK(logits)[row] = v; if (XPK(logits_host)) XPK(logits_host)[row] = v; }
                     best_val = v; best_idx = row;
                 }
             }
@@ -935,22 +935,22 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 // the workgroup's 256 logits as ONE kilobyte of 16-byte stores each: the host's copy (write-through, pinned memory) and the device row; behind
                 // its own stores the completion word of this token (kernels_xpipe.hip.h, the same lines)
                 const int r = row0 + 4 * lane;
-                if (r + 3 < p.n_vocab) {
+                if (r + 3 < XPK(n_vocab)) {
                     const xp_v4f v4 = *reinterpret_cast<const xp_v4f *>(s_S + 4 * lane);
                     if (lg_host) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(lg_host + r), "v"(v4) : "memory");
                     *reinterpret_cast<xp_v4f *>(lg_dev + r) = v4;
                 } else {
-                    for (int j = r; j < p.n_vocab; j++) { if (lg_host) __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
+                    for (int j = r; j < XPK(n_vocab); j++) { if (lg_host) __hip_atomic_store(lg_host + j, s_S[j - row0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); lg_dev[j] = s_S[j - row0]; }
                 }
                 if (p.resident != 0) {
-                    if (lg_host && lane < 4 && lm_rank * 4 + lane < p.lm_blocks) {      // the block maxima behind the row (kernels_xpipe.hip.h, XpParams::logits_host)
+                    if (lg_host && lane < 4 && lm_rank * 4 + lane < XPK(lm_blocks)) {      // the block maxima behind the row (kernels_xpipe.hip.h, XpParams::logits_host)
                         float bm = s_redf[lane * NW];
 #pragma unroll
                         for (int w = 1; w < NW; w++) bm = fmaxf(bm, s_redf[lane * NW + w]);
-                        __hip_atomic_store(lg_host + xp_blockmax_offset(p.n_vocab) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(lg_host + xp_blockmax_offset(XPK(n_vocab)) + lm_rank * 4 + lane, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(p.done_host + lm_rank, p.mbox_seq0 + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (lane == 0) __hip_atomic_store(XPK(done_host) + lm_rank, XPK(mbox_seq0) + (uint32_t)tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
             if (tid < 4) {
@@ -963,12 +963,12 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                 }
                 const int blk = lm_rank * 4 + tid;
-                if (blk < p.lm_blocks) {
-                    if (RES && alt) { p.pmax_alt_val[blk] = bv; p.pmax_alt_idx[blk] = bi; }
-                    else { p.pmax_out_val[blk] = bv; p.pmax_out_idx[blk] = bi; }
+                if (blk < XPK(lm_blocks)) {
+                    if (RES && alt) { XPK(pmax_alt_val)[blk] = bv; XPK(pmax_alt_idx)[blk] = bi; }
+                    else { XPK(pmax_out_val)[blk] = bv; XPK(pmax_out_idx)[blk] = bi; }
                     if (more) {        // the sampler of the next token runs on XCD 0
-                        xp_put(p.samp + blk, epoch, __float_as_uint(bv));
-                        xp_put(p.samp + 1024 + blk, epoch, (uint32_t)bi);
+                        xp_put(XPK(samp) + blk, epoch, __float_as_uint(bv));
+                        xp_put(XPK(samp) + 1024 + blk, epoch, (uint32_t)bi);
                     }
                 }
             }
