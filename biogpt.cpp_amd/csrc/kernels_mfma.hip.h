@@ -142,12 +142,15 @@ template <int WT, int EPI, int K, int J = 1>
 __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void matmul_mfma_kernel(const MatvecParams p, const DevMatrix img) {
     using TI = TypeInfo<WT>;
     static_assert(TI::quant, "block-quantized weights");
-    static_assert(J == 1 || (J == 2 && K == 1024 && !TI::q81 && EPI == EPI_GELU_Q8), "two tiles per wave: one-phase rows, the fc1 site, the formats without a min term (the others do not fit their register budget without scratch -- and any scratch at all costs these launches their dispatch rate)");
+    static_assert(J == 1 || (J == 2 && K == 1024 && !TI::q81 && (EPI == EPI_GELU_Q8 || EPI == EPI_QKV)), "two tiles per wave: one-phase rows, the fc1 and q/k/v sites, the formats without a min term (the others do not fit their register budget without scratch -- and any scratch at all costs these launches their dispatch rate)");
+    // q/k/v walking two tiles: its epilogue inputs (two bias quads, the column's cache row) are requested BEHIND the loop -- inside it they cost the registers the second tile's
+    // parked sums took (18 - 31 spilled registers when they were requested in the last steps as in the one-tile kernel); a workgroup waits one L2 round trip for them, once
+    constexpr bool EPI_LATE = J == 2 && EPI == EPI_QKV;
     constexpr bool Q81 = TI::q81;
     using L = MfmaLds<Q81, J>;
     constexpr int KP = L::KP, NPH = K / KP, BPP = L::BPP, BPR = K / QK, CH = 4, NB = BPP / CH, NBT = NPH * NB, NBL = NB * J;
     constexpr int PITCH = L::PITCH, SWF = L::SWF;
-    constexpr int QDEPTH = (J == 2 && WT != W_Q4_0) ? 2 : 3; // A-operand batches requested ahead of their MFMAs (the walking kernels of Q5_0 / Q8_0 only fit 128 registers without scratch at depth 2)
+    constexpr int QDEPTH = (J == 2 && (WT != W_Q4_0 || EPI == EPI_QKV)) ? 2 : 3; // A-operand batches requested ahead of their MFMAs (the walking kernels only fit 128 registers without scratch at depth 2 -- all but Q4_0's fc1)
     constexpr int NW = mfma_threads(K) / 64;                 // waves of the workgroup
     static_assert(K % KP == 0 && NB == 8, "phases of 1024 elements, 8 batches of 4 blocks");
     static_assert(NBT > QDEPTH, "the prologue requests QDEPTH batches");
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
     float4 e_bias1 = make_float4(0.f, 0.f, 0.f, 0.f);                           // J = 2: the second tile's
     const int colc = min(col0 + li, p.N - 1);
     int e_npast = 0, e_seq = 0;
-    if (EPI == EPI_QKV) {
+    if (EPI == EPI_QKV && !EPI_LATE) {
         e_npast = p.seq ? p.seq[colc].n_past : p.st->n_past + colc;
         e_seq = (p.seq && p.col_mode) ? p.seq[colc].seq_id : colc;
     }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
             if (!(LAST && n + QDEPTH >= NBL)) load_a(gb + QDEPTH, qa[(n + QDEPTH) & 3]);   // (compile time: the row ends with this phase)
             if (n + 1 < NBL) lds_s(n + 1, (n + 1) & 1);
             if (n + 2 < NBL) lds_b(n + 2, sb[n & 1]);                          // batch n's operands went into its MFMAs one step ago
-            if (n == NBL - QDEPTH && LAST) {                                    // the A-operand registers of the batches past the end are free from here
+            if (n == NBL - QDEPTH && LAST && !EPI_LATE) {                       // the A-operand registers of the batches past the end are free from here
                 int t2 = wv * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(t2));   // indices recomputed from the wave's SGPR and the lane counter, not held over the loop (the pipeline fills all 128 registers; threadIdx.x itself would be one more)
                 const int orc2 = min((int)(blockIdx.x * 4 + (t2 >> 6)) * (16 * J) + ((t2 >> 2) & 12), M - (J == 2 ? 20 : 4)), colc2 = min(col0 + (t2 & 15), p.N - 1);
                 if (EPI != EPI_LOGITS) e_bias = *reinterpret_cast<const float4 *>(p.bias + orc2);
@@ -365,7 +368,11 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
             for (int j = 0; j < CH; j++) {                                      // stage 4: the sums, in block order (the one true dependence across blocks)
                 acc2[0] = acc2[0] + t[j][0]; acc2[1] = acc2[1] + t[j][1];
             }
-            if (J == 2 && n == NB - 1) { accA[0] = acc2[0]; accA[1] = acc2[1]; acc2[0] = mm_f2{0.0f, 0.0f}; acc2[1] = mm_f2{0.0f, 0.0f}; }   // the first tile's row is done: its sums wait for the epilogue
+            if (J == 2 && n == NB - 1) {      // the first tile's row is done: its sums wait for the epilogue (named like the running sums below: see there)
+                asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
+                accA[0] = acc2[0]; accA[1] = acc2[1]; acc2[0] = mm_f2{0.0f, 0.0f}; acc2[1] = mm_f2{0.0f, 0.0f};
+                asm volatile("" : "+v"(accA[0]), "+v"(accA[1]));
+            }
             // the step's arithmetic is DONE in the step: without a side effect that names the sums, instruction selection sinks all of a one-phase kernel's
             // cvt / mul / add behind its last MFMA (the sums are only used by the epilogue) and every block's integer dots and scales stay live -- spills
             asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]));
@@ -449,6 +456,13 @@ __global__ __launch_bounds__(mfma_threads(K), TypeInfo<WT>::q81 ? 3 : 4) void ma
     }
     int t3 = wv * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(t3));   // (as above)
     const int col = col0 + (t3 & 15);
+    if (EPI_LATE) {
+        const int orc3 = min((int)(blockIdx.x * 4 + (t3 >> 6)) * (16 * J) + ((t3 >> 2) & 12), M - 20), colc3 = min(col, p.N - 1);
+        e_bias = *reinterpret_cast<const float4 *>(p.bias + orc3);
+        e_bias1 = *reinterpret_cast<const float4 *>(p.bias + orc3 + 16);
+        e_npast = p.seq ? p.seq[colc3].n_past : p.st->n_past + colc3;
+        e_seq = (p.seq && p.col_mode) ? p.seq[colc3].seq_id : colc3;
+    }
 #pragma unroll
     for (int jt = 0; jt < J; jt++) {
         const int orow = (int)(blockIdx.x * 4 + (t3 >> 6)) * (16 * J) + 16 * jt + ((t3 >> 2) & 12);

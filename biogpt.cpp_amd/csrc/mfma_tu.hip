@@ -43,7 +43,11 @@ hipError_t launch_t(int op, const bgk::MatvecParams &p, const bgk::DevMatrix &im
     switch (op) {      // the chain's sites (engine.hip ChainOp)
         // fc1, the tallest site (Q4_0 / Q5_0 / Q8_0): a wave walks two row tiles when the rows allow it (32 | M) and the launch still has >= 2 workgroups per compute unit
         // (kernels_mfma.hip.h, J); BIOGPT_HIP_MFMA_WALK=0 (read once per process): the one-tile kernel (A/B)
-        case 0: return launch_one<WT, bgk::EPI_QKV, 1024>(p, img, st);
+        case 0:
+            if constexpr (!bgk::TypeInfo<WT>::q81) {
+                if (walk_ok() && p.W.M % 32 == 0 && (int64_t)(p.W.M / 128) * ((p.N + 15) / 16) >= 512) return launch_one<WT, bgk::EPI_QKV, 1024, 2>(p, img, st);
+            }
+            return launch_one<WT, bgk::EPI_QKV, 1024>(p, img, st);
         case 1: return launch_one<WT, bgk::EPI_RESID, 1024>(p, img, st);
         case 2:
             if constexpr (!bgk::TypeInfo<WT>::q81) {
