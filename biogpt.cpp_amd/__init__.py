@@ -84,6 +84,8 @@ SYMBOLS = [
     ("biogpt_hip_eval_inplace", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_float))]),
     ("biogpt_hip_resident_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_chunk_launches", C.c_int64, [_P]),
+    ("biogpt_hip_fpipe_launches", C.c_int64, [_P]),
+    ("biogpt_hip_fpipe_stamps", C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     ("biogpt_hip_generate_launches", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int]),
     ("biogpt_hip_lineage_stats", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("biogpt_hip_bench_sweep", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -438,6 +440,17 @@ class BiogptModel:
         buf = (C.c_int32 * 16)()
         n = int(lib().biogpt_hip_generate_launches(self._h, buf, 16))
         return [int(buf[i]) for i in range(max(0, min(n, 16)))]
+
+    def fpipe_launches(self):
+        """Single-token steps through the float-weight persistent launch (biogpt_hip_fpipe_launches); -1: not available to this context."""
+        return int(lib().biogpt_hip_fpipe_launches(self._h))
+
+    def fpipe_stamps(self):
+        """Stage-border times of the last float-weight persistent launch (BIOGPT_HIP_FPIPE_STAMPS=1): numpy uint64 [3 workgroups][32 layers][32], 10 ns units; None when inactive."""
+        import numpy as np
+        buf = (C.c_uint64 * 3072)()
+        n = int(lib().biogpt_hip_fpipe_stamps(self._h, buf, 3072))
+        return None if n != 3072 else np.frombuffer(buf, dtype=np.uint64).reshape(3, 32, 32).copy()
 
     def chunk_launches(self):
         """Evals of 2 .. 8 tokens that went through the column-per-XCD launch (biogpt_hip_chunk_launches)."""

@@ -37,6 +37,7 @@
 #include "kernels_sweep.hip.h"
 #include "kernels_xlong.hip.h"   // parameter blocks and layouts only: the pipelined kernels are instantiated in xpipe_tu.hip
 #include "kernels_xcols.hip.h"   // (likewise: xcols_tu.hip)
+#include "kernels_fpipe.hip.h"   // (likewise: fpipe_tu.hip)
 #include "kernels_quant.hip.h"
 #include "model_file.h"
 #include "quant_host.h"
@@ -175,7 +176,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, proc_lock, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, proc_lock, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, fpipe, fpipe_stamps;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -212,6 +213,8 @@ struct EngineOptions {
         eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
         xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays, resident launches): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
+        fpipe_stamps = get("BIOGPT_HIP_FPIPE_STAMPS", 0);   // diagnostics: the persistent launch records stage-border times of three workgroups (biogpt_hip_fpipe_stamps)
+        fpipe = get("BIOGPT_HIP_FPIPE", 1);                 // single-token steps of F32 / F16 files as ONE persistent launch for all layers (kernels_fpipe.hip.h); 0: five launches per layer
         xcols = get("BIOGPT_HIP_XCOLS", 1);                 // evals of 2 .. 8 tokens (the reference's prompt chunks) as ONE persistent launch, one column per XCD (kernels_xcols.hip.h); 0: the launch chain of kernels_fast.hip.h
         xpipe_long = get("BIOGPT_HIP_XPIPE_LONG", 1);       // contexts of 257 .. 1024 keys on the pipeline too (kernels_xlong.hip.h: attention spread over the chip)
         xpipe_multi = get("BIOGPT_HIP_XPIPE_MULTI", 1);     // biogpt_hip_generate_greedy: all tokens of a context bucket in one pipelined launch
@@ -293,6 +296,10 @@ struct biogpt_hip_ctx {
     bgk::xp_u64 *xp_gran = nullptr;
     bgk::xp_u64 *xp_hop = nullptr;         // the hand-off regions that cross XCDs (x1 and x of every layer): two 8 KB candidates each, xpipe_place_hops picks
     bgk::xp_u64 *xp_gran_l = nullptr;      // long-context variant (kernels_xlong.hip.h): scores and partial outputs of the key-range helpers
+    bgk::xp_u64 *fp_gran = nullptr; bgk::FpLayer *fp_layers = nullptr; uint32_t *fp_ctl = nullptr;   // the float-weight persistent launch (kernels_fpipe.hip.h): hand-off granules, layer table, {tag, error word}
+    int64_t fp_launches = 0;               // single-token steps enqueued (or captured) as the float-weight persistent launch (biogpt_hip_fpipe_launches)
+    int fp_force = -1;                     // while a step is being CAPTURED: 1 the float-weight persistent launch, 0 five launches per layer (the graph is filed under that choice); -1: decided live
+    int fp_state = 0;                      // 0 not prepared yet, 1 usable, -1 unavailable (shape, device, memory) or abandoned after a failed launch
     bgk::xp_u64 *xc_gran = nullptr;        // column-per-XCD chunk launches (kernels_xcols.hip.h): [8 columns][n_layer][XP_G_LAYER] granules, allocated (zeroed) at the first such eval
     int xc_lds = 0;                        // 0 not tried, 1 the kernels' LDS attribute is set, -1 it could not be set (such evals keep the launch chain)
     int state_n_past = 0, state_chunk = 0; // what the last upload_state put into the device state
@@ -852,6 +859,82 @@ bool enqueue_decode_fused(biogpt_hip_ctx *c, int t_max, int tok_src, int advance
     return true;
 }
 
+// ---- single-token steps of FLOAT weight files as ONE persistent launch for all layers (kernels_fpipe.hip.h, fpipe_tu.hip) ----
+extern "C" int bg_fpipe_launch(int wt, hipStream_t st, const void *params, size_t params_bytes);
+extern "C" int bg_fpipe_set_lds(void);
+bool fpipe_prepare(biogpt_hip_ctx *c) {
+    if (c->fp_state != 0) return c->fp_state == 1;
+    c->fp_state = -1;
+    const auto &hp = c->hp;
+    if (!c->opt.fpipe || c->opt.no_fast || hp.d_model != 1024 || hp.d_ff != 4096 || hp.n_head != 16 || hp.n_layer < 1 || c->device < 0 || c->device >= 64) return false;
+    int32_t wt = -1;
+    for (const auto &L : c->plan.layers) {
+        for (const MatSlot *m : {&L.qkv, &L.o, &L.fc1, &L.fc2}) {
+            if (m->type != T_F32 && m->type != T_F16) return false;
+            if (wt >= 0 && m->type != wt) return false;
+            wt = m->type;
+        }
+        if (L.qkv.M != 3072 || L.qkv.K != 1024 || L.o.M != 1024 || L.o.K != 1024 || L.fc1.M != 4096 || L.fc1.K != 1024 || L.fc2.M != 1024 || L.fc2.K != 4096) return false;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); c->fp_state = 0; return false; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || prop.multiProcessorCount != 256 || (size_t)prop.sharedMemPerBlockOptin < bgk::fpipe_smem_bytes()) { (void)hipGetLastError(); return false; }
+    if (!xpipe_process_lock(c)) return false;      // a persistent launch: one process per device drives them (engine_xpipe.inc)
+    const size_t P = (size_t)hp.n_positions, D = (size_t)hp.d_model;
+    std::vector<bgk::FpLayer> tab((size_t)hp.n_layer);
+    for (int l = 0; l < hp.n_layer; l++) {
+        const LayerSlots &L = c->plan.layers[(size_t)l];
+        bgk::FpLayer &y = tab[(size_t)l];
+        y.ln0_w = dev_vec(c, L.ln0_w); y.ln0_b = dev_vec(c, L.ln0_b); y.ln1_w = dev_vec(c, L.ln1_w); y.ln1_b = dev_vec(c, L.ln1_b);
+        y.bqkv = dev_vec(c, L.qkv_b); y.bo = dev_vec(c, L.o_b); y.b1 = dev_vec(c, L.fc1_b); y.b2 = dev_vec(c, L.fc2_b);
+        y.Wqkv = dev_matrix(c, L.qkv).qs; y.Wo = dev_matrix(c, L.o).qs; y.W1 = dev_matrix(c, L.fc1).qs; y.W2 = dev_matrix(c, L.fc2).qs;
+        y.kcache = c->memory_k + (size_t)l * P * D; y.vcache = c->memory_v + (size_t)l * P * D;
+    }
+    const size_t gbytes = (size_t)(1024 + 3072 + 1024 + 1024 + 4096) * 8;
+    const uint32_t ctl0[2] = {1u, 0u};
+    bool ok = hipMalloc(&c->fp_layers, tab.size() * sizeof(bgk::FpLayer)) == hipSuccess && hipMalloc(&c->fp_gran, gbytes) == hipSuccess && hipMalloc(&c->fp_ctl, 64 + 3 * 1024 * 8) == hipSuccess &&
+              hipMemcpy(c->fp_layers, tab.data(), tab.size() * sizeof(bgk::FpLayer), hipMemcpyHostToDevice) == hipSuccess && hipMemset(c->fp_gran, 0, gbytes) == hipSuccess &&
+              hipMemset(c->fp_ctl, 0, 64 + 3 * 1024 * 8) == hipSuccess && hipMemcpy(c->fp_ctl, ctl0, 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && !c->xp_err_host) { ok = hipHostMalloc(reinterpret_cast<void **>(&c->xp_err_host), 64, hipHostMallocDefault) == hipSuccess; if (ok) *c->xp_err_host = 0u; }
+    ok = ok && bg_fpipe_set_lds() == (int)hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (void *q : {(void *)c->fp_layers, (void *)c->fp_gran, (void *)c->fp_ctl}) if (q) (void)hipFree(q);
+        c->fp_layers = nullptr; c->fp_gran = nullptr; c->fp_ctl = nullptr;
+        return false;
+    }
+    c->fp_state = 1;
+    return true;
+}
+bool fpipe_usable(biogpt_hip_ctx *c, int t_max) {
+    if (t_max > bgk::FP_TMAX || !fpipe_prepare(c)) return false;
+    return pipeline_slot_take(c);
+}
+// which form of a single-token step may be captured / replayed for this context bucket: 1 a persistent launch (the XCD pipeline; float files: kernels_fpipe.hip.h) -- the
+// device's slot is then this context's until its next synchronisation --, 0 five launches per layer
+int pipeline_pl(biogpt_hip_ctx *c, int t_max) {
+    if (xpipe_usable(c, t_max)) return 1;
+    return (c->fp_state >= 0 && !fused_decode_ok(c, t_max) && fpipe_usable(c, t_max)) ? 1 : 0;
+}
+// the token of the device state, embedded into c->x by the launch in front, through all layers; the final LayerNorm + lm_head launch follows
+bool enqueue_fpipe(biogpt_hip_ctx *c) {
+    const auto &hp = c->hp;
+    bgk::FpParams fp{};
+    fp.layers = c->fp_layers; fp.n_layer = hp.n_layer;
+    fp.g_x = c->fp_gran; fp.g_qkv = fp.g_x + 1024; fp.g_att = fp.g_qkv + 3072; fp.g_x1 = fp.g_att + 1024; fp.g_h = fp.g_x1 + 1024;
+    fp.ctl = c->fp_ctl; fp.err_host = c->xp_err_host;
+    fp.st = c->state; fp.x_in = c->x; fp.x_out = c->x;
+    fp.eps = 1e-5f; fp.q_scale = 1.0f / sqrtf(64.0f); fp.P = hp.n_positions;
+    fp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
+    fp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
+    if (c->unsynced_from < 0) c->unsynced_from = c->state_n_past;
+    fp.stamps = c->opt.fpipe_stamps ? reinterpret_cast<unsigned long long *>(c->fp_ctl + 16) : nullptr;
+    c->fp_launches++;
+    HIP_TRY(false, (hipError_t)bg_fpipe_launch(c->plan.layers[0].qkv.type == T_F32 ? 0 : 1, c->stream, &fp, sizeof(fp)));
+    return true;
+}
+
 // ---- biogpt_eval with 2 .. 8 tokens (the reference's prompt chunks, main.cpp:129-137) as ONE persistent launch: one column per XCD (kernels_xcols.hip.h) ----
 extern "C" int bg_xcols_launch(int wt, int t_cap, size_t smem_bytes, hipStream_t st, const void *params, size_t params_bytes);
 extern "C" int bg_xcols_set_lds(int wt, size_t smem_bytes);
@@ -977,7 +1060,11 @@ bool enqueue_forward(biogpt_hip_ctx *c, int N, bool all_rows, int t_max, bool ba
     hipLaunchKernelGGL(bgk::embed_kernel, dim3((D + 255) / 256, N), dim3(256), 0, st,
                        dev_matrix(c, c->plan.embed_tokens), dev_matrix(c, c->plan.embed_pos), c->state,
                        sqrtf((float)D), c->x, D, batch ? (cols ? cols : c->seq) : nullptr);
-    for (int l = 0; l < hp.n_layer && !xc_streams; l++) {
+    // a single token of a float-weight file: all layers as ONE persistent launch (kernels_fpipe.hip.h) on the embedding the launch above left in c->x
+    const bool fp_one = N == 1 && !batch && !all_rows && !chain &&
+                        (c->fp_force >= 0 ? (c->fp_force == 1 && c->fp_state == 1 && t_max <= bgk::FP_TMAX) : fpipe_usable(c, t_max));
+    if (fp_one && !enqueue_fpipe(c)) return false;
+    for (int l = 0; l < hp.n_layer && !xc_streams && !fp_one; l++) {
         const LayerSlots &L = c->plan.layers[(size_t)l];
         {  // LN0 + fused q/k/v projection + bias + Q scale + KV append
             const MvShape s = mv_shape(L.qkv.type, L.qkv.M, L.qkv.K, tw, N);
@@ -1432,6 +1519,7 @@ biogpt_hip_ctx *load_impl(const char *fname, int device, int verbosity, void *ex
     HIP_TRY(nullptr, hipDeviceSynchronize());
     c->ready = true;
     xpipe_prepare(c.get());
+    (void)fpipe_prepare(c.get());      // (float files: the persistent launch of kernels_fpipe.hip.h, prepared outside any capture)
     if (verbosity > 0)
         fprintf(stderr, "biogpt_hip_load: weight arena = %.2f MB, KV cache = %.2f MB, %d tensors\n", c->plan.total / 1048576.0,
                 2.0 * hp.n_layer * hp.n_positions * hp.d_model * 4 / 1048576.0, c->n_tensors);
@@ -1455,8 +1543,10 @@ bool ensure_graph(biogpt_hip_ctx *c, int advance, int bucket, int pl) {
     // fused step (contexts up to 256 keys): the sampler of the previous token is the first kernel's prologue and the
     // lm_head kernel advances the position; otherwise embed ... lm_head + the arg-max kernel
     const int tmax = bucket_tmax(c, bucket);
+    c->fp_force = pl;
     bool ok = fused_decode_ok(c, tmax) ? enqueue_decode_fused(c, tmax, 2, advance, 0, -1, -1, 1, nullptr, nullptr, pl)
                                        : (enqueue_forward(c, 1, false, tmax) && enqueue_argmax(c, advance));
+    c->fp_force = -1;
     hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
     HIP_TRY(false, e);
@@ -1504,6 +1594,7 @@ biogpt_hip_ctx *biogpt_hip_attach(const biogpt_hip_hparams *hp, int device, void
     if (!alloc_runtime(c.get())) return nullptr;
     c->ready = true;
     xpipe_prepare(c.get());
+    (void)fpipe_prepare(c.get());      // (float files: the persistent launch of kernels_fpipe.hip.h, prepared outside any capture)
     return c.release();
 }
 
@@ -1540,6 +1631,8 @@ int biogpt_hip_refresh_options(biogpt_hip_ctx *ctx) {
     xpipe_release(ctx);
     ctx->xp_state = 0; ctx->xp_gelu_p = 0; ctx->xp_gelu_n = 0; ctx->xp_gelu_z = 0; ctx->xp_exp_n = 0;
     xpipe_prepare(ctx);
+    ctx->fp_state = 0;
+    (void)fpipe_prepare(ctx);      // (float files: outside any capture)
     return 0;
 }
 
@@ -1967,7 +2060,7 @@ static int generate_greedy_once(biogpt_hip_ctx *ctx, const int32_t *prompt, int3
     auto pl_of = [&](int b) { return pl_bucket[b]; };
     if (use_graph)  // instantiate every bucket this run will touch before the clock starts
         for (int b = graph_bucket(n_prompt + 1); b <= graph_bucket(n_prompt + n_predict - 1 > 0 ? n_prompt + n_predict - 1 : 1); b++) {
-            pl_bucket[b] = xpipe_usable(ctx, bucket_tmax(ctx, b)) ? 1 : 0;
+            pl_bucket[b] = pipeline_pl(ctx, bucket_tmax(ctx, b));
             if (!ensure_graph(ctx, 1, b, pl_bucket[b])) return -2;
         }
     if (use_graph) {   // captured five-launch steps are not replayed beside ANOTHER context's persistent launch (plain_graph_begin): such a run takes eager steps
@@ -2045,6 +2138,14 @@ int biogpt_hip_eval_inplace(biogpt_hip_ctx *ctx, const int32_t *tokens, int32_t 
     return rc;
 }
 int64_t biogpt_hip_chunk_launches(const biogpt_hip_ctx *ctx) { return ctx ? ctx->xc_launches : -1; }
+int biogpt_hip_fpipe_stamps(biogpt_hip_ctx *ctx, uint64_t *out, int n) {
+    if (!ctx || !out || n < 0 || ctx->fp_state != 1 || !ctx->opt.fpipe_stamps) return -1;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    const int m = n < 3 * 1024 ? n : 3 * 1024;
+    return hipMemcpy(out, ctx->fp_ctl + 16, (size_t)m * 8, hipMemcpyDeviceToHost) == hipSuccess ? m : -1;
+}
+int64_t biogpt_hip_fpipe_launches(const biogpt_hip_ctx *ctx) { return ctx ? (ctx->fp_state == 1 ? ctx->fp_launches : -1) : -2; }
 int biogpt_hip_generate_launches(const biogpt_hip_ctx *ctx, int32_t *tokens_out, int cap) {
     if (!ctx) return -1;
     for (int i = 0; i < ctx->gen_launches && i < cap && tokens_out; i++) tokens_out[i] = ctx->gen_launch_tokens[i];

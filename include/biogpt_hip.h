@@ -163,6 +163,13 @@ int biogpt_hip_resident_stats(const biogpt_hip_ctx *ctx, int64_t *out4);
  * XCD, its own K / V cache: no exchange between XCDs) while contexts stay within 256 keys.  Returns how many such launches this context has enqueued or captured (evals;
  * batched generation: one per captured context bucket + the first step) (-1: null context). */
 int64_t biogpt_hip_chunk_launches(const biogpt_hip_ctx *ctx);
+/* F32 / F16 files: single-token steps this context has enqueued (or captured into a replayed step) as ONE persistent launch for all layers (csrc/kernels_fpipe.hip.h);
+ * -1: that launch is not available to this context (shape, device, BIOGPT_HIP_FPIPE=0, or abandoned after a failed launch) -- five launches per layer then */
+int64_t biogpt_hip_fpipe_launches(const biogpt_hip_ctx *ctx);
+/* Diagnostics of that launch (BIOGPT_HIP_FPIPE_STAMPS=1): stage-border times (s_memrealtime, 100 MHz) of workgroups 0, 128 and 255 of the LAST launch, [3][32 layers][32]:
+ * entries 0..8 the first computing wave (A in, A out, B in, C in, C dot, D in, D out, E in, E dot), 16..21 the polling wave (inputs of A, B, C, D, E first / second half seen).
+ * Returns the number of values copied, -1 when the launch or the option is not active. */
+int biogpt_hip_fpipe_stamps(biogpt_hip_ctx *ctx, uint64_t *out, int n);
 /* the last biogpt_hip_generate_greedy call (the loop main.cpp:91-151 with --top_k 1): how many multi-token pipelined launches it took and the tokens of each (up to cap);
  * 0 when every token was a launch / graph replay of its own.  Measurement aid: per-launch durations of a kernel trace divide by these. */
 int biogpt_hip_generate_launches(const biogpt_hip_ctx *ctx, int32_t *tokens_out, int cap);
