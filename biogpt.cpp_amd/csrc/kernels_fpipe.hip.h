@@ -65,7 +65,9 @@ constexpr int FP_S_S = 37632;           // [256] softmax numerators
 constexpr int FP_S_REDF = 38656;        // [16] f32
 constexpr int FP_S_REDD = 38720;        // [8] double
 constexpr int FP_S_PV = 38784;          // [4][64] double
-constexpr int FP_S_K = 40960;           // [FP_TMAX][16 pieces of 16 bytes], piece c of key k at k * 16 + (c ^ (k & 15)): a wave's lanes (one key each) read one piece index without bank conflicts
+constexpr int FP_S_BIAS = 40832;        // [2][48] f32 the layer's biases of this workgroup's rows: q/k/v 12, out_proj 4, fc1 16, fc2 4 -- written by the polling wave while the
+                                        // computing waves may still be in stage E of the layer before: two buffers, by the layer's parity
+constexpr int FP_S_K = 41216;           // [FP_TMAX][16 pieces of 16 bytes], piece c of key k at k * 16 + (c ^ (k & 15)): a wave's lanes (one key each) read one piece index without bank conflicts
 constexpr int FP_S_V = FP_S_K + FP_TMAX * 256;      // [FP_TMAX][64] f32
 constexpr int FP_S_TOTAL = FP_S_V + FP_TMAX * 256;
 __host__ __device__ inline size_t fpipe_smem_bytes() { return (size_t)FP_S_TOTAL; }
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
     float *const s_redf = reinterpret_cast<float *>(smem + FP_S_REDF);
     double *const s_redd = reinterpret_cast<double *>(smem + FP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + FP_S_PV);
+    float *const s_bias = reinterpret_cast<float *>(smem + FP_S_BIAS);
     float4 *const s_K = reinterpret_cast<float4 *>(smem + FP_S_K);
     float *const s_V = reinterpret_cast<float *>(smem + FP_S_V);
 
@@ -158,6 +161,14 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
         // ======================= the polling wave: stage inputs -> LDS (LayerNorm where the stage has one), one s_barrier per stage =======================
         bool alive = true;
         float lw0[16], lb0[16], lw1[16], lb1[16];
+        // the biases of this workgroup's 36 rows, one per lane, a layer ahead (a scalar load by the computing waves is a cold miss -- 1 us -- at its use, and cannot be asked
+        // for earlier: every LDS barrier waits for it)
+        auto bias_of = [&](const FpLayerK &Yx) __attribute__((always_inline)) -> float {
+            const int l = lane < 36 ? lane : 35;
+            const float *q = l < 12 ? Yx.bqkv + b * 12 + l : l < 16 ? Yx.bo + b * 4 + (l - 12) : l < 32 ? Yx.b1 + b * 16 + (l - 16) : Yx.b2 + b * 4 + (l - 32);
+            return *(const __attribute__((address_space(1))) float *)q;
+        };
+        float bias_next = bias_of(((const FpLayerK *)p.layers)[0]);
         {
             const FpLayerK &Y0 = ((const FpLayerK *)p.layers)[0];
 #pragma unroll
@@ -208,11 +219,13 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                 }
                 FP_STAMP(L, 0);
                 layer_norm(x, lw0, lb0, s_x0, s_xn);
+                if (lane < 36) s_bias[(L & 1) * 48 + lane] = bias_next;
                 // LayerNorm weights: this layer's second pair and the next layer's first, asked for HERE -- a cold read is 2 - 3 us under the weight stream and a wave's requests
                 // return in order: asked for in front of a sweep they delay it, behind it they stand in the CU's queue behind the weight requests
                 const FpLayerK &Yn = ((const FpLayerK *)p.layers)[L + 1 < nl ? L + 1 : L];
 #pragma unroll
                 for (int k = 0; k < 16; k++) { lw1[k] = Y.ln1_w[lane + 64 * k]; lb1[k] = Y.ln1_b[lane + 64 * k]; lw0[k] = Yn.ln0_w[lane + 64 * k]; lb0[k] = Yn.ln0_b[lane + 64 * k]; }
+                bias_next = bias_of(Yn);
                 FP_STAMP(L, 6);
             }
             FP_BARRIER();
@@ -281,7 +294,6 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
     }
 
     // ======================= waves 0 .. 3: stream and compute =======================
-    typedef const float __attribute__((address_space(4))) *fp_cf;      // biases: wave-uniform addresses in the constant address space = scalar loads (not in the vector-memory queue)
     uint4 wq[3][NI1], wo[NI1], w1[4][NI1], w2[NI4];
     auto ld = [&](fp_gptr ptr) __attribute__((always_inline)) -> uint4 {
         const fd_u4 t = __builtin_nontemporal_load((const __attribute__((address_space(1))) fd_u4 *)ptr);      // streamed once
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
         const uint32_t tag = epoch0 + (uint32_t)L;
         const FpLayerK &Y = ((const FpLayerK *)p.layers)[L];      // (constant address space: the table's pointers arrive by scalar loads)
         const bool more = L + 1 < nl;
+        const float *const s_bl = s_bias + (L & 1) * 48;
         const int Ln = more ? L + 1 : L;      // the requests are UNCONDITIONAL (the last layer asks for its own rows again, 1/24 of the traffic, nobody waits for it): behind a branch
                                               // hipcc prices every wait for the path WITHOUT the requests -- vmcnt(11) in front of stage A instead of vmcnt(43), a drained queue per stage
         // (the thread index goes through an empty asm in every iteration: without it the attention's sixteen swizzled LDS addresses per thread and a dozen more are hoisted
@@ -353,10 +366,9 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             const int rowA = b * 12 + wave * 3;
             float *kc = Y.kcache, *vc = Y.vcache;
             asm volatile("" : "+s"(kc), "+s"(vc));      // both by scalar loads: a per-lane choice of the table's FIELD is a vector load of the pointer and a vmcnt(0) behind it
-            const float bA0 = ((fp_cf)Y.bqkv)[rowA], bA1 = ((fp_cf)Y.bqkv)[rowA + 1], bA2 = ((fp_cf)Y.bqkv)[rowA + 2];
             if (lane < 3) {
                 const int row = rowA + lane;
-                float o = lane == 0 ? __fadd_rn(bA0, v[0]) : lane == 1 ? __fadd_rn(bA1, v[1]) : __fadd_rn(bA2, v[2]);
+                float o = __fadd_rn(s_bl[wave * 3 + lane], lane == 0 ? v[0] : lane == 1 ? v[1] : v[2]);
                 const int which = row >> 10, rr = row & 1023;
                 if (which == 0) o = __fmul_rn(o, p.q_scale);                 // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 else ((__attribute__((address_space(1))) float *)((which == 1) ? kc : vc))[((size_t)(rr >> 6) * p.P + n_past) * 64 + (rr & 63)] = o;      // KV append (biogpt.cpp:721-727): for later launches
@@ -404,6 +416,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             const float inv = inv_sum_f32(sum);
             {
                 double a0 = 0.0, a1 = 0.0;
+#pragma unroll 4
                 for (int j = wave; j < T; j += 8) {
                     a0 += (double)__fmul_rn(s_V[j * 64 + lane], __fmul_rn(s_S[j], inv));
                     if (j + 4 < T) a1 += (double)__fmul_rn(s_V[(j + 4) * 64 + lane], __fmul_rn(s_S[j + 4], inv));
@@ -425,9 +438,11 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             FP_STAMP(L, 4);
             if (lane == 0) {
                 const int row = b * 4 + wave;
-                xp_put(p.g_x1 + row, tag, __float_as_uint(__fadd_rn(__fadd_rn(v, ((fp_cf)Y.bo)[b * 4 + wave]), s_x0[row])));
+                xp_put(p.g_x1 + row, tag, __float_as_uint(__fadd_rn(__fadd_rn(v, s_bl[12 + wave]), s_x0[row])));
             }
-            if (attn_wg && more) req_kv(L + 1);      // the head's rows of the next layer (the LDS they land in is free once the attention stage is over)
+            // the head's rows of the next layer (the LDS they land in is free once the attention stage is over).  (At the top of fc1's stage instead -- further from this
+            // workgroup's next poll: measured 3 - 4 % slower, fc1's and fc2's stages each 0.6 - 0.9 us longer)
+            if (attn_wg && more) req_kv(L + 1);
         }
         // ================= D: fc1 + bias + GELU (biogpt.cpp:777-787) =================
         FP_BARRIER();
@@ -439,8 +454,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = fp_row_dot<WT, NI1>(w1[r], s_x1n, lane);
             const int rowD = b * 16 + wave * 4;
-            const float bD0 = ((fp_cf)Y.b1)[rowD], bD1 = ((fp_cf)Y.b1)[rowD + 1], bD2 = ((fp_cf)Y.b1)[rowD + 2], bD3 = ((fp_cf)Y.b1)[rowD + 3];
-            if (lane < 4) s_redf[wave * 4 + lane] = lane == 0 ? __fadd_rn(bD0, v[0]) : lane == 1 ? __fadd_rn(bD1, v[1]) : lane == 2 ? __fadd_rn(bD2, v[2]) : __fadd_rn(bD3, v[3]);
+            if (lane < 4) s_redf[wave * 4 + lane] = __fadd_rn(s_bl[16 + wave * 4 + lane], lane == 0 ? v[0] : lane == 1 ? v[1] : lane == 2 ? v[2] : v[3]);
             FP_STAMP(L, 6);
         }
         FP_BARRIER();      // bias + dot of the sixteen rows -> the polling wave (GELU look-up, publication)
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             FP_STAMP(L, 8);
             if (lane == 0) {
                 const int row = b * 4 + wave;
-                const float o = __fadd_rn(__fadd_rn(v, ((fp_cf)Y.b2)[b * 4 + wave]), s_x1[row]);
+                const float o = __fadd_rn(__fadd_rn(v, s_bl[32 + wave]), s_x1[row]);
                 if (more) xp_put(p.g_x + row, tag, __float_as_uint(o));
                 else p.x_out[row] = o;
             }
