@@ -92,3 +92,35 @@ def test_float_generation_in_the_device_loop(pkg, oracle, files, name):
     assert list(ids2) == list(ref)
     assert g.fpipe_launches() != 0
     g.close()
+
+
+def test_full_model_f32_24_layers(pkg, oracle, tmp_path_factory, monkeypatch):
+    """configs[0]'s file format at BioGPT-base size (24 layers, 1.4 GB of F32 weights, README.md:24,45 / main.cpp:160): teacher-forced single-token steps around 100 and 200 keys
+    through the persistent launch == the five-launch layer bit for bit, the oracle within the contract, the same argmax."""
+    d = tmp_path_factory.mktemp("fpipe24")
+    path = str(d / "f32-24.bin")
+    kw = dict(KW, n_layer=24)
+    pkg.write_synthetic(path, seed=92, **kw)
+    monkeypatch.setenv("BIOGPT_HIP_FPIPE", "0")
+    ref = pkg.BiogptModel.load(path)
+    monkeypatch.delenv("BIOGPT_HIP_FPIPE")
+    g = pkg.BiogptModel.load(path)
+    if g.fpipe_launches() < 0:
+        pytest.skip("the persistent float-weight launch is not available on this device")
+    o = oracle.OracleModel(path, n_threads=16)
+    rng = np.random.default_rng(11)
+    ctx = [2] + [int(v) for v in rng.integers(4, KW["n_vocab"], 211)]
+    worst, exact, steps = 0.0, 0, 0
+    for lo_, hi_ in ((0, 96), (104, 196)):
+        for m in (g, ref, o):
+            m.eval(ctx[lo_:hi_], lo_)
+        for n_past in range(hi_, hi_ + 8):
+            lg, lr, lo = g.eval([ctx[n_past]], n_past), ref.eval([ctx[n_past]], n_past), o.eval([ctx[n_past]], n_past)
+            assert (lg == lr).all(), "n_past %d: persistent launch != five-launch layer (max diff %g)" % (n_past, np.abs(lg - lr).max())
+            worst = max(worst, float(np.abs(lg - lo).max()))
+            exact += int((lg == lo).all())
+            steps += 1
+            assert int(lg.argmax()) == int(lo.argmax())
+    print("F32 x 24 layers: %d steps, worst |diff| vs oracle %.2e, %d bit-identical" % (steps, worst, exact))
+    assert worst <= ATOL and g.fpipe_launches() == 16
+    g.close(); ref.close()

@@ -126,7 +126,8 @@ def test_pass_kernels_use_no_scratch(pkg, tmp_path):
         pytest.skip("no clang-offload-bundler / objcopy in this image")
     pkg.build()
     seen = 0
-    for obj, pat in (("mfma_tu.o", r"matmul_mfma_kernel"), ("engine.o", r"attn_tile_kernel|lnq_kernel")):
+    # (the float-weight persistent launch, kernels_fpipe.hip.h: a scratch reload in a computing wave stands in its vector-memory queue behind a layer of weight requests)
+    for obj, pat in (("mfma_tu.o", r"matmul_mfma_kernel"), ("engine.o", r"attn_tile_kernel|lnq_kernel"), ("fpipe_tu.o", r"fpipe_kernel")):
         path = os.path.join(ROOT, "biogpt.cpp_amd", "csrc", "obj", obj)
         assert os.path.exists(path), path
         fat, co = str(tmp_path / (obj + ".fatbin")), str(tmp_path / (obj + ".co"))
@@ -142,4 +143,4 @@ def test_pass_kernels_use_no_scratch(pkg, tmp_path):
             if m and name and re.search(pat, name):
                 assert int(m.group(1)) == 0, "%s uses %s bytes of scratch per lane" % (name, m.group(1))
                 seen += 1
-    assert seen >= 28
+    assert seen >= 32
