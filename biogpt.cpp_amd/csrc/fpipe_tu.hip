@@ -15,11 +15,11 @@ extern "C" int bg_fpipe_launch(int wt, hipStream_t st, const void *params, size_
     const size_t sm = bgk::fpipe_smem_bytes();
     if (wt != bgk::W_F32 && wt != bgk::W_F16) return (int)hipErrorInvalidValue;
     if (fp.stamps) {
-        if (wt == bgk::W_F32) hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F32, true>), dim3(256), dim3(320), sm, st, fp);
-        else hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F16, true>), dim3(256), dim3(320), sm, st, fp);
+        if (wt == bgk::W_F32) hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F32, true>), dim3(256), dim3(384), sm, st, fp);
+        else hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F16, true>), dim3(256), dim3(384), sm, st, fp);
     } else {
-        if (wt == bgk::W_F32) hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F32, false>), dim3(256), dim3(320), sm, st, fp);
-        else hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F16, false>), dim3(256), dim3(320), sm, st, fp);
+        if (wt == bgk::W_F32) hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F32, false>), dim3(256), dim3(384), sm, st, fp);
+        else hipLaunchKernelGGL((bgk::fpipe_kernel<bgk::W_F16, false>), dim3(256), dim3(384), sm, st, fp);
     }
     return (int)hipGetLastError();
 }

@@ -5,7 +5,7 @@
 // 27.5 % of the HBM peak: 120 launches per token of 4 - 16 MB each are launch boundaries, not streams (5.4 us per launch for 0.5 - 2 us of bytes).  The register-stationary
 // XCD pipeline of kernels_xpipe.hip.h does not carry over (a layer is 50 MB, not 7), but its hand-offs do: tagged 8-byte {value, tag} granules, no flags, no fences.
 //
-// Shape: 256 workgroups (one per compute unit) x 5 waves.  Workgroup b owns 1/256 of the rows of EVERY matrix (q/k/v 12, out_proj 4, fc1 16, fc2 4 rows; a wave a quarter of
+// Shape: 256 workgroups (one per compute unit) x 6 waves (4 computing, 2 polling).  Workgroup b owns 1/256 of the rows of EVERY matrix (q/k/v 12, out_proj 4, fc1 16, fc2 4 rows; a wave a quarter of
 // them) and keeps the layer's whole share -- 196 KB of F32 -- in registers: each matrix's rows are re-requested for the NEXT layer right behind their use, so the weight
 // stream of layer l + 1 runs under the dependent stages of layer l and the launch is one continuous stream.  Stages per layer, each consuming the previous one's output of ALL
 // workgroups: A LayerNorm + q/k/v rows (+ KV append), B attention (workgroups 0 .. 15: one head each, its old K / V rows brought into LDS by DMA a layer ahead),
@@ -49,10 +49,12 @@ struct FpParams {
     float eps, q_scale;
     int32_t P;
     const uint16_t *exp_tab, *gelu_tab;
+    int32_t lead;                                  // s_sleep units (64 clocks) between "this workgroup's rows of the stage are published" and the first sweep for everybody's
     unsigned long long *stamps;                    // diagnostics (BIOGPT_HIP_FPIPE_STAMPS=1; nullptr otherwise): s_memrealtime (100 MHz) of three workgroups at every stage border, [3][32 layers][32]
 };
 
 constexpr int FP_TMAX = 224;
+
 // LDS (bytes)
 constexpr int FP_S_X0 = 0;              // [1024] f32 the layer's input (residual of out_proj)
 constexpr int FP_S_XN = 4096;           // [1024] LayerNorm 0 of it (F16 files: rounded through fp16, as ggml converts the activation row)
@@ -80,12 +82,14 @@ __device__ __forceinline__ void fp_fail(const FpParams &p, uint32_t code) {
     __hip_atomic_store(p.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // every lane polls its N granules (stride S) until all of them carry `tag`; wave-uniform exit, bounded; false: the launch is failing (time-out here or the error word set elsewhere)
+__device__ __forceinline__ void fp_lead(int n) { for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1); }
+
 template <int N, int S, int SAMPLE = N - 1>      // SAMPLE: the granule (index, in units of S) polled first; -1: none (a second sweep behind one that had it)
-__device__ __forceinline__ bool fp_sweep(const xp_u64 *g, uint32_t tag, float (&v)[N], const FpParams &p) {
+__device__ __forceinline__ bool fp_sweep(const xp_u64 *gb, uint32_t i0, uint32_t tag, float (&v)[N], const FpParams &p) {      // granules gb[i0 + k S]: uniform base + 32-bit index = one offset register per 4 KB of span
     // first ONE granule per lane (a single 512-byte request) with a pause between passes, the full sweep only once that sample carries the tag: 256 polling waves sweeping
     // 8 - 32 KB each, pass after pass, are megabytes per microsecond on the memory side -- next to the weight stream, and in front of this CU's own requests
     for (uint32_t spins = 0; SAMPLE >= 0; spins++) {
-        const xp_u64 a = __hip_atomic_load(g + SAMPLE * S, XP_RLX);
+        const xp_u64 a = __hip_atomic_load(gb + (i0 + (uint32_t)(SAMPLE * S)), XP_RLX);
         if (__all((uint32_t)(a >> 32) == tag)) break;
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) fp_fail(p, 1u); return false; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return false;
@@ -95,7 +99,7 @@ __device__ __forceinline__ bool fp_sweep(const xp_u64 *g, uint32_t tag, float (&
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+            const xp_u64 a = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
             v[k] = __uint_as_float((uint32_t)a);
             ok &= (uint32_t)(a >> 32) == tag;
         }
@@ -103,6 +107,43 @@ __device__ __forceinline__ bool fp_sweep(const xp_u64 *g, uint32_t tag, float (&
         if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) fp_fail(p, 1u); return false; }
         if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) return false;
     }
+}
+
+// The same with TWO passes in flight, for a hand-over whose moment is known: the caller starts it when its own workgroup's rows of the stage are published (the other 255
+// are within a fraction of a microsecond).  A pass that finds everything returns half a round trip after the data became visible; "one granule first, then the sweep" costs a
+// round trip and a half from there (measured: 1.8 - 2.7 us per hand-over, of 19 per layer).  A pass is 8 KB per workgroup, so this form must not run while nothing can arrive.
+template <int N, int S>
+__device__ __forceinline__ bool fp_sweep_piped(const xp_u64 *gb, uint32_t i0, uint32_t tag, float (&v)[N], const FpParams &p) {
+    xp_u64 ra[N], rb[N];
+    bool from_b = false, good = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) ra[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
+    for (uint32_t spins = 0;; spins++) {      // (ONE way out and the values taken behind it: two exits with their own copies cost a hundred spilled registers at N = 32)
+        __builtin_amdgcn_s_sleep(5);
+#pragma unroll
+        for (int k = 0; k < N; k++) rb[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) ok &= (uint32_t)(ra[k] >> 32) == tag;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(5);
+#pragma unroll
+        for (int k = 0; k < N; k++) ra[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) ok &= (uint32_t)(rb[k] >> 32) == tag;
+        if (__all(ok)) { from_b = true; break; }
+        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) fp_fail(p, 1u); good = false; break; }
+        if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) { good = false; break; }
+    }
+    if (from_b) {      // (a branch, not a select: the other pass is still on its way and nobody waits for it)
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = __uint_as_float((uint32_t)rb[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = __uint_as_float((uint32_t)ra[k]);
+    }
+    return good;
 }
 
 // a row of K elements (this lane's chunks in w) against the activation column in LDS: f32 products, double sums, one wave reduction (fdec_kernel's arithmetic)
@@ -124,7 +165,7 @@ __device__ __forceinline__ float fp_row_dot(const uint4 (&w)[NI], const float *s
 }
 
 template <int WT, bool ST>      // ST: the diagnostics build (stage-border stamps)
-__global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
+__global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
     static_assert(WT == W_F32 || WT == W_F16, "float weights");
     constexpr int EPC = (WT == W_F32) ? 4 : 8;
     constexpr int NI1 = 1024 / (64 * EPC), NI4 = 4096 / (64 * EPC);      // 16-byte chunks per lane of a 1024- / 4096-element row
@@ -143,6 +184,13 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
     double *const s_redd = reinterpret_cast<double *>(smem + FP_S_REDD);
     double *const s_pv = reinterpret_cast<double *>(smem + FP_S_PV);
     float *const s_bias = reinterpret_cast<float *>(smem + FP_S_BIAS);
+    // "this workgroup's rows of stage s of layer L are published" (1 + 4 L + s; s = 0 q/k/v, 1 out_proj, 3 fc2), written by computing wave 0: the polling wave starts its
+    // two-deep sweep for the stage's output of ALL workgroups from there (fp_sweep_piped)
+    // (LDS address space spelled out: through a generic pointer the flag is a FLAT access, and behind a flat access hipcc makes every wait of the wave a vmcnt(0))
+    volatile __attribute__((address_space(3))) uint32_t *const s_flag = (volatile __attribute__((address_space(3))) uint32_t *)((__attribute__((address_space(3))) unsigned char *)smem + (FP_S_REDD + 32));
+    auto own_rows_out = [&](uint32_t want) __attribute__((always_inline)) {
+        for (uint32_t n = 0; n < (1u << 22) && *s_flag < want; n++) __builtin_amdgcn_s_sleep(1);
+    };
     float4 *const s_K = reinterpret_cast<float4 *>(smem + FP_S_K);
     float *const s_V = reinterpret_cast<float *>(smem + FP_S_V);
 
@@ -154,13 +202,18 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
     const bool attn_wg = b < 16;
     const int nl = p.n_layer;
     unsigned long long *stp = nullptr;
-    if (ST && p.stamps && (b == 0 || b == 128 || b == 255) && (wave == 0 || wave == 4)) stp = p.stamps + (b == 0 ? 0 : b == 128 ? 1 : 2) * 1024 + (wave == 4 ? 16 : 0);
+    if (ST && p.stamps && (b == 0 || b == 128 || b == 255) && (wave == 0 || wave >= 4)) stp = p.stamps + (b == 0 ? 0 : b == 128 ? 1 : 2) * 1024 + (wave >= 4 ? 16 : 0);
 #define FP_STAMP(L_, i_) do { if (ST && stp && (L_) < 32) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) stp[(L_) * 32 + (i_)] = t_; } } while (0)
 
-    if (wave == 4) {
-        // ======================= the polling wave: stage inputs -> LDS (LayerNorm where the stage has one), one s_barrier per stage =======================
+    if (wave >= 4) {
+        // ======================= the two polling waves: stage inputs -> LDS (LayerNorm where the stage has one); every wave of the workgroup meets at the same barriers =======================
+        // wave 4: the layer's input + LayerNorm 0 + the biases, the attention's inputs and table look-ups, the attention output, GELU + publication of fc1's rows, the first half of
+        // GELU(fc1); wave 5: out_proj's output + LayerNorm 1, the second half of GELU(fc1).  (One wave for all of it holds 64 registers of LayerNorm weights a stage ahead and
+        // cannot keep two passes over 32 granules per lane in flight beside them.)
+        const bool w5 = wave == 5;
         bool alive = true;
-        float lw0[16], lb0[16], lw1[16], lb1[16];
+        if (!w5 && lane == 0) *s_flag = 0u;
+        float lw[16], lb[16];      // wave 4: LayerNorm 0 of the coming layer; wave 5: LayerNorm 1 of this layer
         // the biases of this workgroup's 36 rows, one per lane, a layer ahead (a scalar load by the computing waves is a cold miss -- 1 us -- at its use, and cannot be asked
         // for earlier: every LDS barrier waits for it)
         auto bias_of = [&](const FpLayerK &Yx) __attribute__((always_inline)) -> float {
@@ -168,11 +221,15 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             const float *q = l < 12 ? Yx.bqkv + b * 12 + l : l < 16 ? Yx.bo + b * 4 + (l - 12) : l < 32 ? Yx.b1 + b * 16 + (l - 16) : Yx.b2 + b * 4 + (l - 32);
             return *(const __attribute__((address_space(1))) float *)q;
         };
-        float bias_next = bias_of(((const FpLayerK *)p.layers)[0]);
-        {
+        float bias_next = 0.0f;
+        if (!w5) {
             const FpLayerK &Y0 = ((const FpLayerK *)p.layers)[0];
+            bias_next = bias_of(Y0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) { lw0[k] = Y0.ln0_w[lane + 64 * k]; lb0[k] = Y0.ln0_b[lane + 64 * k]; lw1[k] = 0.0f; lb1[k] = 0.0f; }
+            for (int k = 0; k < 16; k++) { lw[k] = Y0.ln0_w[lane + 64 * k]; lb[k] = Y0.ln0_b[lane + 64 * k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { lw[k] = 0.0f; lb[k] = 0.0f; }
         }
         for (int L = 0; L < nl; L++) {
             const uint32_t tag = epoch0 + (uint32_t)L;
@@ -180,8 +237,8 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             int tidp = threadIdx.x;
             asm volatile("" : "+v"(tidp));      // (per layer, as in the computing waves' loop: hoisted granule addresses are spilled at the kernel's 256 registers)
             const int lane = tidp & 63;
-            // the column in this wave: element lane + 64 k, k = 0 .. 15 -- ALL of a stage's granules of a lane are requested in one poll pass (a pass is a round trip to the memory side)
-            auto layer_norm = [&](const float (&x)[16], const float (&lw)[16], const float (&lb)[16], float *raw, float *out) __attribute__((always_inline)) {
+            // the column in a wave: element lane + 64 k, k = 0 .. 15 -- ALL of a stage's granules of a lane are requested in one poll pass (a pass is a round trip to the memory side)
+            auto layer_norm = [&](const float (&x)[16], float *raw, float *out) __attribute__((always_inline)) {
                 double s1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 16; k += 4) s1 += ((double)x[k] + (double)x[k + 1]) + ((double)x[k + 2] + (double)x[k + 3]);
@@ -206,8 +263,8 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                     out[lane + 64 * k] = y;
                 }
             };
-            // ---- A: the layer's input, LayerNorm 0 ----
-            {
+            // ---- A: the layer's input, LayerNorm 0 (wave 4) ----
+            if (!w5) {
                 float x[16];
                 if (L == 0) {
 #pragma unroll
@@ -215,31 +272,38 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                 } else {
 #pragma unroll
                     for (int k = 0; k < 16; k++) x[k] = 0.0f;
-                    if (alive) alive = fp_sweep<16, 64>(p.g_x + lane, tag - 1u, x, p);
+                    own_rows_out(1u + 4u * (uint32_t)(L - 1) + 3u);
+                    fp_lead(p.lead);
+                    if (alive) alive = fp_sweep<16, 64, -1>(p.g_x, (uint32_t)lane, tag - 1u, x, p);
                 }
                 FP_STAMP(L, 0);
-                layer_norm(x, lw0, lb0, s_x0, s_xn);
+                layer_norm(x, s_x0, s_xn);
                 if (lane < 36) s_bias[(L & 1) * 48 + lane] = bias_next;
-                // LayerNorm weights: this layer's second pair and the next layer's first, asked for HERE -- a cold read is 2 - 3 us under the weight stream and a wave's requests
-                // return in order: asked for in front of a sweep they delay it, behind it they stand in the CU's queue behind the weight requests
+                // LayerNorm weights and biases of the NEXT layer, asked for HERE -- a cold read is 2 - 3 us under the weight stream and a wave's requests return in order: asked for
+                // in front of a sweep they delay it, behind it they stand in the CU's queue behind the weight requests
                 const FpLayerK &Yn = ((const FpLayerK *)p.layers)[L + 1 < nl ? L + 1 : L];
 #pragma unroll
-                for (int k = 0; k < 16; k++) { lw1[k] = Y.ln1_w[lane + 64 * k]; lb1[k] = Y.ln1_b[lane + 64 * k]; lw0[k] = Yn.ln0_w[lane + 64 * k]; lb0[k] = Yn.ln0_b[lane + 64 * k]; }
+                for (int k = 0; k < 16; k++) { lw[k] = Yn.ln0_w[lane + 64 * k]; lb[k] = Yn.ln0_b[lane + 64 * k]; }
                 bias_next = bias_of(Yn);
                 FP_STAMP(L, 6);
+            } else {      // wave 5: this layer's LayerNorm 1 weights (used two stages on)
+#pragma unroll
+                for (int k = 0; k < 16; k++) { lw[k] = Y.ln1_w[lane + 64 * k]; lb[k] = Y.ln1_b[lane + 64 * k]; }
             }
             FP_BARRIER();
-            // ---- B: the head's q row and the token's new k / v rows (attention workgroups) ----
-            if (attn_wg) {
+            // ---- B: the head's q row and the token's new k / v rows (attention workgroups, wave 4) ----
+            if (attn_wg && !w5) {
                 float v[3] = {0.f, 0.f, 0.f};
-                if (alive) alive = fp_sweep<3, 1024>(p.g_qkv + b * 64 + lane, tag, v, p);
+                own_rows_out(1u + 4u * (uint32_t)L);
+                fp_lead(p.lead);
+                if (alive) alive = fp_sweep<3, 1024, -1>(p.g_qkv, (uint32_t)(b * 64 + lane), tag, v, p);
                 s_q[lane] = v[0]; s_q[64 + lane] = v[1]; s_q[128 + lane] = v[2];
                 FP_STAMP(L, 1);
             }
             FP_BARRIER();
-            if (attn_wg) {      // the attention's own seven barriers; between the fourth and the fifth this wave looks the softmax numerators up (ggml_soft_max: fp16 exp table)
+            if (attn_wg) {      // the attention's own seven barriers; between the fourth and the fifth wave 4 looks the softmax numerators up (ggml_soft_max: fp16 exp table)
                 FP_BARRIER(); FP_BARRIER(); FP_BARRIER(); FP_BARRIER();
-                {
+                if (!w5) {
                     float e[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) { const int key = lane + 64 * k; e[k] = key < T ? h2f(p.exp_tab[f2h(s_S[key])]) : 0.0f; }
@@ -248,45 +312,48 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                 }
                 FP_BARRIER(); FP_BARRIER(); FP_BARRIER();
             }
-            // ---- C: the attention output of all heads ----
-            {
+            // ---- C: the attention output of all heads (wave 4) ----
+            if (!w5) {
                 float v[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) v[k] = 0.0f;
-                if (alive) alive = fp_sweep<16, 64>(p.g_att + lane, tag, v, p);
+                if (alive) alive = fp_sweep<16, 64>(p.g_att, (uint32_t)lane, tag, v, p);
                 FP_STAMP(L, 2);
 #pragma unroll
                 for (int k = 0; k < 16; k++) s_att[lane + 64 * k] = H16 ? h2f(f2h(v[k])) : v[k];
             }
             FP_BARRIER();
-            // ---- D: out_proj's output, LayerNorm 1 ----
-            {
+            // ---- D: out_proj's output, LayerNorm 1 (wave 5) ----
+            if (w5) {
                 float x[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) x[k] = 0.0f;
-                if (alive) alive = fp_sweep<16, 64>(p.g_x1 + lane, tag, x, p);
+                own_rows_out(1u + 4u * (uint32_t)L + 1u);
+                fp_lead(p.lead);
+                if (alive) alive = fp_sweep<16, 64, -1>(p.g_x1, (uint32_t)lane, tag, x, p);
                 FP_STAMP(L, 3);
-                layer_norm(x, lw1, lb1, s_x1, s_x1n);
+                layer_norm(x, s_x1, s_x1n);
                 FP_STAMP(L, 7);
             }
             FP_BARRIER();
-            // fc1's sixteen rows of this workgroup (bias + dot, handed over in LDS): ggml_gelu's fp16 table look-up and the publication are THIS wave's -- a look-up by a computing
+            // fc1's sixteen rows of this workgroup (bias + dot, handed over in LDS): ggml_gelu's fp16 table look-up and the publication are wave 4's -- a look-up by a computing
             // wave would come back behind its weight requests; on the consumers' side it was 2 x 32 look-ups per lane, two table latencies per layer instead of one
             FP_BARRIER();
-            if (lane < 16) xp_put(p.g_h + b * 16 + lane, tag, __float_as_uint(h2f(p.gelu_tab[f2h(s_redf[lane])])));
-            FP_STAMP(L, 5);
-            // ---- E: GELU(fc1), 4096 values: 64 granules per lane (one sample poll, then two sweeps of 32: 64 addresses + 64 granules do not fit the registers) ----
+            if (!w5) {
+                if (lane < 16) xp_put(p.g_h + b * 16 + lane, tag, __float_as_uint(h2f(p.gelu_tab[f2h(s_redf[lane])])));
+                FP_STAMP(L, 5);
+            }
+            // ---- E: GELU(fc1), 4096 values = 64 granules per lane: wave 4 the first half, wave 5 the second (no sample granule: the workgroup's own sixteen are being published) ----
             {
-                float v[64];
+                float v[32];
 #pragma unroll
-                for (int k = 0; k < 64; k++) v[k] = 0.0f;
-                float (&va)[32] = *reinterpret_cast<float (*)[32]>(&v[0]);
-                float (&vb)[32] = *reinterpret_cast<float (*)[32]>(&v[32]);
-                if (alive) alive = fp_sweep<32, 64, 63>(p.g_h + lane, tag, va, p);
-                if (alive) alive = fp_sweep<32, 64, -1>(p.g_h + 2048 + lane, tag, vb, p);
-                FP_STAMP(L, 4);
+                for (int k = 0; k < 32; k++) v[k] = 0.0f;
+                const uint32_t h0 = w5 ? 2048u : 0u;
+                fp_lead(p.lead);
+                if (alive) alive = fp_sweep<32, 64, -1>(p.g_h, h0 + (uint32_t)lane, tag, v, p);
 #pragma unroll
-                for (int k = 0; k < 64; k++) s_h[lane + 64 * k] = v[k];
+                for (int k = 0; k < 32; k++) s_h[h0 + lane + 64 * k] = v[k];
+                FP_STAMP(L, w5 ? 8 : 4);
             }
             FP_BARRIER();
         }
@@ -374,6 +441,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                 else ((__attribute__((address_space(1))) float *)((which == 1) ? kc : vc))[((size_t)(rr >> 6) * p.P + n_past) * 64 + (rr & 63)] = o;      // KV append (biogpt.cpp:721-727): for later launches
                 xp_put(p.g_qkv + row, tag, __float_as_uint(o));
             }
+            if (wave == 0 && lane == 0) *s_flag = 1u + 4u * (uint32_t)L;
             FP_STAMP(L, 1);
         }
         // ================= B: attention of head b (biogpt.cpp:729-764) =================
@@ -439,6 +507,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
             if (lane == 0) {
                 const int row = b * 4 + wave;
                 xp_put(p.g_x1 + row, tag, __float_as_uint(__fadd_rn(__fadd_rn(v, s_bl[12 + wave]), s_x0[row])));
+                if (wave == 0) *s_flag = 1u + 4u * (uint32_t)L + 1u;
             }
             // the head's rows of the next layer (the LDS they land in is free once the attention stage is over).  (At the top of fc1's stage instead -- further from this
             // workgroup's next poll: measured 3 - 4 % slower, fc1's and fc2's stages each 0.6 - 0.9 us longer)
@@ -471,6 +540,7 @@ __global__ __launch_bounds__(320) void fpipe_kernel(const FpParams p) {
                 const float o = __fadd_rn(__fadd_rn(v, s_bl[32 + wave]), s_x1[row]);
                 if (more) xp_put(p.g_x + row, tag, __float_as_uint(o));
                 else p.x_out[row] = o;
+                if (wave == 0) *s_flag = 1u + 4u * (uint32_t)L + 3u;
             }
         }
     }

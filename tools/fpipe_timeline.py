@@ -23,13 +23,13 @@ assert st is not None, "stamps inactive"
 st = st.astype(np.int64)
 t0 = st[0, 0, 0]
 names = ["A.in", "A.out", "B.in", "C.in", "C.dot", "D.in", "D.out", "E.in", "E.dot", "rq.wo", "rq.qkv", "rq.w1", "rq.w2", "at.kv", "at.exp", "at.pv"]
-pn = ["pA", "pB", "pC", "pD", "pE", "geluD", "lnA", "lnD"]
+pn = ["pA", "pB", "pC", "pD", "pE0", "geluD", "lnA", "lnD", "pE1"]
 for w, wg in enumerate((0, 128, 255)):
     print("workgroup %d (us from launch start of wg 0)" % wg)
     print("  L  " + " ".join("%7s" % n for n in names) + " | " + " ".join("%7s" % n for n in pn))
     for L in (0, 1, 2, 3, 10, 11, 22, 23):
         r = st[w, L]
-        print(" %2d  " % L + " ".join("%7.2f" % ((r[i] - t0) / 100.0) for i in range(16)) + " | " + " ".join("%7.2f" % ((r[16 + i] - t0) / 100.0) if r[16 + i] else "      -" for i in range(8)))
+        print(" %2d  " % L + " ".join("%7.2f" % ((r[i] - t0) / 100.0) for i in range(16)) + " | " + " ".join("%7.2f" % ((r[16 + i] - t0) / 100.0) if r[16 + i] else "      -" for i in range(9)))
     d = (st[w, 1:24, 0] - st[w, 0:23, 0]) / 100.0
     print("  layer period: mean %.2f us, min %.2f, max %.2f; total %.1f us" % (d.mean(), d.min(), d.max(), (st[w, 23, 8] - st[w, 0, 0]) / 100.0))
     seg = np.zeros(9)
