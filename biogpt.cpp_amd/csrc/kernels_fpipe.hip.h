@@ -5,19 +5,30 @@
 // 27.5 % of the HBM peak: 120 launches per token of 4 - 16 MB each are launch boundaries, not streams (5.4 us per launch for 0.5 - 2 us of bytes).  The register-stationary
 // XCD pipeline of kernels_xpipe.hip.h does not carry over (a layer is 50 MB, not 7), but its hand-offs do: tagged 8-byte {value, tag} granules, no flags, no fences.
 //
-// Shape: 256 workgroups (one per compute unit) x 6 waves (4 computing, 2 polling).  Workgroup b owns 1/256 of the rows of EVERY matrix (q/k/v 12, out_proj 4, fc1 16, fc2 4 rows; a wave a quarter of
-// them) and keeps the layer's whole share -- 196 KB of F32 -- in registers: each matrix's rows are re-requested for the NEXT layer right behind their use, so the weight
-// stream of layer l + 1 runs under the dependent stages of layer l and the launch is one continuous stream.  Stages per layer, each consuming the previous one's output of ALL
-// workgroups: A LayerNorm + q/k/v rows (+ KV append), B attention (workgroups 0 .. 15: one head each, its old K / V rows brought into LDS by DMA a layer ahead),
-// C out_proj + residual, D LayerNorm + fc1 + GELU, E fc2 + residual.
+// Shape: 256 workgroups (one per compute unit) x 6 waves (4 computing, 2 polling).  Workgroup b owns 1/256 of the rows of EVERY matrix (q/k/v 12, out_proj 4, fc1 16, fc2 4 rows;
+// a computing wave a quarter of them) and keeps the layer's whole share -- 196 KB of F32 -- in registers: each matrix's rows are re-requested for the NEXT layer at the top of
+// the stage behind their use, so the weight stream of layer l + 1 runs under the dependent stages of layer l and the launch is one continuous stream.  Stages per layer, each
+// consuming the previous one's output of ALL workgroups: A LayerNorm + q/k/v rows (+ KV append), B attention (workgroups 0 .. 15: one head each, its old K / V rows brought
+// into LDS by DMA a layer ahead), C out_proj + residual, D LayerNorm + fc1 + GELU, E fc2 + residual.  What the stage-border timeline (BIOGPT_HIP_FPIPE_STAMPS,
+// tools/fpipe_timeline.py) showed, in the order it was found (per layer, F32 / F16: 33 / 32 us on the first build -> 19 / 16; five launches: 27 / 23):
 //   * A wave's vector-memory operations return in order: a poll issued behind a weight request waits for the weights.  So waves 0 .. 3 stream and compute and NEVER poll;
-//     wave 4 polls and never streams: it collects a stage's input granules (1024 - 4096) into LDS -- running the LayerNorm on them where the stage has one: the column is in
-//     its lanes anyway -- and meets the computing waves at ONE s_barrier per stage.
-//   * For the same reason the streaming waves issue NO other vector load: a bias read or a table look-up would be answered only when every weight request in front of it has
-//     come back, i.e. drain the stream once per stage (first build: 33 us per layer, slower than five launches).  Biases come through scalar loads (constant address
-//     space), the residuals from LDS; the two table look-ups belong to the polling wave: GELU on the CONSUMER's side (fc1 publishes bias + dot, stage E's collector looks
-//     the 4096 values up), the softmax's exp inside the attention workgroups (the computing waves hand score - max over in LDS).
+//     waves 4 and 5 poll and never stream: they collect a stage's input granules (1024 - 4096) into LDS -- running the LayerNorm on them where the stage has one: the column is
+//     in a wave's lanes anyway -- and every wave meets at ONE s_barrier per stage.
+//   * For the same reason the computing waves issue NO other vector load: a bias read or a table look-up would be answered only when every weight request in front of it has
+//     come back.  Biases, LayerNorm weights and both table look-ups (GELU: on the producer's side, sixteen values per workgroup; the softmax's exp: inside the attention
+//     workgroups, score - max handed over in LDS) are the polling waves'; the biases reach the computing waves through LDS.
+//   * ... and hipcc must be able to COUNT: weight pointers read from the layer table are generic (flat loads: every wait becomes vmcnt(0)) unless cast to the global address
+//     space; a request behind a branch, or a prologue in another order than the loop's, prices every wait for the path without it; a per-lane choice between two table fields
+//     is a vector load of a pointer + vmcnt(0).  All of these drained the stream once per stage.
+//   * Everything a polling wave reads cold (LayerNorm weights, biases) is asked for a stage or a layer ahead -- a cold read is 2 - 3 us under the weight stream; in front of a
+//     sweep it delays the sweep, behind it it stands in the CU's memory queue behind the weight requests.
+//   * 256 waves sweeping 8 - 32 KB each, pass after pass, are megabytes per microsecond next to the weight stream.  A sweep starts when the workgroup's OWN rows of the stage
+//     are published (LDS flag from computing wave 0) plus FpParams::lead x 64 clocks -- a store's way to the memory side -- and is then one pass that usually finds everything:
+//     1.2 - 1.6 us per hand-over instead of 1.8 - 2.7 for "one sample granule, a round trip, then the sweep" (kept where a workgroup has no rows of its own in the stage: the
+//     attention output).  Two passes in flight: slower (the pass left over stands in front of the next stage's sweep).
 //   * A stage's buffer is reused by the next layer with the next tag; the full dependency chain (every stage needs every workgroup's output of the one before) makes that safe.
+// What bounds it now: five all-to-all hand-overs per layer at 1.2 - 1.6 us (store to the memory side + one read round trip), 3 us of row dots (ONE wave per SIMD issues an
+// instruction every ~5 clocks), 1.8 us of LayerNorm on single waves, 3.4 us inside the attention stage -- 16 of 19 us are dependent latency, not bytes (F32: 2.6 TB/s).
 // Contexts up to FP_TMAX keys (a head's K / V rows must fit LDS beside the stage inputs); beyond, and for every other shape, the five-launch layer stays.
 #pragma once
 
@@ -109,43 +120,6 @@ __device__ __forceinline__ bool fp_sweep(const xp_u64 *gb, uint32_t i0, uint32_t
     }
 }
 
-// The same with TWO passes in flight, for a hand-over whose moment is known: the caller starts it when its own workgroup's rows of the stage are published (the other 255
-// are within a fraction of a microsecond).  A pass that finds everything returns half a round trip after the data became visible; "one granule first, then the sweep" costs a
-// round trip and a half from there (measured: 1.8 - 2.7 us per hand-over, of 19 per layer).  A pass is 8 KB per workgroup, so this form must not run while nothing can arrive.
-template <int N, int S>
-__device__ __forceinline__ bool fp_sweep_piped(const xp_u64 *gb, uint32_t i0, uint32_t tag, float (&v)[N], const FpParams &p) {
-    xp_u64 ra[N], rb[N];
-    bool from_b = false, good = true;
-#pragma unroll
-    for (int k = 0; k < N; k++) ra[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
-    for (uint32_t spins = 0;; spins++) {      // (ONE way out and the values taken behind it: two exits with their own copies cost a hundred spilled registers at N = 32)
-        __builtin_amdgcn_s_sleep(5);
-#pragma unroll
-        for (int k = 0; k < N; k++) rb[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < N; k++) ok &= (uint32_t)(ra[k] >> 32) == tag;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(5);
-#pragma unroll
-        for (int k = 0; k < N; k++) ra[k] = __hip_atomic_load(gb + (i0 + (uint32_t)(k * S)), XP_RLX);
-        ok = true;
-#pragma unroll
-        for (int k = 0; k < N; k++) ok &= (uint32_t)(rb[k] >> 32) == tag;
-        if (__all(ok)) { from_b = true; break; }
-        if (spins >= XP_SPIN_MAX) { if ((threadIdx.x & 63) == 0) fp_fail(p, 1u); good = false; break; }
-        if ((spins & 1023u) == 1023u && __hip_atomic_load(p.ctl + 1, XP_RLX) != 0u) { good = false; break; }
-    }
-    if (from_b) {      // (a branch, not a select: the other pass is still on its way and nobody waits for it)
-#pragma unroll
-        for (int k = 0; k < N; k++) v[k] = __uint_as_float((uint32_t)rb[k]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < N; k++) v[k] = __uint_as_float((uint32_t)ra[k]);
-    }
-    return good;
-}
-
 // a row of K elements (this lane's chunks in w) against the activation column in LDS: f32 products, double sums, one wave reduction (fdec_kernel's arithmetic)
 template <int WT, int NI>
 __device__ __forceinline__ float fp_row_dot(const uint4 (&w)[NI], const float *s_act, int lane) {
@@ -213,8 +187,10 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
         const bool w5 = wave == 5;
         bool alive = true;
         if (!w5 && lane == 0) *s_flag = 0u;
-        float lw[16], lb[16];      // wave 4: LayerNorm 0 of the coming layer; wave 5: LayerNorm 1 of this layer
-        // the biases of this workgroup's 36 rows, one per lane, a layer ahead (a scalar load by the computing waves is a cold miss -- 1 us -- at its use, and cannot be asked
+        // wave 5: LayerNorm weights, asked for a stage or a layer ahead in its idle stretch behind stage A's barrier -- a cold read is 2 - 3 us under the weight stream and a wave's
+        // requests return in order: in front of a sweep they delay it, behind it they stand in the CU's queue behind the weight requests
+        float lw0[16], lb0[16], lw1[16], lb1[16];
+        // wave 4: the biases of this workgroup's 36 rows, one per lane, a layer ahead (a scalar load by the computing waves is a cold miss -- 1 us -- at its use, and cannot be asked
         // for earlier: every LDS barrier waits for it)
         auto bias_of = [&](const FpLayerK &Yx) __attribute__((always_inline)) -> float {
             const int l = lane < 36 ? lane : 35;
@@ -222,14 +198,14 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
             return *(const __attribute__((address_space(1))) float *)q;
         };
         float bias_next = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { lw0[k] = 0.0f; lb0[k] = 0.0f; lw1[k] = 0.0f; lb1[k] = 0.0f; }
         if (!w5) {
-            const FpLayerK &Y0 = ((const FpLayerK *)p.layers)[0];
-            bias_next = bias_of(Y0);
-#pragma unroll
-            for (int k = 0; k < 16; k++) { lw[k] = Y0.ln0_w[lane + 64 * k]; lb[k] = Y0.ln0_b[lane + 64 * k]; }
+            bias_next = bias_of(((const FpLayerK *)p.layers)[0]);
         } else {
+            const FpLayerK &Y0 = ((const FpLayerK *)p.layers)[0];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { lw[k] = 0.0f; lb[k] = 0.0f; }
+            for (int k = 0; k < 16; k++) { lw0[k] = Y0.ln0_w[lane + 64 * k]; lb0[k] = Y0.ln0_b[lane + 64 * k]; }
         }
         for (int L = 0; L < nl; L++) {
             const uint32_t tag = epoch0 + (uint32_t)L;
@@ -238,7 +214,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
             asm volatile("" : "+v"(tidp));      // (per layer, as in the computing waves' loop: hoisted granule addresses are spilled at the kernel's 256 registers)
             const int lane = tidp & 63;
             // the column in a wave: element lane + 64 k, k = 0 .. 15 -- ALL of a stage's granules of a lane are requested in one poll pass (a pass is a round trip to the memory side)
-            auto layer_norm = [&](const float (&x)[16], float *raw, float *out) __attribute__((always_inline)) {
+            auto layer_norm = [&](const float (&x)[16], const float (&lw)[16], const float (&lb)[16], float *raw, float *out) __attribute__((always_inline)) {
                 double s1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 16; k += 4) s1 += ((double)x[k] + (double)x[k + 1]) + ((double)x[k + 2] + (double)x[k + 3]);
@@ -263,8 +239,8 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
                     out[lane + 64 * k] = y;
                 }
             };
-            // ---- A: the layer's input, LayerNorm 0 (wave 4) ----
-            if (!w5) {
+            // ---- A: the layer's input, LayerNorm 0 (wave 5); this layer's biases -> LDS (wave 4) ----
+            if (w5) {
                 float x[16];
                 if (L == 0) {
 #pragma unroll
@@ -277,20 +253,15 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
                     if (alive) alive = fp_sweep<16, 64, -1>(p.g_x, (uint32_t)lane, tag - 1u, x, p);
                 }
                 FP_STAMP(L, 0);
-                layer_norm(x, s_x0, s_xn);
-                if (lane < 36) s_bias[(L & 1) * 48 + lane] = bias_next;
-                // LayerNorm weights and biases of the NEXT layer, asked for HERE -- a cold read is 2 - 3 us under the weight stream and a wave's requests return in order: asked for
-                // in front of a sweep they delay it, behind it they stand in the CU's queue behind the weight requests
-                const FpLayerK &Yn = ((const FpLayerK *)p.layers)[L + 1 < nl ? L + 1 : L];
-#pragma unroll
-                for (int k = 0; k < 16; k++) { lw[k] = Yn.ln0_w[lane + 64 * k]; lb[k] = Yn.ln0_b[lane + 64 * k]; }
-                bias_next = bias_of(Yn);
+                layer_norm(x, lw0, lb0, s_x0, s_xn);
                 FP_STAMP(L, 6);
-            } else {      // wave 5: this layer's LayerNorm 1 weights (used two stages on)
-#pragma unroll
-                for (int k = 0; k < 16; k++) { lw[k] = Y.ln1_w[lane + 64 * k]; lb[k] = Y.ln1_b[lane + 64 * k]; }
-            }
+            } else if (lane < 36) s_bias[(L & 1) * 48 + lane] = bias_next;
             FP_BARRIER();
+            const FpLayerK &Yn = ((const FpLayerK *)p.layers)[L + 1 < nl ? L + 1 : L];
+            if (w5) {      // behind the barrier, with two idle stages in front of this wave: nothing waits for these reads
+#pragma unroll
+                for (int k = 0; k < 16; k++) { lw1[k] = Y.ln1_w[lane + 64 * k]; lb1[k] = Y.ln1_b[lane + 64 * k]; lw0[k] = Yn.ln0_w[lane + 64 * k]; lb0[k] = Yn.ln0_b[lane + 64 * k]; }
+            }
             // ---- B: the head's q row and the token's new k / v rows (attention workgroups, wave 4) ----
             if (attn_wg && !w5) {
                 float v[3] = {0.f, 0.f, 0.f};
@@ -323,6 +294,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
                 for (int k = 0; k < 16; k++) s_att[lane + 64 * k] = H16 ? h2f(f2h(v[k])) : v[k];
             }
             FP_BARRIER();
+            if (!w5) bias_next = bias_of(Yn);      // (wave 4's idle stretch: its next poll is two stages on)
             // ---- D: out_proj's output, LayerNorm 1 (wave 5) ----
             if (w5) {
                 float x[16];
@@ -332,7 +304,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
                 fp_lead(p.lead);
                 if (alive) alive = fp_sweep<16, 64, -1>(p.g_x1, (uint32_t)lane, tag, x, p);
                 FP_STAMP(L, 3);
-                layer_norm(x, s_x1, s_x1n);
+                layer_norm(x, lw1, lb1, s_x1, s_x1n);
                 FP_STAMP(L, 7);
             }
             FP_BARRIER();
