@@ -455,11 +455,22 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
             sum = (s_redd[0] + s_redd[1]) + (s_redd[2] + s_redd[3]);      // (fp16 values below 2^11: exact in any order)
             const float inv = inv_sum_f32(sum);
             {
+                // wave w: keys w, w + 4, w + 8, ... -- alternately into a0 / a1; eight keys per trip, their LDS reads in flight together (a trip per key pair with a branch in it
+                // was 1.4 us of the stage at 100 keys)
                 double a0 = 0.0, a1 = 0.0;
-#pragma unroll 4
-                for (int j = wave; j < T; j += 8) {
-                    a0 += (double)__fmul_rn(s_V[j * 64 + lane], __fmul_rn(s_S[j], inv));
-                    if (j + 4 < T) a1 += (double)__fmul_rn(s_V[(j + 4) * 64 + lane], __fmul_rn(s_S[j + 4], inv));
+                for (int j0 = wave; j0 < T; j0 += 32) {
+                    float vv[8], ss[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int j = min(j0 + 4 * i, T - 1);
+                        vv[i] = s_V[j * 64 + lane]; ss[i] = s_S[j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const double t = (double)__fmul_rn(vv[i], __fmul_rn(ss[i], inv));
+                        const bool live = j0 + 4 * i < T;
+                        if (i & 1) a1 = live ? a1 + t : a1; else a0 = live ? a0 + t : a0;
+                    }
                 }
                 s_pv[wave * 64 + lane] = a0 + a1;
             }
