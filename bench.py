@@ -658,7 +658,8 @@ def main():
         # continuations each after one warm-up; each model is its own context on this device -- the pipeline slot is handed over
         # between contexts whenever the holder has synchronised
         if args.ftype == "q4_0" and not os.environ.get("BIOGPT_BENCH_SKIP_TYPES"):
-            for other in ("q5_1", "q8_0"):
+            # ... and the F32 file of configs[0] (README.md:24,45 / main.cpp:160: 4-token prompt, 200 tokens): single-token steps as ONE persistent launch per token (csrc/kernels_fpipe.hip.h)
+            for other in ("q5_1", "q8_0", "f32"):
                 try:
                     mo = pkg.BiogptModel.load(ensure_model(pkg, args.workdir, other, args.n_layer), device=local_rank)
                     mo.generate_greedy(make_prompt(hp.n_vocab, 1), n_predict, n_batch=8)
@@ -674,6 +675,8 @@ def main():
                                               "T=1024": {"us_per_token": round(s1k * 1e6, 2), "tokens_per_s": round(1.0 / s1k, 1),
                                                          "frac_of_peak": round(b1024 / s1k / 1e9 / HBM_PEAK_GBS, 4)},
                                               "xpipe_state": mo.xpipe_state()}
+                    if other == "f32":
+                        out["decode_f32"]["persistent_launches"] = mo.fpipe_launches()
                     mo.close()
                 except Exception as e:
                     out["decode_" + other] = {"error": str(e)}

@@ -350,17 +350,17 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
 #pragma unroll
         for (int i = 0; i < NI1; i++) wo[i] = ld(base + 1024 * i);
     };
-    auto req_w1 = [&](int L) __attribute__((always_inline)) {
+    auto req_w1 = [&](int L, int r0) __attribute__((always_inline)) {      // rows r0, r0 + 1 of this wave's four
         fp_gptr base = (fp_gptr)((const FpLayerK *)p.layers)[L].W1 + (size_t)(b * 16 + wave * 4) * RB1 + lane * 16;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int i = 0; i < NI1; i++) w1[r][i] = ld(base + (size_t)r * RB1 + 1024 * i);
+            for (int i = 0; i < NI1; i++) w1[r0 + r][i] = ld(base + (size_t)(r0 + r) * RB1 + 1024 * i);
     };
-    auto req_w2 = [&](int L) __attribute__((always_inline)) {
+    auto req_w2 = [&](int L, int i0) __attribute__((always_inline)) {      // chunks i0 .. i0 + NI4 / 2 - 1 of this wave's row
         fp_gptr base = (fp_gptr)((const FpLayerK *)p.layers)[L].W2 + (size_t)(b * 4 + wave) * RB4 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < NI4; i++) w2[i] = ld(base + 1024 * i);
+        for (int i = 0; i < NI4 / 2; i++) w2[i0 + i] = ld(base + 1024 * (i0 + i));
     };
     // the head's old K / V rows -> LDS by DMA (asm: hipcc must not count it, or it drains every load in front of every ds_read).  K: 64 pieces of 16 bytes per instruction,
     // LDS piece q = 64 n + lane holds piece (q & 15) ^ (key & 15) of key q >> 4; V: natural order.  Keys past the cache slice are clamped (never used).
@@ -375,11 +375,12 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
             at_dma16(vb + (size_t)key * 256 + (c << 4), lds0 + FP_S_V + 1024 * n);
         }
     };
-    // Register budget (F32: 48 + 16 + 64 + 64 = 192 of 256): out_proj's rows are asked for one stage ahead (behind stage A), q/k/v's for the next layer only when out_proj's are
-    // used up (behind stage C): at most 176 registers of weights at any time
+    // Requests: a matrix's rows for the next layer at a stage top behind their use (the whole layer's share, 192 registers of F32, is always held or on its way), spread
+    // over the five stage tops -- F32: 8 / 20 / 8 / 4 / 8 requests of 1 KB per wave at A / B / C / D / E.  (fc1's 16 and fc2's 16 each in one piece at E and A: 46 MB for the
+    // chip within 7 us, the requests at the next top then took 1.4 - 2.2 us to ISSUE.)
     if (attn_wg) req_kv(0);
     // (in the loop's order, pinned: hipcc prices a wait for the worst path into the loop, and it interleaves unpinned requests as it likes)
-    req_qkv(0); asm volatile("" ::: "memory"); req_wo(0); asm volatile("" ::: "memory"); req_w1(0); asm volatile("" ::: "memory");
+    req_qkv(0); asm volatile("" ::: "memory"); req_wo(0); asm volatile("" ::: "memory"); req_w1(0, 0); asm volatile("" ::: "memory");
 
     for (int L = 0; L < nl; L++) {
         const uint32_t tag = epoch0 + (uint32_t)L;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
         // ================= A: q / k / v rows (biogpt.cpp:705-727) =================
         FP_BARRIER();
         FP_STAMP(L, 0);
-        req_w2(L);      // (fc2's registers were used up in the stage before)
+        req_w2(L, 0);      // (fc2's registers were used up in the stage before; the other half follows at stage C)
         FP_STAMP(L, 12);
         {
             float v[3];
@@ -420,11 +421,13 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
         FP_BARRIER();
         FP_STAMP(L, 2);
         req_qkv(Ln);
+        req_w1(L, 2);      // (the second half of THIS layer's fc1 rows: two stages ahead of their use; at stage C's top, one stage ahead: 4 % slower)
         FP_STAMP(L, 10);
         if (attn_wg) {
-            // this wave's share of the head's old rows (asked for behind out_proj's dot of the layer before) has landed: every request since -- out_proj, fc1, fc2 of this layer,
-            // q/k/v of the next: 8 NI1 + NI4 -- may still be on its way (the handful of stores in between only make the wait a little stricter)
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NI1 + NI4) : "memory");
+            // this wave's share of the head's old rows (asked for behind out_proj's dot of the layer before) has landed: every request since -- out_proj, half of fc1, half of
+            // fc2 of this layer, q/k/v of the next, the other half of fc1: 8 NI1 + NI4 / 2 -- may still be on its way (the handful of stores in between only make the wait a
+            // little stricter)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NI1 + NI4 / 2) : "memory");
             FP_BARRIER();                          // ... and everyone's
             if (tid < 16) s_K[n_past * 16 + (tid ^ (n_past & 15))] = *reinterpret_cast<const float4 *>(s_q + 64 + 4 * tid);
             else if (tid < 32) *reinterpret_cast<float4 *>(s_V + n_past * 64 + 4 * (tid - 16)) = *reinterpret_cast<const float4 *>(s_q + 128 + 4 * (tid - 16));
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
         // ================= C: out_proj + bias + residual (biogpt.cpp:767-772) =================
         FP_BARRIER();
         FP_STAMP(L, 3);
+        req_w2(L, NI4 / 2);
         {
             const float v = fp_row_dot<WT, NI1>(wo, s_att, lane);
             FP_STAMP(L, 4);
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
         // ================= E: fc2 + bias + residual (biogpt.cpp:790-795) =================
         FP_BARRIER();
         FP_STAMP(L, 7);
-        req_w1(Ln);
+        req_w1(Ln, 0);
         FP_STAMP(L, 11);
         {
             const float v = fp_row_dot<WT, NI4>(w2, s_h, lane);
