@@ -492,6 +492,20 @@ def main():
                 secs2, nbytes2 = model.bench_matvec(1, layer=0, reps=reps)
                 per = {"fc2": {"GBps": round(nbytes2 / secs2 / 1e9, 1), "us": round(secs2 * 1e6, 3), "bytes": nbytes2, "frac": round(nbytes2 / secs2 / 1e9 / HBM_PEAK_GBS, 4)}}
                 kname = "matvec_kernel<%s,LN,GELU> (fc1 %dx%d, 24 launches/token)" % (args.ftype.upper(), hp.d_ff, hp.d_model)
+                method = None
+                if model.fpipe_launches() >= 0:
+                    # float files: a single-token step up to 224 keys is ONE persistent launch for all layers (csrc/kernels_fpipe.hip.h) + the lm_head launch: that launch is
+                    # the dominant kernel; the five-launch layer's fc1 / fc2 above stay as the figures of contexts beyond 224 keys
+                    sx, bx = model.bench_matvec(13, layer=0, reps=40)
+                    per["five_launch_layer_fc1"] = {"GBps": round(nbytes / secs / 1e9, 1), "us": round(secs * 1e6, 3), "bytes": nbytes, "frac": round(nbytes / secs / 1e9 / HBM_PEAK_GBS, 4)}
+                    per["five_launch_layer_fc2"] = per.pop("fc2")
+                    secs, nbytes = sx, bx
+                    kname = ("fpipe_kernel<%s> (all %d layers of one token at 104 keys in ONE persistent launch: 256 workgroups, each holding its rows of the layer's four matrices in "
+                             "registers a layer ahead; stage outputs as tagged granules collected by two polling waves per workgroup)" % (args.ftype.upper(), hp.n_layer))
+                    method = ("HIP events on the engine stream around 40 back-to-back replays of this ONE kernel as a single-token launch (hipGraph, as the decode step is replayed), real arena weights; "
+                              "algorithmic bytes = the four matrices of every layer at file density + K / V rows of 104 keys + the new K / V rows + x in / out; the launch is bound by its "
+                              "dependent chain, not by bytes: %.1f us per layer = five all-to-all hand-overs + row dots on one wave per SIMD + two LayerNorms + the attention stage "
+                              "(profiles/fpipe_timeline_r6_*.txt)" % (sx * 1e6 / hp.n_layer))
             secs_lm, nbytes_lm = model.bench_matvec(4, layer=0, reps=50)    # lm_head
             per["lm_head"] = {"GBps": round(nbytes_lm / secs_lm / 1e9, 1), "us": round(secs_lm * 1e6, 3), "bytes": nbytes_lm, "frac": round(nbytes_lm / secs_lm / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "HIP events around 50 back-to-back launches on the ONE copy of the matrix the model owns: between launches its 24.6 MB stay in the 256 MB Infinity Cache, so "
@@ -511,7 +525,7 @@ def main():
                 # rocprofv3 is not usable here); summaries of the same passes are committed under profiles/ (pmc_*_r4.txt, pmc_attn_tile_r5.txt)
                 "traffic": None,
                 "bytes_per_launch": nbytes, "us_per_launch": round(secs * 1e6, 3),
-                "method": (method if quant and method else
+                "method": (method if method else
                            "HIP events on the engine stream around %d back-to-back launches of this ONE kernel (hipGraph replays of one sweep over the layers, as the decode step is replayed) cycling through the 24 layers' own "
                            "arena weights (no L2 reuse between launches; the 211 MB arena fits the 256 MB Infinity Cache); model shapes only -- "
                            "a launch moves %.1f MB, which 8 TB/s would move in %.2f us, against a measured ~1.3-1.6 us launch boundary" % (reps, nbytes / 1e6, nbytes / 8e6)),

@@ -237,7 +237,8 @@ int biogpt_hip_debug_stamps(biogpt_hip_ctx *ctx, size_t offset, size_t count, un
 /* Stand-alone launch of the block-quantized mat-vec kernel on a weight matrix of the loaded
  * model, for kernel-level roofline timing: which = 0 fc1 of layer `layer`, 1 fc2,
  * 2 q/k/v fused, 3 out_proj, 4 lm_head (5-11: internal, see bench.py), 12 lm_head with the weights taken from a
- * different one of 14 device copies every launch (344 MB: not resident in the Infinity Cache).  Runs `reps` back-to-back launches on the context's
+ * different one of 14 device copies every launch (344 MB: not resident in the Infinity Cache), 13 (float files) all layers of one token at 104 keys as the
+ * ONE persistent launch of kernels_fpipe.hip.h.  Runs `reps` back-to-back launches on the context's
  * stream bracketed by HIP events and returns the average seconds per launch in *seconds_out and
  * the algorithmic bytes of one launch in *bytes_out. */
 int biogpt_hip_bench_matvec(biogpt_hip_ctx *ctx, int which, int layer, int reps,
