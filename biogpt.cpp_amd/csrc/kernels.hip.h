@@ -278,13 +278,15 @@ struct Unit {
 template <int WT>
 __device__ __forceinline__ void load_unit(Unit<WT> &u, const DevMatrix &W, int64_t idx) {
     using TI = TypeInfo<WT>;
-    const uint4 *q = reinterpret_cast<const uint4 *>(W.qs + idx * TI::qbytes);
-    u.q0 = q[0];
-    if (WT == W_Q8_0) u.q1 = q[1];
+    // (weights live in device memory: GLOBAL loads spelled out -- a DevMatrix copied out of a table in memory carries generic pointers, i.e. flat loads)
+    typedef uint32_t lu_u4 __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) lu_u4 *q = (const __attribute__((address_space(1))) lu_u4 *)(W.qs + idx * TI::qbytes);
+    { const lu_u4 t = q[0]; u.q0 = make_uint4(t.x, t.y, t.z, t.w); }
+    if (WT == W_Q8_0) { const lu_u4 t = q[1]; u.q1 = make_uint4(t.x, t.y, t.z, t.w); }
     if (TI::quant) {
-        if (TI::q81) u.sc = reinterpret_cast<const uint32_t *>(W.sc)[idx];
-        else u.sc = reinterpret_cast<const uint16_t *>(W.sc)[idx];
-        if (WT == W_Q5_0 || WT == W_Q5_1) u.qh = W.qh[idx];
+        if (TI::q81) u.sc = ((const __attribute__((address_space(1))) uint32_t *)W.sc)[idx];
+        else u.sc = ((const __attribute__((address_space(1))) uint16_t *)W.sc)[idx];
+        if (WT == W_Q5_0 || WT == W_Q5_1) u.qh = ((const __attribute__((address_space(1))) uint32_t *)W.qh)[idx];
     }
 }
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ void xc_sweep(const xp_u64 *g, bool active, uint32_t 
         if (active) {
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                const xp_u64 a = __hip_atomic_load((xp_gq)g + k * S, XP_RLX);
                 v[k] = (uint32_t)a;
                 ok &= (uint32_t)(a >> 32) == epoch;
             }
@@ -152,48 +152,48 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
     float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0;      // LayerNorm weights of the NEXT layer (workers), its bias entry
     float bnext = 0.0f;
     auto request_small = [&](int L, int tid) __attribute__((always_inline)) {
-        const XpLayer &Y = p.layers[L];
+        const XpLayerK &Y = XPL(L);
         if (tid < 256) {
-            l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid];
-            l2 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l3 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid];
+            l0 = xp_ldg4(Y.ln0_w, tid); l1 = xp_ldg4(Y.ln0_b, tid);
+            l2 = xp_ldg4(Y.ln1_w, tid); l3 = xp_ldg4(Y.ln1_b, tid);
         }
-        if (tid < 192) bnext = Y.bqkv[(tid >> 6) * 1024 + head * 64 + (tid & 63)];
-        else if (tid < 224) bnext = Y.bo[slot * 32 + tid - 192];
-        else if (tid < 352) bnext = Y.b1[slot * 128 + tid - 224];
-        else if (tid < 384) bnext = Y.b2[slot * 32 + tid - 352];
+        if (tid < 192) bnext = ((xp_gf)Y.bqkv)[(tid >> 6) * 1024 + head * 64 + (tid & 63)];
+        else if (tid < 224) bnext = ((xp_gf)Y.bo)[slot * 32 + tid - 192];
+        else if (tid < 352) bnext = ((xp_gf)Y.b1)[slot * 128 + tid - 224];
+        else if (tid < 384) bnext = ((xp_gf)Y.b2)[slot * 32 + tid - 352];
     };
     auto request_qkv = [&](int L, int tid) __attribute__((always_inline)) {
         const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
 #pragma unroll
         for (int s = 0; s < QS; s++) {
             const int jj = s * 2 * NW + wave * 2 + rsub;
-            xc_load_unit<WT>(wqkv[s], p.layers[L].Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+            xc_load_unit<WT>(wqkv[s], XPL_MATRIX(XPL(L).Wqkv), (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
         }
     };
     auto request_wo = [&](int L, int tid) __attribute__((always_inline)) {
         const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
 #pragma unroll
-        for (int s = 0; s < OS; s++) xc_load_unit<WT>(wo[s], p.layers[L].Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+        for (int s = 0; s < OS; s++) xc_load_unit<WT>(wo[s], XPL_MATRIX(XPL(L).Wo), (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
     };
     auto request_w1 = [&](int L, int tid) __attribute__((always_inline)) {
         const int lane = tid & 63, wave = tid >> 6, sub = lane & 31, rsub = lane >> 5;
 #pragma unroll
-        for (int s = 0; s < FS; s++) xc_load_unit<WT>(w1[s], p.layers[L].W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+        for (int s = 0; s < FS; s++) xc_load_unit<WT>(w1[s], XPL_MATRIX(XPL(L).W1), (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
     };
     auto request_w2 = [&](int L, int tid) __attribute__((always_inline)) {
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int r = 0; r < F2R; r++)
 #pragma unroll
-            for (int it = 0; it < 2; it++) xc_load_unit<WT>(w2[r][it], p.layers[L].W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+            for (int it = 0; it < 2; it++) xc_load_unit<WT>(w2[r][it], XPL_MATRIX(XPL(L).W2), (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
     };
     // rows written by EARLIER evals (other launches); rows >= n_old are replaced from LDS before they are used.  Raw buffer loads: ONE offset register per lane for
     // the 8 + 32 loads of the 256-key variant (the per-load part sits in the scalar offset; 64-bit addresses per load cost ~ 30 VGPRs here), rows beyond the cache
     // slice read as 0 (range-checked), streaming hint (nt)
     auto request_kv = [&](int L, int tid) __attribute__((always_inline)) {
         const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
-        const float *kb = (streams ? p.kroot + kv_off + (size_t)L * p.P * 1024 : p.layers[L].kcache) + (size_t)head * p.P * DK;
-        const float *vb = (streams ? p.vroot + kv_off + (size_t)L * p.P * 1024 : p.layers[L].vcache) + (size_t)head * p.P * DK;
+        const float *kb = (streams ? p.kroot + kv_off + (size_t)L * p.P * 1024 : XPL(L).kcache) + (size_t)head * p.P * DK;
+        const float *vb = (streams ? p.vroot + kv_off + (size_t)L * p.P * 1024 : XPL(L).vcache) + (size_t)head * p.P * DK;
         const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
         constexpr int CPOL_NT = 2;
         const int ko = (kidx * DK + 4 * ksub) * 4, vo = (sl * DK + dd) * 4;
@@ -304,9 +304,11 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
                     xp_put_local(G + XP_G_QKV + head * 64 + d, epoch, __float_as_uint(v));
                 } else {
                     xp_put(G + XP_G_QKV + which * 1024 + head * 64 + d, epoch, __float_as_uint(v));      // write-through: the other columns' XCDs poll these
+                    float *kc_ = XPL(L).kcache, *vc_ = XPL(L).vcache;
+                    asm volatile("" : "+s"(kc_), "+s"(vc_));      // both by scalar loads (a per-lane choice of the table's FIELD is a vector load of the pointer)
                     float *cache = streams ? ((which == 1) ? p.kroot : p.vroot) + kv_off + (size_t)L * p.P * 1024
-                                           : ((which == 1) ? p.layers[L].kcache : p.layers[L].vcache);    // KV append (biogpt.cpp:721-727), head-major cache: for later evals
-                    cache[((size_t)head * p.P + pos) * DK + d] = v;
+                                           : ((which == 1) ? kc_ : vc_);    // KV append (biogpt.cpp:721-727), head-major cache: for later evals
+                    ((__attribute__((address_space(1))) float *)cache)[((size_t)head * p.P + pos) * DK + d] = v;
                 }
             }
             XC_WALL(1);
@@ -326,7 +328,7 @@ __device__ __forceinline__ void xc_run(const XcParams &p, unsigned char *smem, c
             float4 kr2[SEG2 ? NF4 : 1];
             float vr2[SEG2 ? NV : 1];
             if constexpr (SEG2) {
-                const float *kb = p.layers[L].kcache + (size_t)head * p.P * DK, *vb = p.layers[L].vcache + (size_t)head * p.P * DK;
+                const float *kb = XPL(L).kcache + (size_t)head * p.P * DK, *vb = XPL(L).vcache + (size_t)head * p.P * DK;
                 const __amdgpu_buffer_rsrc_t krs = xp_kv_rsrc(kb, p.P * DK * 4), vrs = xp_kv_rsrc(vb, p.P * DK * 4);
                 const int ko = ((kidx + 256) * DK + 4 * ksub) * 4, vo = ((256 + sl) * DK + dd) * 4;
 #pragma unroll

@@ -71,11 +71,11 @@ __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t 
     if constexpr (CROSS) {
         xp_u64 cur[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
         for (uint32_t spins = 0;; spins++) {
             xp_u64 nxt[N];
 #pragma unroll
-            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < N; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void xl_sweep(const xp_u64 *g, bool active, uint32_t 
         if (active) {
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                const xp_u64 a = __hip_atomic_load((xp_gq)g + k * S, XP_RLX);
                 v[k] = (uint32_t)a;
                 ok &= (uint32_t)(a >> 32) == epoch;
             }
@@ -155,7 +155,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         if (hx_j0 <= n_past) {          // the range is, or becomes, active with this token
-            const XpLayer &Y = p.layers[L];
+            const XpLayerK &Y = XPL(L);
             const int ksub = tid & (LPK - 1), kidx = tid / LPK, dd = tid & (DK - 1), sl = tid >> 6;
             // streaming loads (kernels_xpipe.hip.h, xp_kv_load*<false>): the rows of this range that were appended during the launch were appended by THIS workgroup
             const float *kb = Y.kcache + (size_t)hx_head * P * DK, *vb = Y.vcache + (size_t)hx_head * P * DK;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
         if (hx_j0 < T) {
-            const XpLayer &Y = p.layers[L];
+            const XpLayerK &Y = XPL(L);
             xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
             xp_u64 *const GL = p.gran_l + (size_t)L * XL_G_LAYER;
             const bool has_new = n_past < hx_j0 + KR;                  // (and n_past >= hx_j0): this range holds the token's own key
@@ -252,8 +252,8 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                 xl_sweep<RES, 1, 1, true>(G + XP_G_QKV + wave * 1024 + hx_head * 64 + lane, true, epoch, v, p, s_dead);
                 s_cur[tid] = __uint_as_float(v[0]);
                 if (wave != 0) {
-                    float *cache = (wave == 1) ? Y.kcache : Y.vcache;
-                    cache[((size_t)hx_head * P + n_past) * DK + lane] = __uint_as_float(v[0]);
+                    float *kc_ = Y.kcache, *vc_ = Y.vcache;
+                    ((__attribute__((address_space(1))) float *)((wave == 1) ? kc_ : vc_))[((size_t)hx_head * P + n_past) * DK + lane] = __uint_as_float(v[0]);
                 }
             }
             __syncthreads();
@@ -395,7 +395,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), sub = lane & 31, rsub = lane >> 5;
             const bool worker = tid < 256;
-            const XpLayer &Y = p.layers[L];
+            const XpLayerK &Y = XPL(L);
             auto sel = [&](const int unit) -> bool {      // ROLE 0: units 0-11 q/k/v, 12-13 out_proj; ROLE 1: 12-13; ROLE 2: 0-7 fc1, 8 + 2 r + it fc2
                 if (part < 0) return true;
                 if (ROLE == 2) return part == 0 ? (unit < 4 || (unit >> 1) == 4) : part == 1 ? ((unit >= 4 && unit < 8) || (unit >> 1) == 5) : unit >= 12;
@@ -404,14 +404,14 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             if (part <= 0) {      // the small vectors travel with the first part
                 float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
                 if (worker) {
-                    if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
-                    else { l0 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
+                    if (FIRST) { l0 = xp_ldg4(Y.ln0_w, tid); l1 = xp_ldg4(Y.ln0_b, tid); }
+                    else { l0 = xp_ldg4(Y.ln1_w, tid); l1 = xp_ldg4(Y.ln1_b, tid); }
                 }
                 float bv = 0.0f;
-                if (tid < 192) { if (ROLE == 0) bv = Y.bqkv[(tid >> 6) * 1024 + slot * 64 + (tid & 63)]; }
-                else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
-                else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
-                else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
+                if (tid < 192) { if (ROLE == 0) bv = ((xp_gf)Y.bqkv)[(tid >> 6) * 1024 + slot * 64 + (tid & 63)]; }
+                else if (tid < 224) { if (FIRST) bv = ((xp_gf)Y.bo)[slot * 32 + tid - 192]; }
+                else if (tid < 352) { if (SECOND) bv = ((xp_gf)Y.b1)[slot * 128 + tid - 224]; }
+                else if (tid < 384) { if (SECOND) bv = ((xp_gf)Y.b2)[slot * 32 + tid - 352]; }
                 if (worker) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
                 if (tid < 384) s_bias[tid] = bv;
             }
@@ -419,23 +419,23 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int s = 0; s < QS; s++) {
                     const int jj = s * 2 * NW + wave * 2 + rsub;
-                    if (sel(s)) load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + slot * 64 + (jj & 63)) * 32 + sub);
+                    if (sel(s)) load_unit<WT>(wqkv[s], XPL_MATRIX(Y.Wqkv), (int64_t)((jj >> 6) * 1024 + slot * 64 + (jj & 63)) * 32 + sub);
                 }
             }
             if constexpr (FIRST) {
 #pragma unroll
                 for (int s = 0; s < OS; s++)
-                    if (sel(12 + s)) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                    if (sel(12 + s)) load_unit<WT>(wo[s], XPL_MATRIX(Y.Wo), (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
             }
             if constexpr (SECOND) {
 #pragma unroll
                 for (int s = 0; s < FS; s++)
-                    if (sel(s)) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                    if (sel(s)) load_unit<WT>(w1[s], XPL_MATRIX(Y.W1), (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
 #pragma unroll
                 for (int r = 0; r < F2R; r++)
 #pragma unroll
                     for (int it = 0; it < 2; it++)
-                        if (sel(8 + 2 * r + it)) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+                        if (sel(8 + 2 * r + it)) load_unit<WT>(w2[r][it], XPL_MATRIX(Y.W2), (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
             }
             // unpacked right here: the wait for the loads falls into this workgroup's idle time
             if constexpr (ROLE == 0) {
@@ -605,7 +605,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         }
                     } else if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256, true>(p.layers[L - 1].gx + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256, true>(XPL(L - 1).gx + tid, true, epoch, v, p, s_dead);
                         xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                     }
                     if (worker) reinterpret_cast<float4 *>(s_x)[tid] = xv;      // residual of stage C
@@ -685,7 +685,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                         if (lane < 2 * OS) {
                             const int lr = (lane >> 1) * 2 * NW + wave * 2 + (lane & 1), row = slot * 32 + lr;
                             const float v = __fadd_rn(__fadd_rn(sum32_in_order(part + lane * DEC_PS), s_bias[192 + lr]), s_x[row]);
-                            xp_put(p.layers[L].gx1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
+                            xp_put(XPL(L).gx1 + xp_col_slot(row), epoch, __float_as_uint(v));       // the MLP half runs on the next XCD
                         }
                     }
                     XL_WALL(3);
@@ -700,7 +700,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                     float4 x1v = make_float4(0.f, 0.f, 0.f, 0.f), lnw = x1v, lnb = x1v;
                     if (wave < 4) {
                         uint32_t v[4];
-                        xl_sweep<RES, 4, 256, true>(p.layers[L].gx1 + tid, true, epoch, v, p, s_dead);
+                        xl_sweep<RES, 4, 256, true>(XPL(L).gx1 + tid, true, epoch, v, p, s_dead);
                         x1v = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
                         reinterpret_cast<float4 *>(s_x1)[tid] = x1v;
                         XL_WALL2(9);
@@ -808,7 +808,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
                             }
                             const int lr = wave * F2R + lane, row = slot * 32 + lr;
                             const float v = __fadd_rn(__fadd_rn(sumf, s_bias[352 + lr]), s_x1[row]);
-                            xp_put(p.layers[L].gx + xp_col_slot(row), epoch, __float_as_uint(v));
+                            xp_put(XPL(L).gx + xp_col_slot(row), epoch, __float_as_uint(v));
                             if (L == n_layer - 1) XPK(x_final)[row] = v;
                         }
                     }
@@ -894,7 +894,7 @@ __device__ __forceinline__ void xl_run(const XpParams &p, unsigned char *smem, c
             }
             if (wave < 4) {
                 uint32_t v[4];
-                xl_sweep<RES, 4, 256, true>(p.layers[n_layer - 1].gx + tid, true, epoch, v, p, s_dead);
+                xl_sweep<RES, 4, 256, true>(XPL(n_layer - 1).gx + tid, true, epoch, v, p, s_dead);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             ln4_q8_1024<TI::q81, TI::q81>(xv, lnw, lnb, p.eps, s_red, s_xq, s_xd, s_xs);

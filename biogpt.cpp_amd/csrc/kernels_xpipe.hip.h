@@ -65,6 +65,18 @@ constexpr int XP_G_H = XP_G_X1 + 1024;         // [1024] 4 x int8, [128] scale, 
 constexpr int XP_G_X = XP_G_H + 1280;          // [1024] the layer's OUTPUT (unused since round 4: XpLayer::gx)
 constexpr int XP_G_LAYER = XP_G_X + 1024;
 
+// The layer table is read through the CONSTANT address space (scalar loads), and what its pointers lead to through the GLOBAL one.  Through generic pointers hipcc cannot
+// prove that the kernel's own stores leave the table alone: every `XPL(L).field` was a VECTOR load of the field + s_waitcnt vmcnt(0) in front of its use -- in front of
+// every poll sweep of a stage -- and every access through such a pointer a FLAT one, behind which every wait of the wave is a vmcnt(0) (round 6, found in kernels_fpipe.hip.h).
+typedef const XpLayer __attribute__((address_space(4))) XpLayerK;
+#define XPL(L_) (((const XpLayerK *)p.layers)[L_])
+#define XPL_MATRIX(m_) DevMatrix{(m_).qs, (m_).sc, (m_).qh, (m_).type, (m_).M, (m_).K}
+typedef const xp_u64 __attribute__((address_space(1))) *xp_gq;      // granules (polls)
+typedef xp_u64 __attribute__((address_space(1))) *xp_gw;            // granules (publication)
+typedef const float __attribute__((address_space(1))) *xp_gf;
+typedef const xp_v4f __attribute__((address_space(1))) *xp_gf4;      // (an ext-vector: HIP's float4 class cannot be copied out of an address space)
+__device__ __forceinline__ float4 xp_ldg4(const float *q, int i) { const xp_v4f t = ((xp_gf4)q)[i]; return make_float4(t.x, t.y, t.z, t.w); }
+
 struct XpParams {
     const XpLayer *layers;
     int32_t n_layer;
@@ -148,13 +160,13 @@ __device__ __forceinline__ XpKernargPtr xp_kernarg() {
 #define XPK_MATRIX(field) DevMatrix{XPK(field.qs), XPK(field.sc), XPK(field.qh), XPK(field.type), XPK(field.M), XPK(field.K)}
 
 // to ANOTHER XCD (the layer output): write-through (sc1) store, visible at the memory side
-__device__ __forceinline__ void xp_put(xp_u64 *g, uint32_t epoch, uint32_t v) { __hip_atomic_store(g, ((xp_u64)epoch << 32) | v, XP_RLX); }
+__device__ __forceinline__ void xp_put(xp_u64 *g, uint32_t epoch, uint32_t v) { __hip_atomic_store((xp_gw)g, ((xp_u64)epoch << 32) | v, XP_RLX); }
 // inside the XCD (every other hand-off): a plain 8-byte store keeps the line in the XCD's L2, where the pollers' sc1 loads
 // (L1 bypassed, L2 served) find it -- tools/microbench11.hip: 4.7 us per layer for the six hand-offs against 7.0 with
 // write-through stores, which drop the line and send every poll of 32 workgroups across the fabric.  Valid only because
 // producer and consumers share ONE L2: that is what the XCC_ID check at the top of the kernel establishes.
 __device__ __forceinline__ void xp_put_local(xp_u64 *g, uint32_t epoch, uint32_t v) {
-    __hip_atomic_store(g, ((xp_u64)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store((xp_gw)g, ((xp_u64)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // x / x1 columns are stored so that LayerNorm worker t (elements 4t .. 4t+3) polls granules t, t + 256, t + 512, t + 768:
 // every poll instruction of a wave covers 512 contiguous bytes
@@ -227,11 +239,11 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
     if constexpr (CROSS) {      // two passes in flight (xp_sweep_pipelined), with the resident launch's exits
         xp_u64 cur[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
         for (uint32_t spins = 0;; spins++) {
             xp_u64 nxt[N];
 #pragma unroll
-            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+            for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < N; k++) { ok &= (uint32_t)(cur[k] >> 32) == epoch; }
@@ -251,7 +263,7 @@ __device__ __forceinline__ void xp_sweep_q(const xp_u64 *g, bool active, uint32_
         if (active) {
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                const xp_u64 a = __hip_atomic_load((xp_gq)g + k * S, XP_RLX);
                 v[k] = (uint32_t)a;
                 ok &= (uint32_t)(a >> 32) == epoch;
             }
@@ -268,11 +280,11 @@ template <int N, int S>
 __device__ __forceinline__ void xp_sweep_pipelined(const xp_u64 *g, bool active, uint32_t epoch, uint32_t (&v)[N], const XpParams &p) {
     xp_u64 cur[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+    for (int k = 0; k < N; k++) cur[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
     for (uint32_t spins = 0;; spins++) {
         xp_u64 nxt[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load(g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
+        for (int k = 0; k < N; k++) nxt[k] = active ? __hip_atomic_load((xp_gq)g + k * S, XP_RLX) : ((xp_u64)epoch << 32);
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < N; k++) { v[k] = (uint32_t)cur[k]; ok &= (uint32_t)(cur[k] >> 32) == epoch; }
@@ -291,7 +303,7 @@ __device__ __forceinline__ void xp_sweep(const xp_u64 *g, bool active, uint32_t 
         if (active) {
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const xp_u64 a = __hip_atomic_load(g + k * S, XP_RLX);
+                const xp_u64 a = __hip_atomic_load((xp_gq)g + k * S, XP_RLX);
                 v[k] = (uint32_t)a;
                 ok &= (uint32_t)(a >> 32) == epoch;
             }
@@ -323,14 +335,14 @@ __device__ __forceinline__ float4 xp_kv_load4(__amdgpu_buffer_rsrc_t r, const fl
         const xp_v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, XP_CPOL_SC1);
         return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
     } else {
-        const xp_v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const xp_v4f *>(base + elem));
+        const xp_v4f t4 = __builtin_nontemporal_load((const __attribute__((address_space(1))) xp_v4f *)(base + elem));
         return make_float4(t4.x, t4.y, t4.z, t4.w);
     }
 }
 template <bool SC1>
 __device__ __forceinline__ float xp_kv_load1(__amdgpu_buffer_rsrc_t r, const float *base, int elem) {
     if constexpr (SC1) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, XP_CPOL_SC1));
-    else return __builtin_nontemporal_load(base + elem);
+    else return __builtin_nontemporal_load((xp_gf)(base + elem));
 }
 
 // arg-max steps without the LDS crossbar (round 4: __shfl_xor is a ds_bpermute, ~120 cycles per step; a DPP move is one VALU instruction): the larger value wins,
@@ -518,7 +530,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         if (tk == 0 && U == xcd && U >= 2) {      // start this XCD's first weight load when unit U - 1 starts, not all eight at once
             if (tid == 0) {
                 // the output of unit U - 2: a layer's x, or (split layers, U - 2 has U's parity) the first half's x1 / the second half's x
-                const xp_u64 *g = SPLIT ? (ROLE != 2 ? p.layers[L - 1].gx1 : p.layers[L - 1].gx) : p.layers[L - 2].gx;
+                const xp_u64 *g = SPLIT ? (ROLE != 2 ? XPL(L - 1).gx1 : XPL(L - 1).gx) : XPL(L - 2).gx;
                 for (uint32_t spins = 0;; spins++) {
                     if ((uint32_t)(__hip_atomic_load(g, XP_RLX) >> 32) == epoch) break;
                     if (spins >= XP_SPIN_MAX) { xp_fail(p, 3u); break; }
@@ -528,7 +540,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
             }
             __syncthreads();
         }
-        const XpLayer &Y = p.layers[L];
+        const XpLayerK &Y = XPL(L);
         xp_u64 *const G = p.gran + (size_t)L * XP_G_LAYER;
         // ---- this layer's weights into registers, its small vectors into LDS: issued as soon as the previous layer of this
         //      XCD is done, i.e. seven layers ahead of their use.  Workgroups 0-15 are the layer's attention heads and hold the
@@ -539,25 +551,25 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         {
             float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0;
             if (worker) {
-                if (FIRST) { l0 = reinterpret_cast<const float4 *>(Y.ln0_w)[tid]; l1 = reinterpret_cast<const float4 *>(Y.ln0_b)[tid]; }
-                if (SECOND) { l2 = reinterpret_cast<const float4 *>(Y.ln1_w)[tid]; l3 = reinterpret_cast<const float4 *>(Y.ln1_b)[tid]; }
+                if (FIRST) { l0 = xp_ldg4(Y.ln0_w, tid); l1 = xp_ldg4(Y.ln0_b, tid); }
+                if (SECOND) { l2 = xp_ldg4(Y.ln1_w, tid); l3 = xp_ldg4(Y.ln1_b, tid); }
             }
             float bv = 0.0f;
-            if (tid < 192) { if (FIRST) bv = Y.bqkv[(tid >> 6) * 1024 + head * 64 + (tid & 63)]; }
-            else if (tid < 224) { if (FIRST) bv = Y.bo[slot * 32 + tid - 192]; }
-            else if (tid < 352) { if (SECOND) bv = Y.b1[slot * 128 + tid - 224]; }
-            else if (tid < 384) { if (SECOND) bv = Y.b2[slot * 32 + tid - 352]; }
+            if (tid < 192) { if (FIRST) bv = ((xp_gf)Y.bqkv)[(tid >> 6) * 1024 + head * 64 + (tid & 63)]; }
+            else if (tid < 224) { if (FIRST) bv = ((xp_gf)Y.bo)[slot * 32 + tid - 192]; }
+            else if (tid < 352) { if (SECOND) bv = ((xp_gf)Y.b1)[slot * 128 + tid - 224]; }
+            else if (tid < 384) { if (SECOND) bv = ((xp_gf)Y.b2)[slot * 32 + tid - 352]; }
             if (FIRST) {
 #pragma unroll
-                for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], Y.Wo, (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < OS; s++) load_unit<WT>(wo[s], XPL_MATRIX(Y.Wo), (int64_t)(slot * 32 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
             }
             if (SECOND) {
 #pragma unroll
-                for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], Y.W1, (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
+                for (int s = 0; s < FS; s++) load_unit<WT>(w1[s], XPL_MATRIX(Y.W1), (int64_t)(slot * 128 + s * 2 * NW + wave * 2 + rsub) * 32 + sub);
 #pragma unroll
                 for (int r = 0; r < F2R; r++)
 #pragma unroll
-                    for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], Y.W2, (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
+                    for (int it = 0; it < 2; it++) load_unit<WT>(w2[r][it], XPL_MATRIX(Y.W2), (int64_t)(slot * 32 + wave * F2R + r) * 128 + lane + 64 * it);
             }
             if (worker) {
                 if (FIRST) { reinterpret_cast<float4 *>(s_ln)[tid] = l0; reinterpret_cast<float4 *>(s_ln + 1024)[tid] = l1; }
@@ -752,7 +764,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 }
             } else if (wave < 4) {
                 uint32_t v[4];
-                xp_sweep_q<RES, 4, 256, true>(p.layers[L - 1].gx + tid, true, epoch, v, p, etag);
+                xp_sweep_q<RES, 4, 256, true>(XPL(L - 1).gx + tid, true, epoch, v, p, etag);
                 xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             // the waves that took the layer input in tell the others whether it was real (waves 4-7 sweep nothing here, yet their lanes append K / V rows):
@@ -778,7 +790,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
             for (int s = Q0; s < QS; s++) {
                 const int jj = s * 2 * NW + wave * 2 + rsub;
-                load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+                load_unit<WT>(wqkv[s], XPL_MATRIX(Y.Wqkv), (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
             }
 #pragma unroll
             for (int s = Q0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
@@ -809,8 +821,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                 if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                 xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
                 if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
-                    float *cache = (which == 1) ? Y.kcache : Y.vcache;
-                    cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                    float *kc_ = Y.kcache, *vc_ = Y.vcache;
+                    asm volatile("" : "+s"(kc_), "+s"(vc_));      // both by scalar loads (a per-lane choice of the table's FIELD is a vector load of the pointer)
+                    ((__attribute__((address_space(1))) float *)((which == 1) ? kc_ : vc_))[((size_t)head * p.P + n_past) * DK + d] = v;
                 }
             }
             XP_WALL(1);
@@ -846,7 +859,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int s = 0; s < QS; s++) {
                     const int jj = s * 2 * NW + wave * 2 + rsub;
-                    load_unit<WT>(wqkv[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+                    load_unit<WT>(wqkv[s], XPL_MATRIX(Y.Wqkv), (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
                 }
 #pragma unroll
                 for (int s = 0; s < QS; s++) xp_settle<WT, EXPAND>(wqkv[s]);
@@ -879,8 +892,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     if (which == 0) v = __fmul_rn(v, p.q_scale);                   // Q scaled AFTER the bias (biogpt.cpp:708-710)
                     s_cur[jj] = v;
                     if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
-                        float *cache = (which == 1) ? Y.kcache : Y.vcache;
-                        cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                        float *kc_ = Y.kcache, *vc_ = Y.vcache;
+                        asm volatile("" : "+s"(kc_), "+s"(vc_));      // both by scalar loads (a per-lane choice of the table's FIELD is a vector load of the pointer)
+                        ((__attribute__((address_space(1))) float *)((which == 1) ? kc_ : vc_))[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
                 }
                 XP_WALL(1);
@@ -891,7 +905,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int s = 0; s < QH; s++) {
                     const int jj = (HI * QH + s) * 2 * NW + wave * 2 + rsub;
-                    load_unit<WT>(wq[s], Y.Wqkv, (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
+                    load_unit<WT>(wq[s], XPL_MATRIX(Y.Wqkv), (int64_t)((jj >> 6) * 1024 + head * 64 + (jj & 63)) * 32 + sub);
                 }
 #pragma unroll
                 for (int s = 0; s < QH; s++) xp_settle<WT, EXPAND>(wq[s]);
@@ -923,8 +937,9 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
                     s_cur[jj] = v;
                     xp_put_local(G + XP_G_QKV + which * 1024 + head * 64 + d, etag, __float_as_uint(v));
                     if (which != 0 && (!RES || (etag != 0u && (s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]) == 0u))) {      // KV append (biogpt.cpp:721-727), head-major cache; never from a draining launch
-                        float *cache = (which == 1) ? Y.kcache : Y.vcache;
-                        cache[((size_t)head * p.P + n_past) * DK + d] = v;
+                        float *kc_ = Y.kcache, *vc_ = Y.vcache;
+                        asm volatile("" : "+s"(kc_), "+s"(vc_));      // both by scalar loads (a per-lane choice of the table's FIELD is a vector load of the pointer)
+                        ((__attribute__((address_space(1))) float *)((which == 1) ? kc_ : vc_))[((size_t)head * p.P + n_past) * DK + d] = v;
                     }
                 }
                 XP_WALL(1);
@@ -942,7 +957,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
 #pragma unroll
                 for (int s = 0; s < Q0; s++) {
                     const int jj = s * 2 * NW + wave * 2 + rsub;      // < 64: a q row
-                    load_unit<WT>(wq[s], Y.Wqkv, (int64_t)(head * 64 + jj) * 32 + sub);
+                    load_unit<WT>(wq[s], XPL_MATRIX(Y.Wqkv), (int64_t)(head * 64 + jj) * 32 + sub);
                 }
 #pragma unroll
                 for (int s = 0; s < Q0; s++) xp_settle<WT, EXPAND>(wq[s]);
@@ -1372,7 +1387,7 @@ __device__ __forceinline__ void xp_run(const XpParams &p, unsigned char *smem, c
         }
         if (wave < 4) {
             uint32_t v[4];
-            xp_sweep_q<RES, 4, 256, true>(p.layers[p.n_layer - 1].gx + tid, true, epoch, v, p, etag);
+            xp_sweep_q<RES, 4, 256, true>(XPL(p.n_layer - 1).gx + tid, true, epoch, v, p, etag);
             xv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             if (lm_rank == 0) XP_TAIL(tk, 1);
         }
