@@ -213,7 +213,7 @@ struct EngineOptions {
         eval_sync = get("BIOGPT_HIP_EVAL_SYNC", 0);
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
         xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays, resident launches): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
-        fpipe_lead = get("BIOGPT_HIP_FPIPE_LEAD", 24);       // the persistent float launch: 64-clock units a polling wave lets pass between its own workgroup's publication and its first sweep
+        fpipe_lead = get("BIOGPT_HIP_FPIPE_LEAD", -1);       // the persistent float launch: 64-clock units a polling wave lets pass between its own workgroup's publication and its first sweep (-1: 26 for F32 files, 16 for F16 -- the measured optima, profiles/fpipe_lead_scan_r6.txt)
         fpipe_stamps = get("BIOGPT_HIP_FPIPE_STAMPS", 0);   // diagnostics: the persistent launch records stage-border times of three workgroups (biogpt_hip_fpipe_stamps)
         fpipe = get("BIOGPT_HIP_FPIPE", 1);                 // single-token steps of F32 / F16 files as ONE persistent launch for all layers (kernels_fpipe.hip.h); 0: five launches per layer
         xcols = get("BIOGPT_HIP_XCOLS", 1);                 // evals of 2 .. 8 tokens (the reference's prompt chunks) as ONE persistent launch, one column per XCD (kernels_xcols.hip.h); 0: the launch chain of kernels_fast.hip.h
@@ -930,7 +930,7 @@ bool enqueue_fpipe(biogpt_hip_ctx *c) {
     fp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
     fp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
     if (c->unsynced_from < 0) c->unsynced_from = c->state_n_past;
-    fp.lead = c->opt.fpipe_lead;
+    fp.lead = c->opt.fpipe_lead >= 0 ? c->opt.fpipe_lead : (c->plan.layers[0].qkv.type == T_F32 ? 26 : 16);
     fp.stamps = c->opt.fpipe_stamps ? reinterpret_cast<unsigned long long *>(c->fp_ctl + 16) : nullptr;
     c->fp_launches++;
     HIP_TRY(false, (hipError_t)bg_fpipe_launch(c->plan.layers[0].qkv.type == T_F32 ? 0 : 1, c->stream, &fp, sizeof(fp)));
