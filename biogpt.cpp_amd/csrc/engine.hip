@@ -176,7 +176,7 @@ int env_int(const char *name, int dflt) {
 // biogpt_hip_refresh_options): no getenv on any launch path.
 struct EngineOptions {
     int mv_waves, max_wgs, lm_steps, fast_steps, no_fast, no_chain, mfma_min_cols, attn_group_min,
-        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, proc_lock, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, fpipe, fpipe_stamps, fpipe_lead;
+        split_min, attn_slim_min, dbg, target_wgs, prompt_cols, no_graph, causal, no_fused_decode, fc1_blocks, fc2_waves, oproj_waves, attn_tile, eval_graph_split, qkv_waves, fc1_waves, attn_waves, xpipe, xpipe_fault, xpipe_tables, xpipe_lm, xpipe_multi, xpipe_long, xpipe_dual, xpipe_as_res, proc_lock, graph_contended, fault_stale, xcols, resident, resident_us, res_dbg, res_spec, no_fdec, lm_stream, hop_place, verbose, topk_blocks, eval_sync, fpipe, fpipe_stamps, fpipe_lead, fpipe_fault;
     void load() {
         auto get = [](const char *name, int dflt) { return env_int(name, dflt); };
         mv_waves = get("BIOGPT_HIP_MV_WAVES", 4);
@@ -214,6 +214,7 @@ struct EngineOptions {
         topk_blocks = get("BIOGPT_HIP_TOPK_BLOCKS", 1);    // biogpt_hip_eval_topk behind a resident launch: select from the blocks whose maximum can hold a candidate (0: scan the whole row)
         xpipe_dual = get("BIOGPT_HIP_XPIPE_DUAL", 1);       // contexts of 257 .. 512 keys (multi-token launches, graph replays, resident launches): dec_xpipe_kernel with two workgroups per head (0: kernels_xlong.hip.h, as in round 3)
         fpipe_lead = get("BIOGPT_HIP_FPIPE_LEAD", -1);       // the persistent float launch: 64-clock units a polling wave lets pass between its own workgroup's publication and its first sweep (-1: 26 for F32 files, 16 for F16 -- the measured optima, profiles/fpipe_lead_scan_r6.txt)
+        fpipe_fault = get("BIOGPT_HIP_FPIPE_FAULT", 0);     // test hook: the context's first persistent float launch never gets one workgroup's out_proj rows and drains with an error
         fpipe_stamps = get("BIOGPT_HIP_FPIPE_STAMPS", 0);   // diagnostics: the persistent launch records stage-border times of three workgroups (biogpt_hip_fpipe_stamps)
         fpipe = get("BIOGPT_HIP_FPIPE", 1);                 // single-token steps of F32 / F16 files as ONE persistent launch for all layers (kernels_fpipe.hip.h); 0: five launches per layer
         xcols = get("BIOGPT_HIP_XCOLS", 1);                 // evals of 2 .. 8 tokens (the reference's prompt chunks) as ONE persistent launch, one column per XCD (kernels_xcols.hip.h); 0: the launch chain of kernels_fast.hip.h
@@ -930,6 +931,7 @@ bool enqueue_fpipe(biogpt_hip_ctx *c) {
     fp.exp_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.exp_tab);
     fp.gelu_tab = reinterpret_cast<const uint16_t *>(c->arena + c->plan.gelu_tab);
     if (c->unsynced_from < 0) c->unsynced_from = c->state_n_past;
+    fp.fault = (c->opt.fpipe_fault && c->fp_launches == 0) ? 1 : 0;
     fp.lead = c->opt.fpipe_lead >= 0 ? c->opt.fpipe_lead : (c->plan.layers[0].qkv.type == T_F32 ? 26 : 16);
     fp.stamps = c->opt.fpipe_stamps ? reinterpret_cast<unsigned long long *>(c->fp_ctl + 16) : nullptr;
     c->fp_launches++;

@@ -60,6 +60,7 @@ struct FpParams {
     float eps, q_scale;
     int32_t P;
     const uint16_t *exp_tab, *gelu_tab;
+    int32_t fault;                                 // test hook (BIOGPT_HIP_FPIPE_FAULT): workgroup 255 withholds its out_proj rows of layer 0 -- the launch must drain on its bounded spins
     int32_t lead;                                  // s_sleep units (64 clocks) between "this workgroup's rows of the stage are published" and the first sweep for everybody's
     unsigned long long *stamps;                    // diagnostics (BIOGPT_HIP_FPIPE_STAMPS=1; nullptr otherwise): s_memrealtime (100 MHz) of three workgroups at every stage border, [3][32 layers][32]
 };
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(384) void fpipe_kernel(const FpParams p) {
             FP_STAMP(L, 4);
             if (lane == 0) {
                 const int row = b * 4 + wave;
-                xp_put(p.g_x1 + row, tag, __float_as_uint(__fadd_rn(__fadd_rn(v, s_bl[12 + wave]), s_x0[row])));
+                if (!(p.fault && b == 255 && L == 0)) xp_put(p.g_x1 + row, tag, __float_as_uint(__fadd_rn(__fadd_rn(v, s_bl[12 + wave]), s_x0[row])));
                 if (wave == 0) *s_flag = 1u + 4u * (uint32_t)L + 1u;
             }
             // the head's rows of the next layer (the LDS they land in is free once the attention stage is over).  (At the top of fc1's stage instead -- further from this

@@ -124,3 +124,31 @@ def test_full_model_f32_24_layers(pkg, oracle, tmp_path_factory, monkeypatch):
     print("F32 x 24 layers: %d steps, worst |diff| vs oracle %.2e, %d bit-identical" % (steps, worst, exact))
     assert worst <= ATOL and g.fpipe_launches() == 16
     g.close(); ref.close()
+
+
+def test_a_persistent_float_launch_that_never_completes_is_repeated_on_five_launches(pkg, files, monkeypatch, capfd):
+    """BIOGPT_HIP_FPIPE_FAULT=1: in the context's first persistent launch one workgroup withholds its out_proj rows of layer 0 -- what a launch whose workgroups are not all
+    resident looks like.  The launch must drain on its bounded spins, the call must be repeated transparently on the five-launch layer with the undisturbed logits and K / V
+    rows, and the context must stay off the persistent launch."""
+    ref = pkg.BiogptModel.load(files["f32"])
+    if ref.fpipe_launches() < 0:
+        pytest.skip("the persistent float-weight launch is not available on this device")
+    prompt = [2, 100, 200, 300, 400, 500]
+    ref.eval(prompt, 0)
+    want = ref.eval([7], 6)
+    want_kv = _kv(ref, 6)
+    want2 = ref.eval([9], 7)
+    ref.close()
+    monkeypatch.setenv("BIOGPT_HIP_FPIPE_FAULT", "1")
+    g = pkg.BiogptModel.load(files["f32"])
+    monkeypatch.delenv("BIOGPT_HIP_FPIPE_FAULT")
+    assert g.fpipe_launches() == 0
+    g.eval(prompt, 0)
+    got = g.eval([7], 6)
+    assert (got == want).all()
+    for a, b in zip(_kv(g, 6), want_kv):
+        assert (a == b).all()
+    assert g.fpipe_launches() == -1
+    assert "five-launch layer" in capfd.readouterr().err
+    assert (g.eval([9], 7) == want2).all()
+    g.close()
